@@ -1,0 +1,135 @@
+/* softmac_hip.h - C ABI of the MI355X-native SoftMAC MPM substep engine (libsoftmac_hip.so).
+ *
+ * The reference exposes this path as a Python class API, not an FFI:
+ *   MPMSimulator            /root/reference/softmac/engine/mpm_simulator.py:16-618
+ *   Primitive / Mesh        /root/reference/softmac/engine/primitive/primitive_base.py:8-336, mesh.py:18-113
+ * Each entry point below names the reference method(s) it replaces.  The Python mirror of those
+ * classes (softmac_amd/engine/) binds this library with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers + sizes, no torch / HIP types in any signature;
+ *   - every function returns 0 on success, a negative smac_status otherwise; the message is
+ *     available from smac_last_error(handle) (or smac_last_error(NULL) for smac_create failures);
+ *   - host arrays are caller-owned, C-contiguous float64 (the reference's public dtype,
+ *     mpm_simulator.py:482-485), copied at the boundary; no pointer is retained after return;
+ *   - a NULL output/input pointer means "skip this field";
+ *   - all device work of a handle is queued on the handle's own HIP stream; only the get_* calls,
+ *     smac_sync and the timer/profile readers block;
+ *   - not re-entrant per handle; distinct handles are independent.
+ */
+#ifndef SOFTMAC_HIP_H
+#define SOFTMAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMAC_ABI_VERSION 1
+#define SMAC_MAX_PRIMS 4
+
+typedef struct smac_sim* smac_handle;
+
+enum smac_status {
+    SMAC_OK = 0,
+    SMAC_ERR_INVALID = -1,   /* bad argument / bad frame index / wrong state */
+    SMAC_ERR_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+    SMAC_ERR_NOMEM = -3,
+    SMAC_ERR_NOGPU = -4      /* no HIP device: the product has no CPU fallback */
+};
+
+/* mpm_simulator.py:4-13 */
+enum { SMAC_MODEL_COROTATED = 0, SMAC_MODEL_NEOHOOKEAN = 1 };
+enum { SMAC_MAT_PLASTIC = 0, SMAC_MAT_ELASTIC = 1, SMAC_MAT_LIQUID = 2 };
+enum { SMAC_CONTACT_GRID = 0, SMAC_CONTACT_PARTICLE = 1, SMAC_CONTACT_MIXED = 2 };
+
+/* Replaces MPMSimulator.__init__ (mpm_simulator.py:17-84).  mu/lam are the already-adjusted
+ * Lame parameters (:41-45); p_vol/p_mass as computed at :34-35. */
+typedef struct smac_config {
+    int32_t abi_version;      /* SMAC_ABI_VERSION */
+    int32_t precision;        /* 32 or 64: storage + arithmetic scalar type of the device path */
+    int32_t device;           /* HIP device ordinal */
+    int32_t n_particles;
+    int32_t n_grid;           /* int(128*quality*0.5), :26-30 */
+    int32_t max_frames;       /* cfg.max_steps: frames 0..max_frames-1 are resident (:53-56) */
+    int32_t grad_enabled;     /* 0: forward only (no adjoint storage) */
+    int32_t substeps;         /* int(env_dt/dt), :52 - enters `life` of the forecast contact (:425) */
+    int32_t ptype;            /* SMAC_MAT_* */
+    int32_t material_model;   /* SMAC_MODEL_* */
+    int32_t collision_type;   /* SMAC_CONTACT_* */
+    int32_t n_control;        /* cfg.n_controllers (:74-77) */
+    int32_t n_primitives;     /* <= SMAC_MAX_PRIMS */
+    int32_t rigid_velocity_control; /* 1: substep() advances primitive poses with forward_kinematics (:329-331, 367-369) */
+    double dt;
+    double mu, lam;
+    double p_vol, p_mass;
+    double gravity[3];
+    double ground_friction;
+    double yield_stress;      /* kept for API parity; the von-Mises path is dead code in the reference (:225) */
+} smac_config;
+
+const char* smac_last_error(smac_handle h);
+int smac_abi_version(void);
+int smac_device_count(void);   /* 0 when no GPU is visible (does not initialise a context) */
+
+int smac_create(const smac_config* cfg, smac_handle* out);
+int smac_destroy(smac_handle h);
+int smac_sync(smac_handle h);
+
+/* ---- particle state IO (mpm_simulator.py:448-574).  x,v: (N,3); F,C: (N,3,3); state: (N,cols). */
+int smac_reset(smac_handle h, const double* state, int cols);                 /* reset :514-519, cols = 3 or 24 */
+int smac_set_frame(smac_handle h, int f, const double* x, const double* v, const double* F, const double* C); /* setframe/set_x/set_v */
+int smac_get_frame(smac_handle h, int f, double* x, double* v, double* F, double* C);                         /* readframe/get_x/get_v */
+int smac_copy_frame(smac_handle h, int src, int dst);                         /* copyframe :468-479 (particles + primitives) */
+int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC);   /* get_grad :570-574 (+F,C) */
+int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC); /* loss kernels' `x.grad[f,i] +=` */
+int smac_clear_grads(smac_handle h);                                          /* ti.ad.clear_all_gradients() */
+int smac_set_control_idx(smac_handle h, const int32_t* idx);                  /* set_control_idx :599-602 */
+int smac_compute_grid_m(smac_handle h, int f, double* grid_m);                /* compute_grid_m_kernel :607-617, (n,n,n) out */
+
+/* ---- the hot path (mpm_simulator.py:320-378).
+ * action: (n_control,3) or NULL.  ext_f_grad: (n_primitives,6) or NULL (set_ext_f_grad :342-344).
+ * action_grad_out: (n_control,3) or NULL - blocks when non-NULL (:378). */
+int smac_substep(smac_handle h, int f, const double* action);
+int smac_substep_grad(smac_handle h, int f, const double* action, const double* ext_f_grad, double* action_grad_out);
+/* Batched forms: frames f0 .. f0+count-1 forward; f0+count-1 down to f0 backward.  One call, no
+ * host round trip between substeps (replaces the python loops at taichi_env.py:101-102,128-131). */
+int smac_substeps(smac_handle h, int f0, int count);
+int smac_substeps_grad(smac_handle h, int f0, int count, const double* ext_f_grad);
+
+/* ---- rigid primitives (primitive_base.py, mesh.py) */
+int smac_prim_upload_sdf(smac_handle h, int prim, const double* sdf, const double* normal, const int32_t res[3],
+                         const double lower[3], const double upper[3], double sdf_dx);          /* mesh.py:35-43 */
+int smac_prim_set_params(smac_handle h, int prim, double friction, double softness, int contact_enabled); /* friction[None], softness[None], primitives_contact[i] */
+int smac_prim_set_state(smac_handle h, int prim, int f_begin, int f_end, const double s13[13]);  /* set_all_states :258-260, frames [f_begin,f_end) */
+int smac_prim_get_state(smac_handle h, int prim, int f, double s13[13]);                         /* get_state :248-251 (+v,w) */
+int smac_prim_get_state_grad(smac_handle h, int prim, int f_begin, int f_end, double g13[13]);   /* sum of get_all_states_grad :262-265 over frames */
+int smac_prim_add_state_grad(smac_handle h, int prim, int f, const double g13[13]);              /* loss kernels' position/v/w .grad[f] += */
+int smac_prim_forward_kinematics(smac_handle h, int prim, int f);                                /* forward_kinematics :280-283 */
+int smac_prim_forward_kinematics_grad(smac_handle h, int prim, int f);                           /* forward_kinematics.grad */
+int smac_prim_get_ext_f(smac_handle h, int prim, double ext_f[6]);                               /* ext_f.to_numpy() */
+int smac_prim_clear_ext_f(smac_handle h, int prim);                                              /* clear_ext_f :183-187 */
+int smac_prim_set_action(smac_handle h, int prim, int s, int n, const double a6[6]);             /* set_action :311-313 */
+int smac_prim_get_action_grad(smac_handle h, int prim, int s, int n, double g6[6]);              /* get_action_grad :315-319 */
+int smac_prim_reset(smac_handle h, int prim);                                                    /* reset :271-275 */
+
+/* ---- measurement (bench.py).  HIP events on the handle's stream. */
+int smac_timer_start(smac_handle h);
+int smac_timer_stop(smac_handle h, double* elapsed_ms);          /* blocks */
+int smac_profile_enable(smac_handle h, int on);                  /* per-kernel event pairs */
+int smac_profile_reset(smac_handle h);
+int smac_profile_count(smac_handle h);                           /* number of kernel classes */
+int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* total_ms, int64_t* launches); /* blocks */
+int smac_count_active_cells(smac_handle h, int f, int64_t* cells); /* cells with grid_m > 0 after P2G of frame f (G_t of SURVEY 8d) */
+
+/* ---- raw device views for the multi-GPU halo exchange (softmac_amd/parallel.py wraps them as
+ * torch tensors for torch.distributed/RCCL; no reference counterpart - SURVEY 8e). */
+int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64_t* n_scalars, int32_t* scalar_bytes);
+int smac_stream_handle(smac_handle h, void** hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTMAC_HIP_H */

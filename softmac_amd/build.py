@@ -1,0 +1,76 @@
+"""Build libsoftmac_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m softmac_amd.build [--force] [--report]
+
+The shared library is written in-tree to softmac_amd/lib/ (git-ignored, but it travels with
+gpurun snapshots).  `--report` also stores hipcc's per-kernel resource usage
+(VGPRs / scratch / occupancy) in softmac_amd/lib/resource_usage.txt.
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+import re
+import subprocess
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+LIBDIR = ROOT / "lib"
+LIB = LIBDIR / "libsoftmac_hip.so"
+SOURCES = [CSRC / "softmac_hip.hip"]
+DEPS = [CSRC / "smac_kernels.hpp", CSRC / "smac_math.hpp", ROOT.parent / "include" / "softmac_hip.h"]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def is_stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + DEPS)
+
+
+def build(force: bool = False, report: bool = False, verbose: bool = True) -> pathlib.Path:
+    if not force and not report and not is_stale():
+        return LIB
+    LIBDIR.mkdir(exist_ok=True)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=fast",
+           "-Wno-unused-value", "-shared", "-fPIC", "-o", str(LIB)] + [str(s) for s in SOURCES]
+    if report:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    if verbose:
+        print("[softmac_amd.build]", " ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed building libsoftmac_hip.so")
+    if report:
+        rows, cur = [], None
+        for line in res.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = {"name": m.group(1)}
+                rows.append(cur)
+            for key in ("VGPRs", "AGPRs", "ScratchSize \\[bytes/lane\\]", "Occupancy \\[waves/SIMD\\]", "LDS Size \\[bytes/block\\]", "SGPRs"):
+                m = re.search(rf"remark:\s+{key}: (\d+)", line)
+                if m and cur is not None:
+                    cur[key.replace("\\", "")] = m.group(1)
+        out = LIBDIR / "resource_usage.txt"
+        with open(out, "w") as fh:
+            for r in rows:
+                name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip() or r["name"]
+                fh.write(f"{name}: " + ", ".join(f"{k}={v}" for k, v in r.items() if k != "name") + "\n")
+        if verbose:
+            print(out.read_text())
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, report="--report" in sys.argv)

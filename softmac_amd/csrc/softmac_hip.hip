@@ -1,0 +1,782 @@
+// libsoftmac_hip.so - C ABI (include/softmac_hip.h) over the HIP kernels in smac_kernels.hpp.
+// Host side only: handle, device memory, launch sequencing, f64 <-> device-layout conversion.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/softmac_hip.h"
+#include "smac_kernels.hpp"
+
+using namespace smac;
+
+static thread_local std::string g_create_error;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            char _b[512];                                                                     \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            this->err = _b;                                                                   \
+            return SMAC_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define REQUIRE(cond, msg)                   \
+    do {                                     \
+        if (!(cond)) {                       \
+            this->err = std::string(msg);    \
+            return SMAC_ERR_INVALID;         \
+        }                                    \
+    } while (0)
+
+enum KernelId { K_CLEAR = 0, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"clear_grid", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "contact_grad",
+                                            "grid_op_grad", "p2g_grad", "forward_kinematics"};
+
+struct ISim {
+    std::string err;
+    virtual ~ISim() {}
+    virtual int init(const smac_config& c) = 0;
+    virtual int sync() = 0;
+    virtual int reset(const double* state, int cols) = 0;
+    virtual int set_frame(int f, const double* x, const double* v, const double* F, const double* C) = 0;
+    virtual int get_frame(int f, double* x, double* v, double* F, double* C) = 0;
+    virtual int copy_frame(int src, int dst) = 0;
+    virtual int get_grad(int f, double* gx, double* gv, double* gF, double* gC) = 0;
+    virtual int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) = 0;
+    virtual int clear_grads() = 0;
+    virtual int set_control_idx(const int32_t* idx) = 0;
+    virtual int compute_grid_m(int f, double* out) = 0;
+    virtual int substep(int f, const double* action) = 0;
+    virtual int substep_grad(int f, const double* action, const double* ext_f_grad, double* action_grad_out) = 0;
+    virtual int prim_upload_sdf(int prim, const double* sdf, const double* normal, const int32_t* res, const double* lower,
+                                const double* upper, double dx) = 0;
+    virtual int prim_set_params(int prim, double friction, double softness, int contact) = 0;
+    virtual int prim_set_state(int prim, int f0, int f1, const double* s13) = 0;
+    virtual int prim_get_state(int prim, int f, double* s13) = 0;
+    virtual int prim_get_state_grad(int prim, int f0, int f1, double* g13) = 0;
+    virtual int prim_add_state_grad(int prim, int f, const double* g13) = 0;
+    virtual int prim_fk(int prim, int f) = 0;
+    virtual int prim_fk_grad(int prim, int f) = 0;
+    virtual int prim_get_ext_f(int prim, double* e6) = 0;
+    virtual int prim_clear_ext_f(int prim) = 0;
+    virtual int prim_set_action(int prim, int s, int n, const double* a6) = 0;
+    virtual int prim_get_action_grad(int prim, int s, int n, double* g6) = 0;
+    virtual int prim_reset(int prim) = 0;
+    virtual int timer_start() = 0;
+    virtual int timer_stop(double* ms) = 0;
+    virtual int profile_enable(int on) = 0;
+    virtual int profile_reset() = 0;
+    virtual int profile_get(int i, char* name, int cap, double* ms, int64_t* launches) = 0;
+    virtual int count_active_cells(int f, int64_t* cells) = 0;
+    virtual int grid_ptr(const char* field, void** p, int64_t* n, int32_t* bytes) = 0;
+    virtual int stream_handle(void** s) = 0;
+};
+
+template <class R> struct Sim final : ISim {
+    smac_config cfg{};
+    DevSim<R> D{};
+    hipStream_t stream = nullptr;
+    R* grid_block = nullptr;      // 20 * G scalars: values (10G) then adjoints (10G)
+    R* prim_tables[SMAC_MAX_PRIMS][2] = {};
+    R* action_buf = nullptr;      // per-primitive velocity-control action buffer [P][max_frames][6] + its grad
+    R* action_buf_grad = nullptr;
+    unsigned long long* d_counter = nullptr;
+    int* d_control_idx = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profiling = false;
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double prof_ms[K_COUNT] = {};
+    int64_t prof_n[K_COUNT] = {};
+    std::vector<R> stage;
+
+    ~Sim() override {
+        if (stream) hipStreamSynchronize(stream);
+        hipFree(D.S); hipFree(D.A); hipFree(grid_block); hipFree(D.prim_state); hipFree(D.prim_grad);
+        hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);
+        hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
+        for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
+        for (auto e : pool) hipEventDestroy(e);
+        for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+        if (t0) hipEventDestroy(t0);
+        if (t1) hipEventDestroy(t1);
+        if (stream) hipStreamDestroy(stream);
+    }
+
+    size_t frame_scalars() const { return (size_t)NCOMP * D.Npad; }
+    int nblk(size_t n) const { return (int)((n + BLOCK - 1) / BLOCK); }
+
+    int init(const smac_config& c) override {
+        cfg = c;
+        REQUIRE(c.n_particles > 0 && c.n_grid >= 8 && c.max_frames >= 2, "bad sizes");
+        REQUIRE(c.n_primitives >= 0 && c.n_primitives <= SMAC_MAX_PRIMS, "n_primitives > SMAC_MAX_PRIMS");
+        REQUIRE(c.substeps >= 1, "substeps < 1");
+        HIP_TRY(hipSetDevice(c.device));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&t0));
+        HIP_TRY(hipEventCreate(&t1));
+        D.N = c.n_particles;
+        D.Npad = (c.n_particles + 255) / 256 * 256;
+        D.n = c.n_grid;
+        D.G = (size_t)c.n_grid * c.n_grid * c.n_grid;
+        D.P = c.n_primitives;
+        D.n_control = c.n_control;
+        D.substeps = c.substeps;
+        D.collision_type = c.collision_type;
+        D.sticky = c.ground_friction >= 10.0 ? 1 : 0;
+        D.max_frames = c.max_frames;
+        D.dt = (R)c.dt;
+        D.inv_dx = (R)c.n_grid;
+        D.dx = (R)(1.0 / c.n_grid);
+        D.p_mass = (R)c.p_mass;
+        D.stress_scale = (R)(-c.dt * c.p_vol * 4.0 * (double)c.n_grid * (double)c.n_grid);    // mpm_simulator.py:247
+        for (int d = 0; d < 3; ++d) D.g[d] = (R)c.gravity[d];
+        D.mat.ptype = c.ptype; D.mat.model = c.material_model; D.mat.mu = (R)c.mu; D.mat.lam = (R)c.lam;
+        const size_t fs = frame_scalars() * sizeof(R);
+        HIP_TRY(hipMalloc((void**)&D.S, fs * c.max_frames));
+        HIP_TRY(hipMemsetAsync(D.S, 0, fs * c.max_frames, stream));
+        if (c.grad_enabled) {
+            HIP_TRY(hipMalloc((void**)&D.A, fs * c.max_frames));
+            HIP_TRY(hipMemsetAsync(D.A, 0, fs * c.max_frames, stream));
+        }
+        HIP_TRY(hipMalloc((void**)&grid_block, 20 * D.G * sizeof(R)));
+        HIP_TRY(hipMemsetAsync(grid_block, 0, 20 * D.G * sizeof(R), stream));
+        R* g = grid_block;
+        D.gm = g; D.gvin = g + D.G; D.gvmix = g + 4 * D.G; D.gvout = g + 7 * D.G;
+        g += 10 * D.G;
+        D.agm = g; D.agvin = g + D.G; D.agvmix = g + 4 * D.G; D.agvout = g + 7 * D.G;
+        const int Pn = c.n_primitives > 0 ? c.n_primitives : 1;
+        const size_t ps = (size_t)Pn * c.max_frames * 13 * sizeof(R);
+        HIP_TRY(hipMalloc((void**)&D.prim_state, ps));
+        HIP_TRY(hipMalloc((void**)&D.prim_grad, ps));
+        HIP_TRY(hipMemsetAsync(D.prim_state, 0, ps, stream));
+        HIP_TRY(hipMemsetAsync(D.prim_grad, 0, ps, stream));
+        HIP_TRY(hipMalloc((void**)&D.ext_f, 2 * Pn * 6 * sizeof(R)));
+        HIP_TRY(hipMemsetAsync(D.ext_f, 0, 2 * Pn * 6 * sizeof(R), stream));
+        D.ext_f_grad = D.ext_f + Pn * 6;
+        const size_t ab = (size_t)Pn * c.max_frames * 6 * sizeof(R);
+        HIP_TRY(hipMalloc((void**)&action_buf, ab));
+        HIP_TRY(hipMalloc((void**)&action_buf_grad, ab));
+        HIP_TRY(hipMemsetAsync(action_buf, 0, ab, stream));
+        HIP_TRY(hipMemsetAsync(action_buf_grad, 0, ab, stream));
+        const int nc = c.n_control > 0 ? c.n_control : 1;
+        HIP_TRY(hipMalloc((void**)&D.action, nc * 3 * sizeof(R)));
+        HIP_TRY(hipMalloc((void**)&D.action_grad, nc * 3 * sizeof(R)));
+        HIP_TRY(hipMemsetAsync(D.action, 0, nc * 3 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(D.action_grad, 0, nc * 3 * sizeof(R), stream));
+        HIP_TRY(hipMalloc((void**)&d_control_idx, D.Npad * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_control_idx, 0, D.Npad * sizeof(int), stream));   // ti.field default 0 (:76)
+        D.control_idx = d_control_idx;
+        HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
+        for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
+            D.prim[i].sdf = nullptr; D.prim[i].normal = nullptr; D.prim[i].contact = 0;
+            D.prim[i].friction = (R)0.9; D.prim[i].softness = (R)666.0; D.prim[i].inv_dx = (R)1;
+            for (int d = 0; d < 3; ++d) { D.prim[i].res[d] = 2; D.prim[i].lower[d] = 0; D.prim[i].upper[d] = 0; }
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+
+    // ---- profiling helpers
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+    void prof_begin(int id) {
+        if (!profiling) return;
+        Rec r{id, get_event(), get_event()};
+        hipEventRecord(r.a, stream);
+        recs.push_back(r);
+    }
+    void prof_end() {
+        if (!profiling) return;
+        hipEventRecord(recs.back().b, stream);
+    }
+    int prof_collect() {
+        if (recs.empty()) return SMAC_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& r : recs) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, r.a, r.b);
+            prof_ms[r.id] += ms; prof_n[r.id] += 1;
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+        return SMAC_OK;
+    }
+    int check_launch() {
+        HIP_TRY(hipGetLastError());
+        return SMAC_OK;
+    }
+
+    int sync() override { HIP_TRY(hipStreamSynchronize(stream)); return SMAC_OK; }
+
+    // ---- IO -----------------------------------------------------------------------------
+    int upload_comp(R* base, int f, int c0, int cnt, const double* src, bool minus_identity) {
+        stage.resize((size_t)cnt * D.Npad);
+        for (int c = 0; c < cnt; ++c) {
+            R* dst = stage.data() + (size_t)c * D.Npad;
+            const double sub = (minus_identity && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
+            for (int p = 0; p < D.N; ++p) dst[p] = (R)(src[(size_t)p * cnt + c] - sub);
+            for (int p = D.N; p < D.Npad; ++p) dst[p] = 0;
+        }
+        R* d = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
+        HIP_TRY(hipMemcpyAsync(d, stage.data(), stage.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int download_comp(const R* base, int f, int c0, int cnt, double* dst, bool plus_identity) {
+        stage.resize((size_t)cnt * D.Npad);
+        const R* s = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
+        HIP_TRY(hipMemcpyAsync(stage.data(), s, stage.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < cnt; ++c) {
+            const R* src = stage.data() + (size_t)c * D.Npad;
+            const double add = (plus_identity && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
+            for (int p = 0; p < D.N; ++p) dst[(size_t)p * cnt + c] = (double)src[p] + add;
+        }
+        return SMAC_OK;
+    }
+    int check_frame(int f) {
+        REQUIRE(f >= 0 && f < cfg.max_frames, "frame index out of range");
+        return SMAC_OK;
+    }
+
+    int set_frame(int f, const double* x, const double* v, const double* F, const double* C) override {
+        int rc = check_frame(f);
+        if (rc) return rc;
+        if (x && (rc = upload_comp(D.S, f, CX, 3, x, false))) return rc;
+        if (v && (rc = upload_comp(D.S, f, CV, 3, v, false))) return rc;
+        if (C && (rc = upload_comp(D.S, f, CC, 9, C, false))) return rc;
+        if (F && (rc = upload_comp(D.S, f, CF, 9, F, true))) return rc;
+        return SMAC_OK;
+    }
+    int get_frame(int f, double* x, double* v, double* F, double* C) override {
+        int rc = check_frame(f);
+        if (rc) return rc;
+        if (x && (rc = download_comp(D.S, f, CX, 3, x, false))) return rc;
+        if (v && (rc = download_comp(D.S, f, CV, 3, v, false))) return rc;
+        if (C && (rc = download_comp(D.S, f, CC, 9, C, false))) return rc;
+        if (F && (rc = download_comp(D.S, f, CF, 9, F, true))) return rc;
+        return SMAC_OK;
+    }
+    int reset(const double* state, int cols) override {                       // mpm_simulator.py:494-519
+        REQUIRE(state && (cols == 3 || cols == 24), "reset: cols must be 3 or 24");
+        const int N = D.N;
+        std::vector<double> x((size_t)N * 3), v((size_t)N * 3, 0.0), F((size_t)N * 9, 0.0), C((size_t)N * 9, 0.0);
+        for (int p = 0; p < N; ++p) {
+            const double* s = state + (size_t)p * cols;
+            for (int j = 0; j < 3; ++j) x[(size_t)p * 3 + j] = s[j];
+            if (cols == 24) {
+                for (int j = 0; j < 3; ++j) v[(size_t)p * 3 + j] = s[3 + j];
+                for (int j = 0; j < 9; ++j) { F[(size_t)p * 9 + j] = s[6 + j]; C[(size_t)p * 9 + j] = s[15 + j]; }
+            } else {
+                F[(size_t)p * 9] = F[(size_t)p * 9 + 4] = F[(size_t)p * 9 + 8] = 1.0;
+            }
+        }
+        return set_frame(0, x.data(), v.data(), F.data(), C.data());
+    }
+    int copy_frame(int src, int dst) override {                               // :468-479
+        int rc;
+        if ((rc = check_frame(src)) || (rc = check_frame(dst))) return rc;
+        if (src == dst) return SMAC_OK;
+        HIP_TRY(hipMemcpyAsync(D.S + (size_t)dst * frame_scalars(), D.S + (size_t)src * frame_scalars(),
+                               frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        for (int i = 0; i < D.P; ++i)
+            for (int j = 0; j < cfg.substeps; ++j) {
+                if (src + j >= cfg.max_frames || dst + j >= cfg.max_frames) break;
+                R* base = D.prim_state + (size_t)i * cfg.max_frames * 13;
+                HIP_TRY(hipMemcpyAsync(base + (size_t)(dst + j) * 13, base + (size_t)(src + j) * 13, 13 * sizeof(R),
+                                       hipMemcpyDeviceToDevice, stream));
+                R* ab = action_buf + (size_t)i * cfg.max_frames * 6;
+                HIP_TRY(hipMemcpyAsync(ab + (size_t)(dst + j) * 6, ab + (size_t)(src + j) * 6, 6 * sizeof(R),
+                                       hipMemcpyDeviceToDevice, stream));
+            }
+        return SMAC_OK;
+    }
+    int need_grad() {
+        REQUIRE(D.A != nullptr, "handle created with grad_enabled = 0");
+        return SMAC_OK;
+    }
+    int get_grad(int f, double* gx, double* gv, double* gF, double* gC) override {
+        int rc;
+        if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
+        if (gx && (rc = download_comp(D.A, f, CX, 3, gx, false))) return rc;
+        if (gv && (rc = download_comp(D.A, f, CV, 3, gv, false))) return rc;
+        if (gC && (rc = download_comp(D.A, f, CC, 9, gC, false))) return rc;
+        if (gF && (rc = download_comp(D.A, f, CF, 9, gF, false))) return rc;
+        return SMAC_OK;
+    }
+    int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) override {
+        int rc;
+        if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
+        const double* src[4] = {gx, gv, gC, gF};
+        const int c0[4] = {CX, CV, CC, CF}, cnt[4] = {3, 3, 9, 9};
+        std::vector<double> cur;
+        for (int a = 0; a < 4; ++a) {
+            if (!src[a]) continue;
+            cur.resize((size_t)D.N * cnt[a]);
+            if ((rc = download_comp(D.A, f, c0[a], cnt[a], cur.data(), false))) return rc;
+            for (size_t i = 0; i < cur.size(); ++i) cur[i] += src[a][i];
+            if ((rc = upload_comp(D.A, f, c0[a], cnt[a], cur.data(), false))) return rc;
+        }
+        return SMAC_OK;
+    }
+    int clear_grads() override {
+        if (D.A) HIP_TRY(hipMemsetAsync(D.A, 0, frame_scalars() * sizeof(R) * cfg.max_frames, stream));
+        const int Pn = D.P > 0 ? D.P : 1;
+        HIP_TRY(hipMemsetAsync(D.prim_grad, 0, (size_t)Pn * cfg.max_frames * 13 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(action_buf_grad, 0, (size_t)Pn * cfg.max_frames * 6 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(D.ext_f_grad, 0, Pn * 6 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(D.action_grad, 0, (D.n_control > 0 ? D.n_control : 1) * 3 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(grid_block + 10 * D.G, 0, 10 * D.G * sizeof(R), stream));
+        return SMAC_OK;
+    }
+    int set_control_idx(const int32_t* idx) override {
+        REQUIRE(idx, "null idx");
+        std::vector<int> tmp(D.Npad, -1);
+        for (int p = 0; p < D.N; ++p) tmp[p] = D.n_control == 0 ? 0 : idx[p];          // :599-602
+        HIP_TRY(hipMemcpyAsync(d_control_idx, tmp.data(), D.Npad * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int compute_grid_m(int f, double* out) override {
+        int rc = check_frame(f);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(D.gm, 0, D.G * sizeof(R), stream));
+        hipLaunchKernelGGL(k_grid_m_only<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
+        if ((rc = check_launch())) return rc;
+        if (out) {
+            std::vector<R> tmp(D.G);
+            HIP_TRY(hipMemcpyAsync(tmp.data(), D.gm, D.G * sizeof(R), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (size_t i = 0; i < D.G; ++i) out[i] = (double)tmp[i];
+        }
+        return SMAC_OK;
+    }
+    int count_active_cells(int f, int64_t* cells) override {
+        int rc = compute_grid_m(f, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(k_count_active<R>, dim3(nblk(D.G)), dim3(BLOCK), 0, stream, D.gm, D.G, d_counter);
+        if ((rc = check_launch())) return rc;
+        unsigned long long h = 0;
+        HIP_TRY(hipMemcpyAsync(&h, d_counter, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *cells = (int64_t)h;
+        return SMAC_OK;
+    }
+
+    // ---- hot path -----------------------------------------------------------------------
+    bool any_contact() const {
+        for (int i = 0; i < D.P; ++i)
+            if (D.prim[i].contact) return true;
+        return false;
+    }
+    int set_action(const double* action) {                                    // :579-592
+        REQUIRE(D.n_control > 0, "action given but n_control == 0");
+        R tmp[3 * 64];
+        REQUIRE(D.n_control <= 64, "n_control > 64");
+        for (int i = 0; i < 3 * D.n_control; ++i) tmp[i] = (R)action[i];
+        HIP_TRY(hipMemcpyAsync(D.action, tmp, 3 * D.n_control * sizeof(R), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemsetAsync(D.action_grad, 0, 3 * D.n_control * sizeof(R), stream));
+        return SMAC_OK;
+    }
+    int check_contact_supported() {
+        if (D.P > 0 && any_contact()) {
+            REQUIRE(D.collision_type == CONTACT_MIXED,
+                    "rigid contact is implemented for collision_type 2 (forecast/mixed) only");
+            for (int i = 0; i < D.P; ++i)
+                if (D.prim[i].contact) REQUIRE(D.prim[i].sdf != nullptr, "contact primitive without an uploaded SDF");
+        }
+        return SMAC_OK;
+    }
+    int forward_grid(int f, bool store_F, bool is_recompute) {
+        int rc;
+        prof_begin(K_CLEAR);
+        // clear_grid :93-114 (values; adjoints are cleared in substep_grad where they are used)
+        hipMemsetAsync(grid_block, 0, 10 * D.G * sizeof(R), stream);
+        prof_end();
+        prof_begin(K_P2G);
+        if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
+        else hipLaunchKernelGGL((k_p2g<R, false>), dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
+        prof_end();
+        if (!is_recompute && cfg.rigid_velocity_control) {                                 // rigid_velocity_control, :329-331
+            for (int i = 0; i < D.P; ++i)
+                if ((rc = prim_fk(i, f))) return rc;
+        }
+        prof_begin(K_GRID_OP);
+        hipLaunchKernelGGL(k_grid_op<R>, dim3(nblk(D.G)), dim3(BLOCK), 0, stream, D);
+        prof_end();
+        if (D.collision_type == CONTACT_MIXED && any_contact()) {
+            prof_begin(K_CONTACT);
+            DevSim<R> Dc = D;
+            if (is_recompute) Dc.ext_f = scratch_ext();
+            hipLaunchKernelGGL(k_contact<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, Dc, f);
+            prof_end();
+        }
+        return check_launch();
+    }
+    // the recompute pass of substep_grad must not double-count ext_f: send its wrench sums to a scratch slot
+    R* scratch = nullptr;
+    R* scratch_ext() {
+        if (!scratch) hipMalloc((void**)&scratch, SMAC_MAX_PRIMS * 6 * sizeof(R));
+        return scratch;
+    }
+    int substep(int f, const double* action) override {
+        int rc;
+        REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
+        if ((rc = check_contact_supported())) return rc;
+        if (action && (rc = set_action(action))) return rc;
+        if ((rc = forward_grid(f, true, false))) return rc;
+        prof_begin(K_G2P);
+        hipLaunchKernelGGL(k_g2p<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
+        prof_end();
+        return check_launch();
+    }
+    int substep_grad(int f, const double* action, const double* ext_f_grad, double* action_grad_out) override {
+        int rc;
+        if ((rc = need_grad())) return rc;
+        REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep_grad: frame f+1 exceeds max_frames");
+        if ((rc = check_contact_supported())) return rc;
+        if (action && (rc = set_action(action))) return rc;
+        if (ext_f_grad && D.P > 0) {                                          // :342-344
+            R tmp[6 * SMAC_MAX_PRIMS];
+            for (int i = 0; i < 6 * D.P; ++i) tmp[i] = (R)ext_f_grad[i];
+            HIP_TRY(hipMemcpyAsync(D.ext_f_grad, tmp, 6 * D.P * sizeof(R), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        prof_begin(K_CLEAR);
+        hipMemsetAsync(grid_block + 10 * D.G, 0, 10 * D.G * sizeof(R), stream);   // grid adjoints, :101-107
+        prof_end();
+        if ((rc = forward_grid(f, false, true))) return rc;                   // :352-359
+        prof_begin(K_G2P_GRAD);
+        hipLaunchKernelGGL(k_g2p_grad<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);   // :361
+        prof_end();
+        if (D.collision_type == CONTACT_MIXED && any_contact()) {             // :362-363, 389-393
+            prof_begin(K_CONTACT_GRAD);
+            hipLaunchKernelGGL(k_contact_grad<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
+            prof_end();
+        }
+        prof_begin(K_GRID_OP_GRAD);
+        hipLaunchKernelGGL(k_grid_op_grad<R>, dim3(nblk(D.G)), dim3(BLOCK), 0, stream, D);   // :394 / :365
+        prof_end();
+        if (cfg.rigid_velocity_control)                                                    // :367-369
+            for (int i = D.P - 1; i >= 0; --i)
+                if ((rc = prim_fk_grad(i, f))) return rc;
+        prof_begin(K_P2G_GRAD);
+        hipLaunchKernelGGL(k_p2g_grad<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);   // :371-374
+        prof_end();
+        if ((rc = check_launch())) return rc;
+        if (action_grad_out && D.n_control > 0) {                             // :378
+            R tmp[3 * 64];
+            HIP_TRY(hipMemcpyAsync(tmp, D.action_grad, 3 * D.n_control * sizeof(R), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (int i = 0; i < 3 * D.n_control; ++i) action_grad_out[i] = (double)tmp[i];
+        }
+        return SMAC_OK;
+    }
+
+    // ---- primitives -----------------------------------------------------------------------
+    int check_prim(int prim) {
+        REQUIRE(prim >= 0 && prim < D.P, "primitive index out of range");
+        return SMAC_OK;
+    }
+    R* pstate(int prim) { return D.prim_state + (size_t)prim * cfg.max_frames * 13; }
+    R* pgrad(int prim) { return D.prim_grad + (size_t)prim * cfg.max_frames * 13; }
+    int prim_upload_sdf(int prim, const double* sdf, const double* normal, const int32_t* res, const double* lower,
+                        const double* upper, double dx) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(sdf && normal && res && lower && upper && dx > 0, "null table");
+        REQUIRE(res[0] >= 2 && res[1] >= 2 && res[2] >= 2, "sdf res < 2");
+        const size_t cells = (size_t)res[0] * res[1] * res[2];
+        std::vector<R> ts(cells), tn(cells * 3);
+        for (size_t i = 0; i < cells; ++i) ts[i] = (R)sdf[i];
+        for (size_t i = 0; i < cells * 3; ++i) tn[i] = (R)normal[i];
+        hipFree(prim_tables[prim][0]); hipFree(prim_tables[prim][1]);
+        HIP_TRY(hipMalloc((void**)&prim_tables[prim][0], cells * sizeof(R)));
+        HIP_TRY(hipMalloc((void**)&prim_tables[prim][1], cells * 3 * sizeof(R)));
+        HIP_TRY(hipMemcpy(prim_tables[prim][0], ts.data(), cells * sizeof(R), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(prim_tables[prim][1], tn.data(), cells * 3 * sizeof(R), hipMemcpyHostToDevice));
+        PrimTable<R>& T = D.prim[prim];
+        T.sdf = prim_tables[prim][0]; T.normal = prim_tables[prim][1];
+        for (int d = 0; d < 3; ++d) { T.res[d] = res[d]; T.lower[d] = (R)lower[d]; T.upper[d] = (R)upper[d]; }
+        T.inv_dx = (R)(1.0 / dx);                                             // mesh.py:29
+        return SMAC_OK;
+    }
+    int prim_set_params(int prim, double friction, double softness, int contact) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        D.prim[prim].friction = (R)friction; D.prim[prim].softness = (R)softness; D.prim[prim].contact = contact ? 1 : 0;
+        return SMAC_OK;
+    }
+    int prim_set_state(int prim, int f0, int f1, const double* s13) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(s13 && f0 >= 0 && f1 <= cfg.max_frames && f0 < f1, "prim_set_state: bad frame range");
+        std::vector<R> tmp((size_t)(f1 - f0) * 13);
+        for (int f = 0; f < f1 - f0; ++f)
+            for (int c = 0; c < 13; ++c) tmp[(size_t)f * 13 + c] = (R)s13[c];
+        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)f0 * 13, tmp.data(), tmp.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int prim_get_state(int prim, int f, double* s13) override {
+        int rc;
+        if ((rc = check_prim(prim)) || (rc = check_frame(f))) return rc;
+        R tmp[13];
+        HIP_TRY(hipMemcpyAsync(tmp, pstate(prim) + (size_t)f * 13, sizeof tmp, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < 13; ++c) s13[c] = (double)tmp[c];
+        return SMAC_OK;
+    }
+    int prim_get_state_grad(int prim, int f0, int f1, double* g13) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(g13 && f0 >= 0 && f1 <= cfg.max_frames && f0 < f1, "prim_get_state_grad: bad frame range");
+        std::vector<R> tmp((size_t)(f1 - f0) * 13);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), pgrad(prim) + (size_t)f0 * 13, tmp.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < 13; ++c) g13[c] = 0;
+        for (int f = 0; f < f1 - f0; ++f)
+            for (int c = 0; c < 13; ++c) g13[c] += (double)tmp[(size_t)f * 13 + c];
+        return SMAC_OK;
+    }
+    int prim_add_state_grad(int prim, int f, const double* g13) override {
+        int rc;
+        if ((rc = check_prim(prim)) || (rc = check_frame(f))) return rc;
+        R tmp[13];
+        HIP_TRY(hipMemcpyAsync(tmp, pgrad(prim) + (size_t)f * 13, sizeof tmp, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < 13; ++c) tmp[c] += (R)g13[c];
+        HIP_TRY(hipMemcpyAsync(pgrad(prim) + (size_t)f * 13, tmp, sizeof tmp, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int prim_fk(int prim, int f) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");
+        prof_begin(K_FK);
+        hipLaunchKernelGGL(k_prim_fk<R>, dim3(1), dim3(64), 0, stream, pstate(prim), f, D.dt);
+        prof_end();
+        return check_launch();
+    }
+    int prim_fk_grad(int prim, int f) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "forward_kinematics.grad: frame out of range");
+        prof_begin(K_FK);
+        hipLaunchKernelGGL(k_prim_fk_grad<R>, dim3(1), dim3(64), 0, stream, (const R*)pstate(prim), pgrad(prim), f, D.dt);
+        prof_end();
+        return check_launch();
+    }
+    int prim_get_ext_f(int prim, double* e6) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        R tmp[6];
+        HIP_TRY(hipMemcpyAsync(tmp, D.ext_f + prim * 6, sizeof tmp, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < 6; ++c) e6[c] = (double)tmp[c];
+        return SMAC_OK;
+    }
+    int prim_clear_ext_f(int prim) override {                                 // :183-187 (value and grad)
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(D.ext_f + prim * 6, 0, 6 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(D.ext_f_grad + prim * 6, 0, 6 * sizeof(R), stream));
+        return SMAC_OK;
+    }
+    // velocity control (primitive_base.py:285-319): action_buffer[s] = a6 ; v[j] = a[3:6], w[j] = a[0:3] for j in [s n, (s+1) n)
+    int prim_set_action(int prim, int s, int n, const double* a6) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(a6 && s >= 0 && n >= 1 && (s + 1) * n <= cfg.max_frames, "prim_set_action: frames out of range");
+        R a[6];
+        for (int c = 0; c < 6; ++c) a[c] = (R)a6[c];
+        HIP_TRY(hipMemcpyAsync(action_buf + ((size_t)prim * cfg.max_frames + s) * 6, a, sizeof a, hipMemcpyHostToDevice, stream));
+        std::vector<R> cur((size_t)n * 13);
+        HIP_TRY(hipMemcpyAsync(cur.data(), pstate(prim) + (size_t)s * n * 13, cur.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int j = 0; j < n; ++j)
+            for (int k = 0; k < 3; ++k) { cur[(size_t)j * 13 + 7 + k] = a[3 + k]; cur[(size_t)j * 13 + 10 + k] = a[k]; }
+        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)s * n * 13, cur.data(), cur.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int prim_get_action_grad(int prim, int s, int n, double* g6) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(g6 && s >= 0 && n >= 1 && (s + 1) * n <= cfg.max_frames, "prim_get_action_grad: frames out of range");
+        std::vector<R> g((size_t)n * 13);
+        R acc[6];
+        HIP_TRY(hipMemcpyAsync(g.data(), pgrad(prim) + (size_t)s * n * 13, g.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(acc, action_buf_grad + ((size_t)prim * cfg.max_frames + s) * 6, sizeof acc, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        // set_velocity_from_action_kernel.grad accumulates into action_buffer.grad[s] (:315-319)
+        for (int j = 0; j < n; ++j)
+            for (int k = 0; k < 3; ++k) { acc[3 + k] += g[(size_t)j * 13 + 7 + k]; acc[k] += g[(size_t)j * 13 + 10 + k]; }
+        HIP_TRY(hipMemcpyAsync(action_buf_grad + ((size_t)prim * cfg.max_frames + s) * 6, acc, sizeof acc, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < 6; ++c) g6[c] = (double)acc[c];
+        return SMAC_OK;
+    }
+    int prim_reset(int prim) override {                                       // :271-275
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(pstate(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(pgrad(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(action_buf + (size_t)prim * cfg.max_frames * 6, 0, (size_t)cfg.max_frames * 6 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(action_buf_grad + (size_t)prim * cfg.max_frames * 6, 0, (size_t)cfg.max_frames * 6 * sizeof(R), stream));
+        return prim_clear_ext_f(prim);
+    }
+
+    // ---- measurement ----------------------------------------------------------------------
+    int timer_start() override { HIP_TRY(hipEventRecord(t0, stream)); return SMAC_OK; }
+    int timer_stop(double* ms) override {
+        HIP_TRY(hipEventRecord(t1, stream));
+        HIP_TRY(hipEventSynchronize(t1));
+        float f = 0;
+        HIP_TRY(hipEventElapsedTime(&f, t0, t1));
+        if (ms) *ms = f;
+        return SMAC_OK;
+    }
+    int profile_enable(int on) override { profiling = on != 0; return SMAC_OK; }
+    int profile_reset() override {
+        int rc = prof_collect();
+        for (int i = 0; i < K_COUNT; ++i) { prof_ms[i] = 0; prof_n[i] = 0; }
+        return rc;
+    }
+    int profile_get(int i, char* name, int cap, double* ms, int64_t* launches) override {
+        REQUIRE(i >= 0 && i < K_COUNT, "profile index out of range");
+        int rc = prof_collect();
+        if (rc) return rc;
+        if (name && cap > 0) { strncpy(name, kKernelNames[i], cap - 1); name[cap - 1] = 0; }
+        if (ms) *ms = prof_ms[i];
+        if (launches) *launches = prof_n[i];
+        return SMAC_OK;
+    }
+    int grid_ptr(const char* field, void** p, int64_t* n, int32_t* bytes) override {
+        REQUIRE(field && p, "null argument");
+        struct { const char* name; R* ptr; int64_t n; } tab[] = {
+            {"grid_m", D.gm, (int64_t)D.G}, {"grid_v_in", D.gvin, (int64_t)(3 * D.G)}, {"grid_v_mixed", D.gvmix, (int64_t)(3 * D.G)},
+            {"grid_v_out", D.gvout, (int64_t)(3 * D.G)}, {"grid_m.grad", D.agm, (int64_t)D.G}, {"grid_v_in.grad", D.agvin, (int64_t)(3 * D.G)},
+            {"grid_v_mixed.grad", D.agvmix, (int64_t)(3 * D.G)}, {"grid_v_out.grad", D.agvout, (int64_t)(3 * D.G)}};
+        for (auto& t : tab)
+            if (!strcmp(t.name, field)) {
+                *p = t.ptr;
+                if (n) *n = t.n;
+                if (bytes) *bytes = (int32_t)sizeof(R);
+                return SMAC_OK;
+            }
+        err = std::string("unknown grid field ") + field;
+        return SMAC_ERR_INVALID;
+    }
+    int stream_handle(void** s) override { *s = (void*)stream; return SMAC_OK; }
+};
+
+struct smac_sim { ISim* impl; };
+
+extern "C" {
+
+const char* smac_last_error(smac_handle h) { return h ? h->impl->err.c_str() : g_create_error.c_str(); }
+int smac_abi_version(void) { return SMAC_ABI_VERSION; }
+int smac_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int smac_create(const smac_config* cfg, smac_handle* out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return SMAC_ERR_INVALID; }
+    if (cfg->abi_version != SMAC_ABI_VERSION) { g_create_error = "abi_version mismatch"; return SMAC_ERR_INVALID; }
+    if (cfg->precision != 32 && cfg->precision != 64) { g_create_error = "precision must be 32 or 64"; return SMAC_ERR_INVALID; }
+    int ndev = smac_device_count();
+    if (ndev <= 0) { g_create_error = "no HIP device visible: libsoftmac_hip has no CPU fallback"; return SMAC_ERR_NOGPU; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return SMAC_ERR_INVALID; }
+    ISim* s = cfg->precision == 64 ? (ISim*)new Sim<double>() : (ISim*)new Sim<float>();
+    int rc = s->init(*cfg);
+    if (rc != SMAC_OK) { g_create_error = s->err; delete s; return rc; }
+    *out = new smac_sim{s};
+    return SMAC_OK;
+}
+int smac_destroy(smac_handle h) {
+    if (!h) return SMAC_ERR_INVALID;
+    delete h->impl;
+    delete h;
+    return SMAC_OK;
+}
+#define FWD(call) (h ? h->impl->call : (int)SMAC_ERR_INVALID)
+int smac_sync(smac_handle h) { return FWD(sync()); }
+int smac_reset(smac_handle h, const double* state, int cols) { return FWD(reset(state, cols)); }
+int smac_set_frame(smac_handle h, int f, const double* x, const double* v, const double* F, const double* C) { return FWD(set_frame(f, x, v, F, C)); }
+int smac_get_frame(smac_handle h, int f, double* x, double* v, double* F, double* C) { return FWD(get_frame(f, x, v, F, C)); }
+int smac_copy_frame(smac_handle h, int src, int dst) { return FWD(copy_frame(src, dst)); }
+int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC) { return FWD(get_grad(f, gx, gv, gF, gC)); }
+int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC) { return FWD(add_grad(f, gx, gv, gF, gC)); }
+int smac_clear_grads(smac_handle h) { return FWD(clear_grads()); }
+int smac_set_control_idx(smac_handle h, const int32_t* idx) { return FWD(set_control_idx(idx)); }
+int smac_compute_grid_m(smac_handle h, int f, double* grid_m) { return FWD(compute_grid_m(f, grid_m)); }
+int smac_substep(smac_handle h, int f, const double* action) { return FWD(substep(f, action)); }
+int smac_substep_grad(smac_handle h, int f, const double* action, const double* ext_f_grad, double* action_grad_out) {
+    return FWD(substep_grad(f, action, ext_f_grad, action_grad_out));
+}
+int smac_substeps(smac_handle h, int f0, int count) {
+    if (!h) return SMAC_ERR_INVALID;
+    for (int i = 0; i < count; ++i) {
+        int rc = h->impl->substep(f0 + i, nullptr);
+        if (rc) return rc;
+    }
+    return SMAC_OK;
+}
+int smac_substeps_grad(smac_handle h, int f0, int count, const double* ext_f_grad) {
+    if (!h) return SMAC_ERR_INVALID;
+    for (int i = count - 1; i >= 0; --i) {
+        int rc = h->impl->substep_grad(f0 + i, nullptr, i == count - 1 ? ext_f_grad : nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return SMAC_OK;
+}
+int smac_prim_upload_sdf(smac_handle h, int prim, const double* sdf, const double* normal, const int32_t res[3],
+                         const double lower[3], const double upper[3], double sdf_dx) {
+    return FWD(prim_upload_sdf(prim, sdf, normal, res, lower, upper, sdf_dx));
+}
+int smac_prim_set_params(smac_handle h, int prim, double friction, double softness, int contact_enabled) {
+    return FWD(prim_set_params(prim, friction, softness, contact_enabled));
+}
+int smac_prim_set_state(smac_handle h, int prim, int f0, int f1, const double s13[13]) { return FWD(prim_set_state(prim, f0, f1, s13)); }
+int smac_prim_get_state(smac_handle h, int prim, int f, double s13[13]) { return FWD(prim_get_state(prim, f, s13)); }
+int smac_prim_get_state_grad(smac_handle h, int prim, int f0, int f1, double g13[13]) { return FWD(prim_get_state_grad(prim, f0, f1, g13)); }
+int smac_prim_add_state_grad(smac_handle h, int prim, int f, const double g13[13]) { return FWD(prim_add_state_grad(prim, f, g13)); }
+int smac_prim_forward_kinematics(smac_handle h, int prim, int f) { return FWD(prim_fk(prim, f)); }
+int smac_prim_forward_kinematics_grad(smac_handle h, int prim, int f) { return FWD(prim_fk_grad(prim, f)); }
+int smac_prim_get_ext_f(smac_handle h, int prim, double ext_f[6]) { return FWD(prim_get_ext_f(prim, ext_f)); }
+int smac_prim_clear_ext_f(smac_handle h, int prim) { return FWD(prim_clear_ext_f(prim)); }
+int smac_prim_set_action(smac_handle h, int prim, int s, int n, const double a6[6]) { return FWD(prim_set_action(prim, s, n, a6)); }
+int smac_prim_get_action_grad(smac_handle h, int prim, int s, int n, double g6[6]) { return FWD(prim_get_action_grad(prim, s, n, g6)); }
+int smac_prim_reset(smac_handle h, int prim) { return FWD(prim_reset(prim)); }
+int smac_timer_start(smac_handle h) { return FWD(timer_start()); }
+int smac_timer_stop(smac_handle h, double* ms) { return FWD(timer_stop(ms)); }
+int smac_profile_enable(smac_handle h, int on) { return FWD(profile_enable(on)); }
+int smac_profile_reset(smac_handle h) { return FWD(profile_reset()); }
+int smac_profile_count(smac_handle h) { return h ? (int)K_COUNT : (int)SMAC_ERR_INVALID; }
+int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* total_ms, int64_t* launches) {
+    return FWD(profile_get(i, name, name_cap, total_ms, launches));
+}
+int smac_count_active_cells(smac_handle h, int f, int64_t* cells) { return FWD(count_active_cells(f, cells)); }
+int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64_t* n_scalars, int32_t* scalar_bytes) {
+    return FWD(grid_ptr(field, dev_ptr, n_scalars, scalar_bytes));
+}
+int smac_stream_handle(smac_handle h, void** hip_stream) { return FWD(stream_handle(hip_stream)); }
+
+}  // extern "C"

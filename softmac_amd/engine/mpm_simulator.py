@@ -1,0 +1,277 @@
+"""MPMSimulator - host-side mirror of the reference class
+(/root/reference/softmac/engine/mpm_simulator.py:16-618) over libsoftmac_hip.so.
+
+Same constructor, attributes and method names as the reference so that TaichiEnv, the losses
+and the demos can drive it; every method forwards to one C-ABI entry point (include/softmac_hip.h).
+The public dtype stays float64 numpy (reference :482-485); the device arithmetic type is chosen
+by `cfg.precision` ("float32" default / "float64") - see DESIGN.md "precision".
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _ffi
+
+MODEL_COROTATED = 0
+MODEL_NEOHOOKEAN = 1
+
+MAT_PLASTIC = 0
+MAT_ELASTIC = 1
+MAT_LIQUID = 2
+
+CONTACT_GRID = 0
+CONTACT_PARTICLE = 1
+CONTACT_MIXED = 2
+
+
+class _FrameField:
+    """`sim.x[f]`-style read access to one trajectory field (+ `.grad`), as the losses use it
+    (reference loss_pour.py:12).  Indexing returns numpy copies; the data lives on the GPU."""
+
+    def __init__(self, sim, name, grad=False):
+        self._sim, self._name, self._grad = sim, name, grad
+        if not grad:
+            self.grad = _FrameField(sim, name, grad=True)
+
+    def __getitem__(self, idx):
+        f, rest = (idx, None) if not isinstance(idx, tuple) else (idx[0], idx[1:])
+        arr = self._sim._read_field(self._name, int(f), self._grad)
+        return arr if rest is None else arr[rest if len(rest) > 1 else rest[0]]
+
+    def to_numpy(self, f):
+        return self[f]
+
+
+class MPMSimulator:
+    def __init__(self, cfg, primitives=(), env_dt=2e-3, rigid_velocity_control=False):
+        dim = self.dim = cfg.dim
+        assert dim == 3, "the MI355X path implements the 3-D simulator only"
+        assert cfg.dtype == 'float64'                       # reference :19 (public dtype)
+        self.dtype = np.float64
+        self._yield_stress = cfg.yield_stress
+        self.ground_friction = cfg.ground_friction
+        self.default_gravity = cfg.gravity
+        self.n_primitive = len(primitives)
+
+        quality = cfg.quality * 0.5                         # :26-30
+        n_particles = self.n_particles = int(cfg.n_particles)
+        n_grid = self.n_grid = int(128 * quality)
+        if getattr(cfg, "n_grid", None):                    # extension: explicit grid size (128^3 / 256^3 runs)
+            n_grid = self.n_grid = int(cfg.n_grid)
+
+        self.dx, self.inv_dx = 1 / n_grid, float(n_grid)
+        self.dt = cfg.dt
+        self.p_vol, self.p_rho = (self.dx * 0.5) ** 2, 1    # :34
+        self.p_mass = self.p_vol * self.p_rho
+
+        self.ptype = cfg.ptype
+        self.material_model = cfg.material_model
+        E, nu = cfg.E, cfg.nu
+        self._mu, self._lam = E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))   # :41
+        if self.ptype == 1:
+            self._mu, self._lam = 0.3 * self._mu, 0.3 * self._lam
+        elif self.ptype == 2:
+            self._mu = 0.0
+
+        self.max_steps = int(cfg.max_steps)
+        self.substeps = int(env_dt / self.dt)               # :52
+        self.res = (n_grid, n_grid, n_grid)
+        self.primitives = primitives
+        self.primitives_contact = [True for _ in range(self.n_primitive)]   # :70, mutated by demos
+        self.rigid_velocity_control = rigid_velocity_control
+        self.n_control = int(cfg.n_controllers)
+        self.collision_type = int(cfg.collision_type)
+        self.cur = 0
+
+        precision = getattr(cfg, "precision", "float32")
+        self.precision = 64 if str(precision) in ("float64", "64", "f64") else 32
+        self.device = int(getattr(cfg, "device", 0))
+        self.grad_enabled = bool(getattr(cfg, "grad_enabled", True))
+
+        c = _ffi.SmacConfig()
+        c.abi_version = _ffi.ABI_VERSION
+        c.precision = self.precision
+        c.device = self.device
+        c.n_particles = n_particles
+        c.n_grid = n_grid
+        c.max_frames = self.max_steps
+        c.grad_enabled = 1 if self.grad_enabled else 0
+        c.substeps = max(self.substeps, 1)
+        c.ptype = self.ptype
+        c.material_model = self.material_model
+        c.collision_type = self.collision_type
+        c.n_control = self.n_control
+        c.n_primitives = self.n_primitive
+        c.rigid_velocity_control = 1 if rigid_velocity_control else 0
+        c.dt = self.dt
+        c.mu, c.lam = self._mu, self._lam
+        c.p_vol, c.p_mass = self.p_vol, self.p_mass
+        g = tuple(cfg.gravity)
+        c.gravity[0], c.gravity[1], c.gravity[2] = float(g[0]), float(g[1]), float(g[2])
+        c.ground_friction = float(self.ground_friction)
+        c.yield_stress = float(self._yield_stress)
+        self._h = _ffi.Handle(c)                            # raises without a GPU: no CPU fallback
+
+        for i, p in enumerate(primitives):                  # device-side primitive slots
+            p._bind(self._h, i)
+        self._contact_pushed = None
+
+        self.x = _FrameField(self, "x")
+        self.v = _FrameField(self, "v")
+        self.C = _FrameField(self, "C")
+        self.F = _FrameField(self, "F")
+
+    # ------------------------------------------------------------------ plumbing
+    def initialize(self):                                   # :86-90 (gravity/mu/lam already in the handle)
+        pass
+
+    def _push_contact_flags(self):
+        flags = tuple(bool(b) for b in self.primitives_contact)
+        if flags != self._contact_pushed:
+            for i, p in enumerate(self.primitives):
+                p._push_params(contact=flags[i])
+            self._contact_pushed = flags
+
+    def _read_field(self, name, f, grad):
+        N = self.n_particles
+        shape = (N, 3) if name in ("x", "v") else (N, 3, 3)
+        out = np.zeros(shape, dtype=np.float64)
+        args = {"x": 0, "v": 1, "F": 2, "C": 3}[name]
+        ptrs = [None, None, None, None]
+        ptrs[args] = _ffi.dptr(out)
+        self._h.call("smac_get_grad" if grad else "smac_get_frame", f, *ptrs)
+        return out
+
+    def sync(self):
+        self._h.call("smac_sync")
+
+    # ------------------------------------------------------------------ hot path (:320-378)
+    def substep(self, s, action=None):
+        self._push_contact_flags()
+        a = None if action is None else _ffi.as_f64(np.asarray(action).reshape(self.n_control, self.dim))
+        self._h.call("smac_substep", int(s), _ffi.dptr(a))
+
+    def substep_grad(self, s, action=None, ext_f_grad=None):
+        self._push_contact_flags()
+        a = None if action is None else _ffi.as_f64(np.asarray(action).reshape(self.n_control, self.dim))
+        e = None
+        if ext_f_grad is not None:
+            e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]))
+        out = None if action is None else np.zeros((self.n_control, self.dim))
+        self._h.call("smac_substep_grad", int(s), _ffi.dptr(a), _ffi.dptr(e), _ffi.dptr(out))
+        if action is None:
+            return None
+        return out.reshape(np.asarray(action).shape)
+
+    def substeps(self, s0, count):
+        """Batched forward: frames s0 .. s0+count-1 in one FFI call."""
+        self._push_contact_flags()
+        self._h.call("smac_substeps", int(s0), int(count))
+
+    def substeps_grad(self, s0, count, ext_f_grad=None):
+        self._push_contact_flags()
+        e = None
+        if ext_f_grad is not None:
+            e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]))
+        self._h.call("smac_substeps_grad", int(s0), int(count), _ffi.dptr(e))
+
+    # ------------------------------------------------------------------ IO (:448-574)
+    def get_state(self, f):
+        N = self.n_particles
+        x, v = np.zeros((N, 3)), np.zeros((N, 3))
+        F, Cm = np.zeros((N, 3, 3)), np.zeros((N, 3, 3))
+        self._h.call("smac_get_frame", int(f), _ffi.dptr(x), _ffi.dptr(v), _ffi.dptr(F), _ffi.dptr(Cm))
+        return np.hstack([x, v, F.reshape(N, -1), Cm.reshape(N, -1)])
+
+    def set_state(self, f, state):
+        x, v, F, Cm = (_ffi.as_f64(s) for s in state[:4])
+        self._h.call("smac_set_frame", int(f), _ffi.dptr(x), _ffi.dptr(v), _ffi.dptr(F), _ffi.dptr(Cm))
+
+    def reset(self, x):
+        x = _ffi.as_f64(x)
+        assert x.shape[0] == self.n_particles and x.shape[1] in (3, 24)
+        self._h.call("smac_reset", _ffi.dptr(x), int(x.shape[1]))
+        self.cur = 0
+
+    def copyframe(self, source, target):
+        self._h.call("smac_copy_frame", int(source), int(target))
+
+    def get_x(self, f):
+        return self._read_field("x", int(f), False)
+
+    def get_v(self, f):
+        return self._read_field("v", int(f), False)
+
+    def set_x(self, f, x):
+        x = _ffi.as_f64(x, (self.n_particles, 3))
+        self._h.call("smac_set_frame", int(f), _ffi.dptr(x), None, None, None)
+
+    def set_v(self, f, v):
+        v = _ffi.as_f64(v, (self.n_particles, 3))
+        self._h.call("smac_set_frame", int(f), None, _ffi.dptr(v), None, None)
+
+    def get_grad(self, f):
+        N = self.n_particles
+        gx, gv = np.zeros((N, 3)), np.zeros((N, 3))
+        self._h.call("smac_get_grad", int(f), _ffi.dptr(gx), _ffi.dptr(gv), None, None)
+        return gx, gv
+
+    def get_grad_full(self, f):
+        N = self.n_particles
+        gx, gv, gF, gC = np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3, 3)), np.zeros((N, 3, 3))
+        self._h.call("smac_get_grad", int(f), _ffi.dptr(gx), _ffi.dptr(gv), _ffi.dptr(gF), _ffi.dptr(gC))
+        return gx, gv, gF, gC
+
+    def add_grad(self, f, gx=None, gv=None, gF=None, gC=None):
+        """`x.grad[f, i] += ...` as done by the loss kernels (reference loss_pour.py:130-140)."""
+        arrs = [None if a is None else _ffi.as_f64(a) for a in (gx, gv, gF, gC)]
+        self._h.call("smac_add_grad", int(f), *[_ffi.dptr(a) for a in arrs])
+
+    def clear_grads(self):
+        self._h.call("smac_clear_grads")
+
+    # ------------------------------------------------------------------ control (:579-602)
+    def set_action(self, action):
+        # forwarded with the next substep()/substep_grad(), which is where the reference uploads it
+        raise NotImplementedError("pass `action` to substep()/substep_grad() as the reference's callers do")
+
+    def set_control_idx(self, idx=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if self.n_control == 0:
+            idx = idx * 0
+        self._h.call("smac_set_control_idx", idx.ctypes.data_as(_ffi.c_int32_p))
+
+    def compute_grid_m_kernel(self, f):
+        out = np.zeros(self.res, dtype=np.float64)
+        self._h.call("smac_compute_grid_m", int(f), _ffi.dptr(out))
+        return out
+
+    # ------------------------------------------------------------------ measurement helpers
+    def count_active_cells(self, f):
+        n = C.c_int64(0)
+        self._h.call("smac_count_active_cells", int(f), C.byref(n))
+        return int(n.value)
+
+    def timer_start(self):
+        self._h.call("smac_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        self._h.call("smac_timer_stop", C.byref(ms))
+        return ms.value
+
+    def profile(self, on=True):
+        self._h.call("smac_profile_enable", 1 if on else 0)
+        self._h.call("smac_profile_reset")
+
+    def profile_report(self):
+        n = self._h.lib.smac_profile_count(self._h.h)
+        rows = {}
+        for i in range(n):
+            name = C.create_string_buffer(64)
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            self._h.call("smac_profile_get", i, name, 64, C.byref(ms), C.byref(cnt))
+            rows[name.value.decode()] = (ms.value, int(cnt.value))
+        return rows

@@ -1,0 +1,99 @@
+// Test-only host build of softmac_amd/csrc/smac_math.hpp (g++).  Lets pytest compare the
+// per-particle device arithmetic with the torch oracle on the CPU.  Never linked into the product.
+#include "../../softmac_amd/csrc/smac_math.hpp"
+
+using namespace smac;
+
+template <class R>
+static void constitutive_run(int n, int ptype, int model, double mu, double lam, const double* Et, const double* G,
+                             const double* gFn, double* En, double* stress, double* gEt) {
+    Material<R> M{ptype, model, (R)mu, (R)lam};
+    for (int p = 0; p < n; ++p) {
+        R e[9], g[9], gf[9], en[9], st[9], ge[9];
+        for (int i = 0; i < 9; ++i) { e[i] = (R)Et[9 * p + i]; g[i] = (R)G[9 * p + i]; gf[i] = (R)gFn[9 * p + i]; }
+        ConstState<R> cs;
+        constitutive_fwd(M, e, en, st, cs);
+        constitutive_bwd(M, e, cs, g, gf, ge);
+        for (int i = 0; i < 9; ++i) { En[9 * p + i] = en[i]; stress[9 * p + i] = st[i]; gEt[9 * p + i] = ge[i]; }
+    }
+}
+
+template <class R>
+static void svd_run(int n, const double* E, double* U, double* e, double* V) {
+    for (int p = 0; p < n; ++p) {
+        R a[9], u[9], v[9], s[3];
+        for (int i = 0; i < 9; ++i) a[i] = (R)E[9 * p + i];
+        svd_I_plus_E(a, u, s, v);
+        for (int i = 0; i < 9; ++i) { U[9 * p + i] = u[i]; V[9 * p + i] = v[i]; }
+        for (int i = 0; i < 3; ++i) e[3 * p + i] = s[i];
+    }
+}
+
+template <class R>
+static void collide_run(int n, const double* sdf, const double* normal, const int* res, const double* lower,
+                        const double* upper, double sdf_dx, double friction, double softness, const double* st13,
+                        const double* pos, const double* vel, double p_mass, double dt, double life,
+                        const double* g_v, const double* g_ext, double* out_v, double* out_ext, int* active,
+                        double* g_pos, double* g_vin, double* g_state) {
+    long cells = (long)res[0] * res[1] * res[2];
+    R* ts = new R[cells];
+    R* tn = new R[cells * 3];
+    for (long i = 0; i < cells; ++i) ts[i] = (R)sdf[i];
+    for (long i = 0; i < cells * 3; ++i) tn[i] = (R)normal[i];
+    PrimTable<R> T;
+    T.sdf = ts; T.normal = tn;
+    for (int i = 0; i < 3; ++i) { T.res[i] = res[i]; T.lower[i] = (R)lower[i]; T.upper[i] = (R)upper[i]; }
+    T.inv_dx = (R)(1.0 / sdf_dx); T.friction = (R)friction; T.softness = (R)softness; T.contact = 1;
+    R st[13];
+    for (int i = 0; i < 13; ++i) st[i] = (R)st13[i];
+    for (int i = 0; i < 13; ++i) g_state[i] = 0;
+    for (int p = 0; p < n; ++p) {
+        R x[3], v[3], vin[3], ext[6] = {0, 0, 0, 0, 0, 0}, gv[3], ge[6], gp[3] = {0, 0, 0}, gvi[3], gs[13];
+        for (int i = 0; i < 3; ++i) { x[i] = (R)pos[3 * p + i]; v[i] = vin[i] = (R)vel[3 * p + i]; gv[i] = (R)g_v[3 * p + i]; }
+        for (int i = 0; i < 6; ++i) ge[i] = (R)g_ext[i];
+        for (int i = 0; i < 13; ++i) gs[i] = 0;
+        bool act = collide_mixed(T, st, x, v, (R)p_mass, (R)dt, (R)life, ext);
+        active[p] = act;
+        for (int i = 0; i < 3; ++i) out_v[3 * p + i] = v[i];
+        for (int i = 0; i < 6; ++i) out_ext[6 * p + i] = ext[i];
+        for (int i = 0; i < 3; ++i) gvi[i] = gv[i];   // identity outside the band
+        collide_mixed_adjoint(T, st, x, vin, (R)p_mass, (R)dt, (R)life, gv, ge, gp, gvi, gs);
+        for (int i = 0; i < 3; ++i) { g_pos[3 * p + i] = gp[i]; g_vin[3 * p + i] = gvi[i]; }
+        for (int i = 0; i < 13; ++i) g_state[i] += gs[i];
+    }
+    delete[] ts;
+    delete[] tn;
+}
+
+template <class R> static void fk_run(const double* s13, double dt, double* out7) {
+    R s[13], o[7];
+    for (int i = 0; i < 13; ++i) s[i] = (R)s13[i];
+    forward_kinematics(s, (R)dt, o);
+    for (int i = 0; i < 7; ++i) out7[i] = o[i];
+}
+
+extern "C" {
+void h_constitutive(int prec, int n, int ptype, int model, double mu, double lam, const double* Et, const double* G,
+                    const double* gFn, double* En, double* stress, double* gEt) {
+    if (prec == 64) constitutive_run<double>(n, ptype, model, mu, lam, Et, G, gFn, En, stress, gEt);
+    else constitutive_run<float>(n, ptype, model, mu, lam, Et, G, gFn, En, stress, gEt);
+}
+void h_svd(int prec, int n, const double* E, double* U, double* e, double* V) {
+    if (prec == 64) svd_run<double>(n, E, U, e, V); else svd_run<float>(n, E, U, e, V);
+}
+void h_collide_mixed(int prec, int n, const double* sdf, const double* normal, const int* res, const double* lower,
+                     const double* upper, double sdf_dx, double friction, double softness, const double* st13,
+                     const double* pos, const double* vel, double p_mass, double dt, double life, const double* g_v,
+                     const double* g_ext, double* out_v, double* out_ext, int* active, double* g_pos, double* g_vin,
+                     double* g_state) {
+    if (prec == 64)
+        collide_run<double>(n, sdf, normal, res, lower, upper, sdf_dx, friction, softness, st13, pos, vel, p_mass, dt,
+                            life, g_v, g_ext, out_v, out_ext, active, g_pos, g_vin, g_state);
+    else
+        collide_run<float>(n, sdf, normal, res, lower, upper, sdf_dx, friction, softness, st13, pos, vel, p_mass, dt,
+                           life, g_v, g_ext, out_v, out_ext, active, g_pos, g_vin, g_state);
+}
+void h_forward_kinematics(int prec, const double* s13, double dt, double* out7) {
+    if (prec == 64) fk_run<double>(s13, dt, out7); else fk_run<float>(s13, dt, out7);
+}
+}

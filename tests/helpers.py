@@ -1,0 +1,143 @@
+"""Shared scene builders and oracle/engine drivers for the parity tests."""
+from __future__ import annotations
+
+import pathlib
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from oracle import softmac_oracle as O  # noqa: E402  (test infrastructure only)
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def sim_cfg(n_particles, n_grid=64, dt=2e-4, E=3e3, nu=0.2, ptype=0, material_model=0, gravity=(0., -9.8, 0.),
+            ground_friction=20., collision_type=2, n_controllers=0, max_steps=16, precision="float64", **extra):
+    c = types.SimpleNamespace(dim=3, dtype="float64", quality=1, yield_stress=50., ground_friction=ground_friction,
+                              gravity=gravity, n_particles=n_particles, dt=dt, ptype=ptype,
+                              material_model=material_model, E=E, nu=nu, max_steps=max_steps,
+                              n_controllers=n_controllers, collision_type=collision_type, n_grid=n_grid,
+                              precision=precision)
+    for k, v in extra.items():
+        setattr(c, k, v)
+    return c
+
+
+def oracle_params(cfg, env_dt):
+    return O.SimParams(n_grid=cfg.n_grid, dt=cfg.dt, E=cfg.E, nu=cfg.nu, ptype=cfg.ptype,
+                       material_model=cfg.material_model, gravity=tuple(cfg.gravity),
+                       ground_friction=cfg.ground_friction, collision_type=cfg.collision_type,
+                       substeps=max(int(env_dt / cfg.dt), 1), n_control=cfg.n_controllers)
+
+
+def make_cloud(n, n_grid, seed=0, lo=(0.3, 0.3, 0.3), hi=(0.7, 0.7, 0.7), v_std=0.1, C_std=1.0, F_std=0.01):
+    """Synthetic seeded particle cloud: state rows = x3 v3 F9 C9."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(lo, hi, (n, 3))
+    v = v_std * rng.standard_normal((n, 3))
+    F = np.eye(3)[None] + F_std * rng.standard_normal((n, 3, 3))
+    C = C_std * rng.standard_normal((n, 3, 3))
+    return np.hstack([x, v, F.reshape(n, 9), C.reshape(n, 9)])
+
+
+def load_palm():
+    d = np.load(GOLDEN / "palm_sdf.npz")
+    return dict(sdf=d["sdf"], normal=d["normal"], lower=d["lower"], upper=d["upper"], dx=float(d["dx"]),
+                res=np.asarray(d["res"]))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = np.abs(b).max()
+    return float(np.abs(a - b).max() / scale) if scale > 0 else float(np.abs(a).max())
+
+
+class OracleRollout:
+    """Drives oracle.substep over several frames and chains substep_grad backwards,
+    accumulating adjoints the way the reference's fields do (`+=` into frame f)."""
+
+    def __init__(self, P, state24, prim_specs=(), prim_states=None, control_idx=None):
+        self.P = P
+        x, v, C, F = O.state24_split(state24)
+        self.frames = [(x, v, C, F)]
+        self.prim_specs = list(prim_specs)           # dict(table..., friction, softness, contact)
+        self.prim_states = prim_states               # [frame][prim] -> 13-vector
+        self.control_idx = None if control_idx is None else torch.as_tensor(control_idx, dtype=torch.int64)
+        self.ext = []
+
+    def prims_at(self, f):
+        out = []
+        for i, s in enumerate(self.prim_specs):
+            st = np.asarray(self.prim_states[f][i], dtype=np.float64)
+            out.append(O.make_prim(st[:3], st[3:7], st[7:10], st[10:13], s["sdf"], s["normal"], s["lower"],
+                                   s["upper"], s["dx"], s.get("friction", 0.9), s.get("softness", 666.0),
+                                   s.get("contact", True)))
+        return out
+
+    def forward(self, nsteps, actions=None):
+        for f in range(nsteps):
+            x, v, C, F = self.frames[-1]
+            act = None if actions is None else torch.as_tensor(actions[f], dtype=O.DT)
+            nx, nv, nC, nF, ext = O.substep(x, v, C, F, self.P, self.prims_at(f), f, self.control_idx, act)
+            self.frames.append((nx.detach(), nv.detach(), nC.detach(), nF.detach()))
+            self.ext.append([e.detach().numpy() for e in ext])
+        return self
+
+    def backward(self, seeds, ext_f_grad=None, actions=None):
+        """seeds: dict frame -> (gx, gv, gC, gF) numpy (any may be None).  Returns per-frame adjoints,
+        per-frame per-primitive state grads (13) and per-frame action grads."""
+        n = len(self.frames) - 1
+        N = self.frames[0][0].shape[0]
+        z3, z9 = lambda: torch.zeros(N, 3, dtype=O.DT), lambda: torch.zeros(N, 3, 3, dtype=O.DT)
+        adj = [[z3(), z3(), z9(), z9()] for _ in range(n + 1)]
+        for f, s in seeds.items():
+            for k in range(4):
+                if s[k] is not None:
+                    adj[f][k] = adj[f][k] + torch.as_tensor(s[k], dtype=O.DT).reshape(adj[f][k].shape)
+        pg = [[np.zeros(13) for _ in self.prim_specs] for _ in range(n + 1)]
+        ag = [None] * n
+        eg = None if ext_f_grad is None else [torch.as_tensor(g, dtype=O.DT) for g in ext_f_grad]
+        for f in range(n - 1, -1, -1):
+            x, v, C, F = self.frames[f]
+            act = None if actions is None else torch.as_tensor(actions[f], dtype=O.DT)
+            out = O.substep_grad(x, v, C, F, self.P, self.prims_at(f), f, *adj[f + 1], ext_f_grad=eg,
+                                 control_idx=self.control_idx, action=act)
+            adj[f][0] = adj[f][0] + out["gx"]; adj[f][1] = adj[f][1] + out["gv"]
+            adj[f][2] = adj[f][2] + out["gC"]; adj[f][3] = adj[f][3] + out["gF"]
+            for i, g in enumerate(out["prims"]):
+                pg[f][i] += torch.cat(g).numpy()
+            if out["action"] is not None:
+                ag[f] = out["action"].numpy()
+        return adj, pg, ag
+
+
+def build_engine(cfg, env_dt, prim_specs=(), prim_states=None, nframes=None):
+    """MPMSimulator + Mesh primitives over the HIP library (requires a GPU)."""
+    from softmac_amd.engine.mpm_simulator import MPMSimulator
+    from softmac_amd.engine.primitive import Mesh, Primitives
+    from softmac_amd.config import CfgNode
+    meshes = []
+    for s in prim_specs:
+        pc = CfgNode()
+        pc.friction = s.get("friction", 0.9)
+        pc.enable_external_force = True
+        pc.urdf_path = ""
+        meshes.append(Mesh(sdf=s, cfg=pc, max_timesteps=cfg.max_steps))
+    prims = Primitives(primitives=meshes)
+    sim = MPMSimulator(cfg, prims, env_dt)
+    prims.initialize()
+    for i, (m, s) in enumerate(zip(meshes, prim_specs)):
+        m.friction[None] = s.get("friction", 0.9)
+        m.softness[None] = s.get("softness", 666.0)
+    sim.primitives_contact = [bool(s.get("contact", True)) for s in prim_specs]
+    if prim_states is not None:
+        for f in range(len(prim_states)):
+            for i, m in enumerate(meshes):
+                m.set_all_states(f, prim_states[f][i])
+    return sim, prims

@@ -1,0 +1,184 @@
+"""GPU parity: HIP path (through the C ABI) vs the f64 oracle on identical seeded inputs.
+
+f64 device mode must match to ~1e-9 (same algorithm, different summation order); f32 device mode
+to the north-star tolerance 1e-5 relative (max-norm relative to the field's max magnitude) on
+positions / velocities / gradients over short windows."""
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"float64": dict(state=1e-9, grad=1e-8), "float32": dict(state=1e-5, grad=2e-4)}
+# NB grads in f32: 2e-4 bounds the worst field in the stiff plastic scenes; typical is ~1e-5.
+
+
+def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None, actions=None, control_idx=None,
+                     ext_f_grad=None, seed=0, tol=None):
+    P = H.oracle_params(cfg, env_dt)
+    orc = H.OracleRollout(P, state, prim_specs, prim_states, control_idx).forward(nsteps, actions)
+    sim, prims = H.build_engine(cfg, env_dt, prim_specs, prim_states)
+    if control_idx is not None:
+        sim.set_control_idx(np.asarray(control_idx, dtype=np.int32))
+    sim.reset(state)
+    for f in range(nsteps):
+        sim.substep(f, None if actions is None else actions[f])
+    tol = tol or TOL[cfg.precision]
+    N = cfg.n_particles
+    errs = {}
+    for f in (1, nsteps):
+        st = sim.get_state(f)
+        x, v, C, F = orc.frames[f]
+        errs[f"x[{f}]"] = H.rel_err(st[:, 0:3], x.numpy())
+        errs[f"v[{f}]"] = H.rel_err(st[:, 3:6], v.numpy())
+        errs[f"F[{f}]"] = H.rel_err(st[:, 6:15], F.reshape(N, 9).numpy())
+        errs[f"C[{f}]"] = H.rel_err(st[:, 15:24], C.reshape(N, 9).numpy())
+    for k, e in errs.items():
+        assert e < tol["state"], (k, e, errs)
+    if prim_specs:
+        ext_ref = np.sum(np.array(orc.ext), axis=0)            # (P,6) accumulated over the window
+        for i, m in enumerate(prims):
+            got = m.ext_f.to_numpy()
+            scale = max(np.abs(ext_ref[i]).max(), 1e-12)
+            assert np.abs(got - ext_ref[i]).max() / scale < max(tol["state"] * 50, 1e-8), (i, got, ext_ref[i])
+    # ---- backward: seed all four adjoints at the last frame, x adjoint at a middle frame too
+    rng = np.random.default_rng(seed + 100)
+    seeds = {nsteps: (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), 0.01 * rng.standard_normal((N, 3, 3)),
+                      0.01 * rng.standard_normal((N, 3, 3)))}
+    if nsteps > 1:
+        seeds[1] = (rng.standard_normal((N, 3)), None, None, None)
+    adj, pg, ag = orc.backward(seeds, ext_f_grad, actions)
+    sim.clear_grads()
+    for f, s in seeds.items():
+        sim.add_grad(f, gx=s[0], gv=s[1], gC=s[2], gF=s[3])
+    got_ag = []
+    for f in range(nsteps - 1, -1, -1):
+        got_ag.append(sim.substep_grad(f, None if actions is None else actions[f], ext_f_grad))
+    got_ag = got_ag[::-1]
+    gx, gv, gF, gC = sim.get_grad_full(0)
+    gerrs = dict(gx=H.rel_err(gx, adj[0][0].numpy()), gv=H.rel_err(gv, adj[0][1].numpy()),
+                 gC=H.rel_err(gC, adj[0][2].numpy()), gF=H.rel_err(gF, adj[0][3].numpy()))
+    for k, e in gerrs.items():
+        assert e < tol["grad"], (k, e, gerrs)
+    if prim_specs:
+        for i, m in enumerate(prims):
+            for f in range(nsteps):
+                ref = pg[f][i]
+                got = m.get_all_states_grad(f)
+                scale = max(np.abs(ref).max(), 1e-9)
+                assert np.abs(got - ref).max() / scale < tol["grad"] * 10, (i, f, got, ref)
+    if actions is not None:
+        for f in range(nsteps):
+            assert H.rel_err(got_ag[f], ag[f]) < tol["grad"], (f, got_ag[f], ag[f])
+    return errs, gerrs
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+@pytest.mark.parametrize("ptype,model", [(1, 0), (0, 0), (2, 0), (1, 1), (2, 1), (0, 1)])
+def test_materials_no_contact(precision, ptype, model):
+    n_grid, N = 32, 3000
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=ptype, material_model=model, ground_friction=0.0,
+                    precision=precision, E=3e3 if ptype != 2 else 22.0)
+    state = H.make_cloud(N, n_grid, seed=ptype * 2 + model, lo=(0.3, 0.05, 0.3), hi=(0.7, 0.4, 0.7))
+    _compare_rollout(cfg, 1e-3, state, 3)
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_grip_fixture_plastic_sticky_floor(precision):
+    d = np.load(H.GOLDEN / "grip_state_2k.npz")
+    state = d["state"]
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, material_model=0, ground_friction=20.0,
+                    precision=precision)
+    _compare_rollout(cfg, 1e-3, state, 4)
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_pour_fixture_liquid(precision):
+    d = np.load(H.GOLDEN / "pour_state_1k.npz")
+    state = d["state"]
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=1e-3, E=22.0, ptype=2, material_model=0, ground_friction=0.0,
+                    precision=precision)
+    _compare_rollout(cfg, 1e-3, state, 3)
+
+
+def _palm_scene(state, nframes):
+    """Palm box (reference asset SDF) pressed into the top of the grip block, tilted and moving."""
+    palm = H.load_palm()
+    top = state[:, 1].max()
+    q = np.array([0.995, 0.02, 0.03, 0.09]); q /= np.linalg.norm(q)
+    s0 = np.concatenate([[0.5, top + 0.15 - 0.004, 0.5], q, [0.02, -0.3, 0.01], [0.1, 0.05, -0.2]])
+    spec = dict(palm, friction=0.4, softness=666.0, contact=True)
+    states = []
+    s = s0.copy()
+    for f in range(nframes + 1):
+        states.append([s.copy()])
+        s[:3] = s[:3] + 2e-4 * np.array([0.02, -0.3, 0.01])
+    return [spec], states
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_grip_fixture_forecast_contact(precision):
+    d = np.load(H.GOLDEN / "grip_state_2k.npz")
+    state = d["state"]
+    specs, pstates = _palm_scene(state, 4)
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, material_model=0, ground_friction=20.0,
+                    precision=precision)
+    rng = np.random.default_rng(5)
+    eg = [rng.standard_normal(6) * 1e-2]
+    tol = None
+    if precision == "float32":
+        # fp32 positions (6e-8 * 0.5) divided by dt in the forecast push-out bound contact accuracy
+        tol = dict(state=5e-4, grad=5e-3)
+    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg, tol=tol)
+
+
+@pytest.mark.parametrize("precision", ["float64"])
+def test_two_primitives_one_disabled(precision):
+    d = np.load(H.GOLDEN / "grip_state_2k.npz")
+    state = d["state"]
+    specs, pstates = _palm_scene(state, 3)
+    spec2 = dict(specs[0], contact=False)
+    spec3 = dict(specs[0], friction=0.05)
+    specs = [spec2, specs[0], spec3]
+    ps = []
+    for f in range(len(pstates)):
+        a = pstates[f][0]
+        b = a.copy(); b[0] += 0.01; b[1] += 0.002
+        ps.append([a, a, b])
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, precision=precision)
+    _compare_rollout(cfg, 1e-3, state, 2, specs, ps)
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_particle_control_action_grad(precision):
+    n_grid, N = 32, 2000
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, material_model=0, ground_friction=0.0, n_controllers=2,
+                    precision=precision)
+    state = H.make_cloud(N, n_grid, seed=11)
+    rng = np.random.default_rng(3)
+    idx = rng.integers(-1, 2, N)
+    actions = [rng.standard_normal((2, 3)) for _ in range(3)]
+    _compare_rollout(cfg, 1e-3, state, 3, actions=actions, control_idx=idx)
+
+
+def test_edge_cases_errors():
+    """Error behaviour at the boundary: bad frames / missing tables raise instead of faulting."""
+    from softmac_amd._ffi import SmacError
+    cfg = H.sim_cfg(300, n_grid=32, max_steps=4)
+    sim, _ = H.build_engine(cfg, 1e-3)
+    sim.reset(H.make_cloud(300, 32)[:, :3])                 # 3-column reset: v=0, F=I, C=0 (reference :495-501)
+    st = sim.get_state(0)
+    assert np.allclose(st[:, 3:6], 0) and np.allclose(st[:, 6:15], np.eye(3).reshape(9)) and np.allclose(st[:, 15:], 0)
+    with pytest.raises(SmacError):
+        sim.substep(3)                                      # frame 4 does not exist
+    with pytest.raises(SmacError):
+        sim.get_x(99)
+    sim.substep(0)
+    # a particle outside the grid must not fault the GPU (addressing is clamped)
+    far = H.make_cloud(300, 32)
+    far[0, :3] = [1.7, -0.4, 0.5]
+    sim.reset(far)
+    sim.substep(0)
+    sim.sync()

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Derive small test fixtures from the reference's own DATA files (run in the build container,
+where /root/reference exists; the outputs under tests/golden/ are committed and travel).
+
+Only data is read - particle-state arrays and a cached SDF table - never source.  The SDF
+cache is a pickle, so it is opened with a numpy-only restricted unpickler.
+
+  grip_state_2k.npz   2000-particle subsample of softmac/envs/grip/grip_mpm_init_state.npy
+  pour_state_1k.npz   1000-particle subsample of softmac/envs/pour/pour_mpm_init_state_corotated.npy
+  palm_sdf.npz        sdf/normal tables of softmac/assets/gripper/palm.obj (the cached 6895...c4d5 blob)
+"""
+import importlib
+import pathlib
+import pickle
+import sys
+
+import numpy as np
+
+REF = pathlib.Path("/root/reference/softmac")
+OUT = pathlib.Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+_ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+            ("numpy", "ndarray"), ("numpy", "dtype"),
+            ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
+
+
+class NumpyOnlyUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) not in _ALLOWED:
+            raise pickle.UnpicklingError(f"forbidden global {module}.{name}")
+        return getattr(importlib.import_module(module.replace("numpy.core", "numpy._core")), name)
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(0)
+    grip = np.load(REF / "envs/grip/grip_mpm_init_state.npy")
+    idx = np.sort(rng.choice(len(grip), 2000, replace=False))
+    np.savez_compressed(OUT / "grip_state_2k.npz", state=grip[idx], index=idx)
+    pour = np.load(REF / "envs/pour/pour_mpm_init_state_corotated.npy")
+    idx = np.sort(rng.choice(len(pour), 1000, replace=False))
+    np.savez_compressed(OUT / "pour_state_1k.npz", state=pour[idx], index=idx)
+    with open(REF / "assets/gripper/68956732a79bf09d8703ab990a2e2319bf5492c792294e9a86632db03b5ac4d5", "rb") as f:
+        blob = NumpyOnlyUnpickler(f).load()
+    sdf = blob["sdf"]
+    np.savez_compressed(OUT / "palm_sdf.npz", sdf=sdf["sdf"], normal=sdf["normal"],
+                        lower=np.asarray(sdf["position"][0]), upper=np.asarray(sdf["position"][1]),
+                        dx=float(sdf["dx"][0]), res=np.asarray(sdf["res"]),
+                        vertices=blob["meshes"][0][0], faces=blob["meshes"][0][1])
+    for p in sorted(OUT.glob("*.npz")):
+        print(p.name, p.stat().st_size)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py - MPM substeps/s (forward + backward) on the S-grip workload (BASELINE config C3:
+1,048,576 particles, 128^3 grid, plasticine + gripper SDF forecast contact), synthetic seeded data.
+
+One "step" = one substep() + one substep_grad() (its forward recompute included), run as K forward
+substeps followed by K backward substeps with inputs resident in HBM.  Contract: SURVEY/driver
+(`python bench.py --gpus N --steps K --warmup W`, one JSON line on rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_sim(args, rank, world):
+    from softmac_amd import scenes
+    from softmac_amd.config import CfgNode
+    from softmac_amd.engine.mpm_simulator import MPMSimulator
+    from softmac_amd.engine.primitive import Mesh, Primitives
+    frames = args.warmup + args.steps + 2
+    dev = int(os.environ.get("LOCAL_RANK", 0)) if world > 1 else 0
+    if args.workload == "s-grip":
+        cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, frames, args.precision, dev, seed=1 + rank)
+    else:
+        cfg, env_dt, state, specs, s13 = scenes.s_elastic(args.particles, args.grid, frames, args.precision, dev, seed=rank)
+    meshes = []
+    for s in specs:
+        pc = CfgNode(); pc.friction = s["friction"]; pc.enable_external_force = True; pc.urdf_path = ""
+        meshes.append(Mesh(sdf=s, cfg=pc, max_timesteps=frames))
+    prims = Primitives(primitives=meshes)
+    sim = MPMSimulator(cfg, prims, env_dt)
+    prims.initialize()
+    for m, s in zip(meshes, specs):
+        m.friction[None] = s["friction"]
+    sim.primitives_contact = [bool(s["contact"]) for s in specs]
+    for i, m in enumerate(meshes):
+        for f in range(frames):
+            st = s13[i].copy()
+            st[:3] += f * cfg.dt * st[7:10]
+            m.set_all_states(f, st)
+    sim.reset(state)
+    return sim, cfg, env_dt, state, specs, s13
+
+
+def algorithmic_bytes(N, G_t, s):
+    """per substep, fwd = 48 s N + 20 s G_t ; bwd = 72 s N + 40 s G_t."""
+    return dict(fwd=48 * s * N + 20 * s * G_t, bwd=72 * s * N + 40 * s * G_t)
+
+
+# compulsory bytes of each kernel taken alone (DESIGN.md "kernels"): scalars per particle, scalars per touched cell
+KERNEL_BYTES = {
+    "p2g": (24 + 9, 4), "grid_op": (0, 4 + 6), "contact": (3, 0), "g2p": (3 + 15, 3),
+    "g2p_grad": (3 + 15 + 3, 3 + 3), "contact_grad": (3, 0), "grid_op_grad": (0, 4 + 6 + 4), "p2g_grad": (24 + 9 + 3 + 24, 4),
+    "clear_grid": (0, 10), "forward_kinematics": (0, 0),
+}
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement, f64) timed on a bounded sample of the same workload on this box's host cores."""
+    import torch
+    from softmac_amd import scenes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from oracle import softmac_oracle as O
+    n_s, grid_s = args.cpu_particles, args.cpu_grid
+    cfg, env_dt, state, specs, s13 = scenes.s_grip(n_s, grid_s, 8, "float64", 0, seed=1)
+    P = H.oracle_params(cfg, env_dt)
+    nsub = args.cpu_steps
+    pstates = []
+    for f in range(nsub + 1):
+        row = []
+        for st in s13:
+            a = st.copy(); a[:3] += f * cfg.dt * a[7:10]; row.append(a)
+        pstates.append(row)
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    orc = H.OracleRollout(P, state, specs, pstates).forward(nsub)
+    rng = np.random.default_rng(0)
+    seeds = {nsub: (rng.standard_normal((n_s, 3)), None, None, None)}
+    orc.backward(seeds)
+    dt = time.perf_counter() - t0
+    per_particle_rate = nsub * n_s / dt                       # particle-substeps / s (fwd+bwd)
+    value = per_particle_rate / args.particles                # scaled to substeps/s at the benchmark's N
+    return {"value": value, "unit": "substeps/s (fwd+bwd)", "cores": threads, "kind": "port",
+            "sample": f"{nsub} fwd+bwd substeps of S-grip at {n_s} particles / {grid_s}^3 (same 8 ppc, same primitives), "
+                      f"f64 torch oracle, {dt:.1f}s, scaled by particle count to {args.particles}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="s-grip", choices=["s-grip", "s-elastic"])
+    ap.add_argument("--particles", type=int, default=1 << 20)
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--precision", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles", type=int, default=1 << 16)
+    ap.add_argument("--cpu-grid", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
+
+    sim, cfg, env_dt, state, specs, s13 = build_sim(args, rank, world)
+    N, K, W = args.particles, args.steps, args.warmup
+    sbytes = 4 if args.precision == "float32" else 8
+    rng = np.random.default_rng(7 + rank)
+    seed_gx = rng.standard_normal((N, 3))
+
+    def barrier():
+        sim.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # warmup: W fwd + W bwd on frames [0, W)
+    sim.run_substeps(0, W)
+    sim.clear_grads()
+    sim.add_grad(W, gx=seed_gx)
+    sim.run_substeps_grad(0, W)
+    sim.clear_grads()
+    sim.add_grad(W + K, gx=seed_gx)
+    for m in sim.primitives:
+        m.clear_ext_f()
+    barrier()
+
+    # timed: K forward substeps then K backward substeps, frames [W, W+K)
+    t0 = time.perf_counter()
+    sim.timer_start()
+    sim.run_substeps(W, K)
+    sim.run_substeps_grad(W, K)
+    dev_ms = sim.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    value = world * K / wall
+
+    # per-kernel HIP-event profile over a second identical pass (kept out of the timed region)
+    sim.clear_grads()
+    sim.add_grad(W + K, gx=seed_gx)
+    sim.profile(True)
+    sim.run_substeps(W, K)
+    sim.run_substeps_grad(W, K)
+    prof = sim.profile_report()
+    sim.profile(False)
+    G_t = sim.count_active_cells(W)
+
+    if rank == 0:
+        kern = {k: v for k, v in prof.items() if v[1] > 0}
+        dom = max(kern, key=lambda k: kern[k][0])
+        avg_ms = kern[dom][0] / kern[dom][1]
+        pp, pc = KERNEL_BYTES[dom]
+        alg = (pp * N + pc * G_t) * sbytes
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        ab = algorithmic_bytes(N, G_t, sbytes)
+        sub_gbs = (ab["fwd"] + ab["bwd"]) * (K / (dev_ms * 1e-3)) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPM substeps/s (fwd+bwd) at 1M particles/128^3 grid",
+            "value": value, "unit": "substeps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * wall / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
+                                   f"3 gripper SDF primitives (2 in forecast contact), fwd+bwd",
+                       "particles_per_gpu": N, "n_grid": args.grid, "touched_cells": G_t,
+                       "parallelism": "1 gpu" if world == 1 else f"{world} independent slabs (no halo yet)"},
+            "device_ms_per_step": dev_ms / K,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
+            "roofline_substep": {"algorithmic_bytes_fwd_bwd": ab["fwd"] + ab["bwd"], "achieved": sub_gbs,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sub_gbs / PEAK_HBM_GBS},
+            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,12 +165,12 @@ class MPMSimulator:
             return None
         return out.reshape(np.asarray(action).shape)
 
-    def substeps(self, s0, count):
+    def run_substeps(self, s0, count):
         """Batched forward: frames s0 .. s0+count-1 in one FFI call."""
         self._push_contact_flags()
         self._h.call("smac_substeps", int(s0), int(count))
 
-    def substeps_grad(self, s0, count, ext_f_grad=None):
+    def run_substeps_grad(self, s0, count, ext_f_grad=None):
         self._push_contact_flags()
         e = None
         if ext_f_grad is not None:

@@ -1,0 +1,104 @@
+"""Synthetic, seeded workloads of SURVEY.md section 8(d) (no datasets are needed or available).
+
+S-grip (BASELINE config C3): 1,048,576 particles at 8 per cell on a 128^3 grid, plasticine
+(fixed-corotated + sigma clamp), sticky floor, three gripper primitives (palm disabled, two fingers
+touching the block and closing at 0.3 m/s) with forecast contact.
+S-elastic (C2): 262,144 particles, 64^3, elastic, no primitives.
+"""
+from __future__ import annotations
+
+import types
+
+import numpy as np
+
+
+def block_cloud(n_particles, n_grid, center, ppc=8, seed=0, v_std=0.1, C_std=1.0, F_std=5e-3):
+    """Uniform random block with `ppc` particles per cell: side = (N/ppc)^(1/3) cells."""
+    rng = np.random.default_rng(seed)
+    side = (n_particles / ppc) ** (1.0 / 3.0) / n_grid
+    lo = np.asarray(center) - side / 2
+    x = lo + side * rng.random((n_particles, 3))
+    v = v_std * rng.standard_normal((n_particles, 3))
+    F = np.eye(3).reshape(1, 9) + F_std * rng.standard_normal((n_particles, 9))
+    C = C_std * rng.standard_normal((n_particles, 9))
+    return np.hstack([x, v, F, C]), lo, side
+
+
+def cylinder_sdf(radius=0.05, height=0.2, dx=0.0025, margin=0.01):
+    """Voxelised SDF of the gripper finger (a y-axis cylinder r=0.05, h=0.2, as built by the reference's
+    assets/gripper/build_gripper_mesh.py) on the grid the reference's voxeliser would choose
+    (mesh.py:170-176, 190-233: dx = min(0.01, extent/80), margin = max(3dx, 0.01), samples at cell centres,
+    negative inside, normal = normal of the closest face)."""
+    half = np.array([radius, height / 2, radius])
+    res = np.ceil((2 * half + 2 * margin) / dx).astype(int)
+    lower = -res * dx / 2.0
+    ax = [np.arange(0.5, r) * dx + l for r, l in zip(res, lower)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    rho = np.sqrt(X * X + Z * Z)
+    dr = rho - radius                    # signed distance to the side
+    dy = np.abs(Y) - height / 2          # signed distance to the caps
+    outside = np.sqrt(np.maximum(dr, 0) ** 2 + np.maximum(dy, 0) ** 2)
+    inside = np.minimum(np.maximum(dr, dy), 0)
+    sdf = outside + inside
+    side_closer = dr > dy                # which face is closest
+    nrm = np.zeros(sdf.shape + (3,))
+    safe = np.maximum(rho, 1e-12)
+    nrm[..., 0] = np.where(side_closer, X / safe, 0.0)
+    nrm[..., 2] = np.where(side_closer, Z / safe, 0.0)
+    nrm[..., 1] = np.where(side_closer, 0.0, np.sign(Y))
+    lower = lower + dx / 2.0
+    upper = lower + (res - 1) * dx
+    return dict(sdf=sdf, normal=nrm, lower=lower, upper=upper, dx=dx, res=res)
+
+
+def box_sdf(half=(0.3, 0.15, 0.075), dx=0.0075, margin=0.0225):
+    """Voxelised SDF of the gripper palm box (assets/gripper/palm.obj), same sampling rule."""
+    half = np.asarray(half)
+    res = np.ceil((2 * half + 2 * margin) / dx).astype(int)
+    lower = -res * dx / 2.0
+    ax = [np.arange(0.5, r) * dx + l for r, l in zip(res, lower)]
+    P = np.stack(np.meshgrid(*ax, indexing="ij"), -1)
+    q = np.abs(P) - half
+    sdf = np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(q.max(-1), 0)
+    k = np.argmax(q, axis=-1)
+    nrm = np.zeros_like(P)
+    np.put_along_axis(nrm, k[..., None], np.take_along_axis(np.sign(P), k[..., None], -1), -1)
+    lower = lower + dx / 2.0
+    upper = lower + (res - 1) * dx
+    return dict(sdf=sdf, normal=nrm, lower=lower, upper=upper, dx=dx, res=res)
+
+
+def sim_namespace(**kw):
+    base = dict(dim=3, dtype="float64", quality=1, yield_stress=30., ground_friction=20., gravity=(0., -9.8, 0.),
+                n_particles=0, dt=1e-4, ptype=0, material_model=0, E=3e3, nu=0.2, max_steps=128, n_controllers=0,
+                collision_type=2, n_grid=128, precision="float32", device=0, grad_enabled=True)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def s_grip(n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
+           substeps=10, x_offset=0.0):
+    """Returns (cfg namespace, env_dt, state24, primitive specs, primitive state13 at frame 0)."""
+    center = (0.5 + x_offset, 0.3, 0.5)
+    state, lo, side = block_cloud(n_particles, n_grid, center, ppc=8, seed=seed, v_std=0.05, C_std=0.5, F_std=5e-3)
+    cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=dt, max_steps=max_steps, precision=precision,
+                        device=device)
+    finger = cylinder_sdf()
+    palm = box_sdf()
+    specs = [dict(palm, friction=0.001, softness=666.0, contact=False),     # demo_grip.py:117 [False, True, True]
+             dict(finger, friction=0.001, softness=666.0, contact=True),
+             dict(finger, friction=0.001, softness=666.0, contact=True)]
+    ident = [1.0, 0.0, 0.0, 0.0]
+    yc = center[1]
+    x_l, x_r = lo[0] - 0.05 + 0.002, lo[0] + side + 0.05 - 0.002          # fingers just biting into the block
+    s13 = [np.array([center[0], lo[1] + side + 0.2, 0.5] + ident + [0, 0, 0] + [0, 0, 0], dtype=np.float64),
+           np.array([x_l, yc, 0.5] + ident + [0.3, 0, 0] + [0, 0, 0], dtype=np.float64),
+           np.array([x_r, yc, 0.5] + ident + [-0.3, 0, 0] + [0, 0, 0], dtype=np.float64)]
+    return cfg, dt * substeps, state, specs, s13
+
+
+def s_elastic(n_particles=1 << 18, n_grid=64, max_steps=128, precision="float32", device=0, seed=0):
+    state, lo, side = block_cloud(n_particles, n_grid, (0.5, 0.5, 0.5), ppc=8, seed=seed, v_std=0.1, C_std=1.0, F_std=0.01)
+    cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=2e-4, ptype=1, max_steps=max_steps,
+                        precision=precision, device=device, ground_friction=1.5)
+    return cfg, 2e-3, state, [], []

@@ -62,6 +62,8 @@ typedef struct smac_config {
     int32_t n_control;        /* cfg.n_controllers (:74-77) */
     int32_t n_primitives;     /* <= SMAC_MAX_PRIMS */
     int32_t rigid_velocity_control; /* 1: substep() advances primitive poses with forward_kinematics (:329-331, 367-369) */
+    int32_t sort_interval;    /* re-bin particles every this many substeps (0 = default 8); no reference counterpart */
+    int32_t reserved1;
     double dt;
     double mu, lam;
     double p_vol, p_mass;

@@ -4,8 +4,11 @@
 //   particle frames  S[f][c][p]   c = 0..23 (x3 v3 C9 E9, E = F - I), SoA so that a wave reads 64
 //                                 consecutive scalars of one component (256 B / 512 B per instruction);
 //   adjoint frames   A[f][c][p]   same shape;
-//   grid             dense n^3, one array per scalar: m, v_in[3], v_mixed[3], v_out[3] and the
-//                    same ten for the adjoints; cell = (i*n + j)*n + k;
+//   grid             n^3 cells in 4x4x4 blocks, block-major (smac_sort.hpp), one array per scalar:
+//                    m, v_in[3], v_mixed[3], v_out[3] and the same ten for the adjoints; only the
+//                    ACTIVE blocks of the current epoch are cleared and swept;
+//   particles        sorted by (block, rank-in-cell); one workgroup per chunk (<= 256 particles of
+//                    one block); scatters accumulate in an 8x8x8-node LDS tile and are flushed once;
 //   primitives       state[P][max_frames][13], grad[P][max_frames][13], ext_f[P][6], ext_f_grad[P][6].
 //
 // Kernel <-> reference map (softmac/engine/mpm_simulator.py):
@@ -20,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "smac_math.hpp"
+#include "smac_sort.hpp"
 
 namespace smac {
 
@@ -40,11 +44,38 @@ template <class R> struct DevSim {
     R* prim_grad;
     R* ext_f;
     R* ext_f_grad;
-    const int* control_idx;
+    const int* control_idx;      // indexed by ORIGINAL particle id
     R* action;
     R* action_grad;
     size_t G;
+    // epoch data (smac_sort.hpp)
+    int nb;                      // blocks per dimension
+    const Chunk* chunks;
+    int nchunks;
+    const int* active;
+    int nactive;
+    const int* orig_id;          // sorted slot -> original particle id
+    const R* An;                 // adjoint of frame f+1 in THIS epoch's particle order (A[f+1] or a re-ordered copy)
+    R* slab;                     // [nchunks][4][TILE_WORDS] per-chunk tiles (P2G: m,vin ; G2P adjoint: agvout)
+    const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
+    const int* block_chunks;
+    int* drift_flag;
 };
+
+// LDS tile: the 6x6x6 nodes a particle whose base lies in a 4x4x4 block can touch (origin = 4*block).
+// A chunk accumulates its scatter there with LDS atomics and stores the tile ONCE, coalesced, to its
+// slab in HBM; the grid kernels then sum, per node, the <= 8 slabs that overlap it.  Particles that
+// drifted out of their block since the last sort fall back to global atomics on the dense arrays.
+constexpr int TW = 6, TSY = 6, TSX = 36, TILE_WORDS = 216;
+__device__ __forceinline__ int tile_index(int li, int lj, int lk) { return li * TSX + lj * TSY + lk; }
+
+// LDS tiles accumulate in f64 whatever R is: measured on gfx950 (tools/microbench/lds_atomics.hip),
+// ds_add_f64 retires a conflict-free wave instruction in ~10 cycles while ds_add_f32 is lane-serial
+// (~193 cycles) - and the f64 sum is the more accurate one anyway.
+typedef double tile_t;
+template <class R> __device__ __forceinline__ void lds_add(tile_t* p, R v) {
+    __hip_atomic_fetch_add(p, (tile_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 template <class R> __device__ __forceinline__ void atomic_add(R* p, R v) { unsafeAtomicAdd(p, v); }
 
@@ -66,15 +97,41 @@ template <class R> __device__ __forceinline__ void load_vec(const R* fr, int c0,
     for (int i = 0; i < cnt; ++i) out[i] = fr[(size_t)(c0 + i) * Npad + p];
 }
 
-// Stencil with the base clamped into the grid for ADDRESSING only (the reference would touch
-// memory outside its fields for a particle that left the [1.5dx, 1-1.5dx] box; we must not).
-template <class R> __device__ __forceinline__ void stencil_at(const DevSim<R>& D, const R* x, Stencil<R>& st, int* cb) {
+// Addresses of the 27 stencil nodes: block-major global cell = cx[i] + cy[j] + cz[k]; tile-local word
+// = tx[i] + ty[j] + tz[k] when the node lies inside the chunk's 6^3 tile (bit i of okx etc.).
+// The base is clamped into the grid for ADDRESSING only (the reference would touch memory outside its
+// fields for a particle that left the [1.5dx, 1-1.5dx] box; we must not).
+struct Nodes {
+    int cx[3], cy[3], cz[3];
+    int tx[3], ty[3], tz[3];
+    int okx, oky, okz;
+    __device__ __forceinline__ int cell(int i, int j, int k) const { return cx[i] + cy[j] + cz[k]; }
+    __device__ __forceinline__ bool in_tile(int i, int j, int k) const { return ((okx >> i) & (oky >> j) & (okz >> k) & 1) != 0; }
+    __device__ __forceinline__ int tile(int i, int j, int k) const { return tx[i] + ty[j] + tz[k]; }
+};
+template <class R> __device__ __forceinline__ void stencil_at(const DevSim<R>& D, const R* x, Stencil<R>& st, Nodes& nd, int block) {
     make_stencil(x, D.inv_dx, st);
+    const int nb = D.nb;
+    const int bz = block % nb, by = (block / nb) % nb, bx = block / (nb * nb);
+    const int org[3] = {4 * bx, 4 * by, 4 * bz};
+    int cb[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int b = st.base[d];
-        b = b < 0 ? 0 : (b > D.n - 3 ? D.n - 3 : b);
-        cb[d] = b;
+        cb[d] = b < 0 ? 0 : (b > D.n - 3 ? D.n - 3 : b);
+    }
+    nd.okx = nd.oky = nd.okz = 0;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const int i = cb[0] + o, j = cb[1] + o, k = cb[2] + o;
+        nd.cx[o] = ((i >> 2) * nb * nb) * 64 + ((i & 3) << 4);
+        nd.cy[o] = ((j >> 2) * nb) * 64 + ((j & 3) << 2);
+        nd.cz[o] = (k >> 2) * 64 + (k & 3);
+        const int li = i - org[0], lj = j - org[1], lk = k - org[2];
+        nd.tx[o] = li * TSX; nd.ty[o] = lj * TSY; nd.tz[o] = lk;
+        nd.okx |= ((unsigned)li < (unsigned)TW) << o;
+        nd.oky |= ((unsigned)lj < (unsigned)TW) << o;
+        nd.okz |= ((unsigned)lk < (unsigned)TW) << o;
     }
 }
 
@@ -87,54 +144,115 @@ template <class R> __device__ __forceinline__ void f_tmp(const R* C, const R* E,
 }
 
 // ------------------------------------------------------------------------------------------
+// chunk prologue shared by the particle kernels
+// ------------------------------------------------------------------------------------------
+#define SMAC_CHUNK_PROLOGUE                                   \
+    const Chunk ch = D.chunks[blockIdx.x];                    \
+    const int t = threadIdx.x;                                \
+    const bool valid = t < ch.count;                          \
+    const int p = ch.start + (valid ? t : 0);
+
+// store this chunk's LDS tile (NS scalars) to its slab, coalesced
+template <class R, int NS> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const tile_t* tile) {
+    R* dst = D.slab + (size_t)blockIdx.x * 4 * TILE_WORDS;
+    for (int i = threadIdx.x; i < NS * TILE_WORDS; i += BLOCK) dst[i] = (R)tile[i];
+}
+
+// Sum, for one cell of block `b`, scalar `c` of every slab that overlaps it (own block and the
+// blocks at -1 along each dimension in which the cell's local coordinate is <= 1).
+template <class R, int NS>
+__device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, R* acc) {
+    const int nb = D.nb;
+    const int bz = b % nb, by = (b / nb) % nb, bx = b / (nb * nb);
+    const int lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
+    const int ex = (lx <= 1 && bx > 0) ? 1 : 0, ey = (ly <= 1 && by > 0) ? 1 : 0, ez = (lz <= 1 && bz > 0) ? 1 : 0;
+    for (int dx = 0; dx <= ex; ++dx)
+        for (int dy = 0; dy <= ey; ++dy)
+            for (int dz = 0; dz <= ez; ++dz) {
+                const int src = ((bx - dx) * nb + (by - dy)) * nb + (bz - dz);
+                const int nch = D.block_chunks[src];
+                if (nch == 0) continue;
+                const int w = tile_index(lx + 4 * dx, ly + 4 * dy, lz + 4 * dz);
+                const R* sl = D.slab + (size_t)D.block_chunk_start[src] * 4 * TILE_WORDS + w;
+                for (int c = 0; c < nch; ++c, sl += 4 * TILE_WORDS)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[s] += sl[s * TILE_WORDS];
+            }
+}
+
+// zero `nfields` consecutive grid fields (starting at field0 of the 20-field block) on the active blocks
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_clear_active(DevSim<R> D, R* base, int nfields) {
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= D.nactive) return;
+    const size_t cell = (size_t)D.active[a] * 64 + (threadIdx.x & 63);
+    for (int f = 0; f < nfields; ++f) base[(size_t)f * D.G + cell] = R(0);
+}
+
+// ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
 template <class R, bool STORE_F>
 __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= D.N) return;
-    const R* Sf = frame(D.S, f, D.Npad);
-    R x[3], v[3], C[9], E[9], Et[9], En[9], stress[9], aff[9];
-    load_vec(Sf, CX, 3, D.Npad, p, x);
-    load_vec(Sf, CV, 3, D.Npad, p, v);
-    load_vec(Sf, CC, 9, D.Npad, p, C);
-    load_vec(Sf, CF, 9, D.Npad, p, E);
-    f_tmp(C, E, D.dt, Et);
-    ConstState<R> cs;
-    constitutive_fwd(D.mat, Et, En, stress, cs);
-    if (STORE_F) {
-        R* Sn = frame(D.S, f + 1, D.Npad);
+    __shared__ tile_t tile[4 * TILE_WORDS];
+    SMAC_CHUNK_PROLOGUE
+    for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
+    __syncthreads();
+    if (valid) {
+        const R* Sf = frame(D.S, f, D.Npad);
+        R x[3], v[3], C[9], E[9], Et[9], En[9], stress[9], aff[9];
+        load_vec(Sf, CX, 3, D.Npad, p, x);
+        load_vec(Sf, CV, 3, D.Npad, p, v);
+        load_vec(Sf, CC, 9, D.Npad, p, C);
+        load_vec(Sf, CF, 9, D.Npad, p, E);
+        f_tmp(C, E, D.dt, Et);
+        ConstState<R> cs;
+        constitutive_fwd(D.mat, Et, En, stress, cs);
+        if (STORE_F) {
+            R* Sn = frame(D.S, f + 1, D.Npad);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Sn[(size_t)(CF + i) * D.Npad + p] = En[i];     // :250
-    }
+            for (int i = 0; i < 9; ++i) Sn[(size_t)(CF + i) * D.Npad + p] = En[i];     // :250
+        }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
-    R imp[3] = {R(0), R(0), R(0)};
-    if (D.n_control > 0) {                                                            // :209-213
-        int ci = D.control_idx[p];
-        if (ci >= 0)
-            for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
-    }
-    Stencil<R> st;
-    int cb[3];
-    stencil_at(D, x, st, cb);
-    const size_t G = D.G;
+        for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
+        R imp[3] = {R(0), R(0), R(0)};
+        if (D.n_control > 0) {                                                            // :209-213
+            int ci = D.control_idx[D.orig_id[p]];
+            if (ci >= 0)
+                for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
+        }
+        Stencil<R> st;
+        Nodes nd;
+        stencil_at(D, x, st, nd, ch.block);
+        const size_t G = D.G;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                const R d0 = (R(i) - st.fx[0]) * D.dx, d1 = (R(j) - st.fx[1]) * D.dx, d2 = (R(k) - st.fx[2]) * D.dx;
-                const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
+                for (int k = 0; k < 3; ++k) {
+                    const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
+                    const R d0 = (R(i) - st.fx[0]) * D.dx, d1 = (R(j) - st.fx[1]) * D.dx, d2 = (R(k) - st.fx[2]) * D.dx;
+                    R mom[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    R mom = D.p_mass * v[c] + aff[3 * c] * d0 + aff[3 * c + 1] * d1 + aff[3 * c + 2] * d2 + imp[c];
-                    atomic_add(D.gvin + c * G + cell, w * mom);                         // :261
+                    for (int c = 0; c < 3; ++c)
+                        mom[c] = w * (D.p_mass * v[c] + aff[3 * c] * d0 + aff[3 * c + 1] * d1 + aff[3 * c + 2] * d2 + imp[c]);   // :261
+                    if (nd.in_tile(i, j, k)) {
+                        tile_t* tp = tile + nd.tile(i, j, k);
+                        lds_add(tp, w * D.p_mass);                                         // :262
+                        lds_add(tp + TILE_WORDS, mom[0]);
+                        lds_add(tp + 2 * TILE_WORDS, mom[1]);
+                        lds_add(tp + 3 * TILE_WORDS, mom[2]);
+                    } else {                                                               // drifted out of the block
+                        const size_t cell = nd.cell(i, j, k);
+                        atomic_add(D.gm + cell, w * D.p_mass);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) atomic_add(D.gvin + c * G + cell, mom[c]);
+                    }
                 }
-                atomic_add(D.gm + cell, w * D.p_mass);                                  // :262
-            }
+    }
+    __syncthreads();
+    tile_store<R, 4>(D, tile);
 }
 
 // boundary_condition :268-281 on a velocity; returns mask bits of the components that were zeroed
@@ -150,17 +268,37 @@ template <class R> __device__ __forceinline__ int boundary(const DevSim<R>& D, i
     return mask;
 }
 
+// one thread per cell of an active block; returns false past the end
+template <class R> __device__ __forceinline__ bool active_cell(const DevSim<R>& D, int& b, int& l, size_t& cell, int& i, int& j, int& k) {
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= D.nactive) return false;
+    b = D.active[a];
+    l = threadIdx.x & 63;
+    cell = (size_t)b * 64 + l;
+    const int nb = D.nb;
+    i = 4 * (b / (nb * nb)) + (l >> 4);
+    j = 4 * ((b / nb) % nb) + ((l >> 2) & 3);
+    k = 4 * (b % nb) + (l & 3);
+    return true;
+}
+
+// slab reduction (completes P2G) fused with grid_op :283-297 / grid_op_mixed1 :396-404
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D) {
-    const size_t cell = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (cell >= D.G) return;
-    const R m = D.gm[cell];
+    int b, l, i, j, k;
+    size_t cell;
+    if (!active_cell(D, b, l, cell, i, j, k)) return;
+    R acc[4] = {D.gm[cell], D.gvin[cell], D.gvin[D.G + cell], D.gvin[2 * D.G + cell]};   // drift fallback part
+    slab_reduce<R, 4>(D, b, l, acc);
+    const R m = acc[0];
+    D.gm[cell] = m;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) D.gvin[d * D.G + cell] = acc[1 + d];
     if (!(m > R(1e-10))) return;                                                       // :286 / :399
-    const int k = cell % D.n, j = (cell / D.n) % D.n, i = cell / ((size_t)D.n * D.n);
     const R inv = R(1) / m;
     R v[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) v[d] = inv * D.gvin[d * D.G + cell] + D.dt * D.g[d];   // :287-288
+    for (int d = 0; d < 3; ++d) v[d] = inv * acc[1 + d] + D.dt * D.g[d];               // :287-288
     boundary(D, i, j, k, v);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -183,7 +321,7 @@ template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& 
 }
 
 template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D, const R* field, const Stencil<R>& st,
-                                                              const int* cb, R* out) {
+                                                              const Nodes& nd, R* out) {
     out[0] = out[1] = out[2] = R(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -192,7 +330,7 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
+                const size_t cell = nd.cell(i, j, k);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) out[c] += w * field[c * D.G + cell];
             }
@@ -200,8 +338,7 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
 
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = p < D.N;
+    SMAC_CHUNK_PROLOGUE
     R x[3] = {R(0.5), R(0.5), R(0.5)};
     if (valid) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
     const int mask = valid ? contact_mask(D, f, x) : 0;
@@ -212,10 +349,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
         for (int c = 0; c < 6; ++c) ext[i][c] = R(0);
     if (mask) {
         Stencil<R> st;
-        int cb[3];
-        stencil_at(D, x, st, cb);
+        Nodes nd;
+        stencil_at(D, x, st, nd, ch.block);
         R v_tmp[3], v_tgt[3];
-        gather_vec(D, D.gvmix, st, cb, v_tmp);                                          // mixed2
+        gather_vec(D, D.gvmix, st, nd, v_tmp);                                          // mixed2
         v_tgt[0] = v_tmp[0]; v_tgt[1] = v_tmp[1]; v_tgt[2] = v_tmp[2];
         const R life = R(1) / R(D.substeps - f % D.substeps);                           // :425
 #pragma unroll
@@ -233,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
+                    const size_t cell = nd.cell(i, j, k);
                     if (D.gm[cell] > R(1e-10)) {
                         const R w = R(2) * st.w[i][0] * st.w[j][1] * st.w[k][2];        // alpha = 2, :437
 #pragma unroll
@@ -258,15 +395,22 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
 
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_g2p(DevSim<R> D, int f) {
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= D.N) return;
+    SMAC_CHUNK_PROLOGUE
+    if (!valid) return;
     const R* Sf = frame(D.S, f, D.Npad);
     R* Sn = frame(D.S, f + 1, D.Npad);
     R x[3];
     load_vec(Sf, CX, 3, D.Npad, p, x);
     Stencil<R> st;
-    int cb[3];
-    stencil_at(D, x, st, cb);
+    Nodes nd;
+    stencil_at(D, x, st, nd, ch.block);
+    if ((nd.okx & nd.oky & nd.okz) != 7) {          // stencil left the chunk's tile: how far has this particle drifted?
+        const int nb = D.nb;
+        const int pb[3] = {st.base[0] >> 2, st.base[1] >> 2, st.base[2] >> 2};
+        const int cbk[3] = {ch.block / (nb * nb), (ch.block / nb) % nb, ch.block % nb};
+        for (int d = 0; d < 3; ++d)
+            if (pb[d] < cbk[d] - 1 || pb[d] > cbk[d] + 1) *D.drift_flag = 1;            // beyond the active halo
+    }
     R nv[3] = {R(0), R(0), R(0)}, nC[9] = {R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0)};
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -276,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void k_g2p(DevSim<R> D, int f) {
             for (int k = 0; k < 3; ++k) {
                 const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
                 const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
-                const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
+                const size_t cell = nd.cell(i, j, k);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const R gv = w * D.gvout[c * D.G + cell];
@@ -320,62 +464,82 @@ template <class R> struct WGrad {
 
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_g2p_grad(DevSim<R> D, int f) {
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= D.N) return;
-    const R* Sf = frame(D.S, f, D.Npad);
-    const R* An = frame(D.A, f + 1, D.Npad);
-    R* Af = frame(D.A, f, D.Npad);
-    R x[3], gx1[3], gv1[3], gC1[9];
-    load_vec(Sf, CX, 3, D.Npad, p, x);
-    load_vec(An, CX, 3, D.Npad, p, gx1);
-    load_vec(An, CV, 3, D.Npad, p, gv1);
-    load_vec(An, CC, 9, D.Npad, p, gC1);
-    Stencil<R> st;
-    int cb[3];
-    stencil_at(D, x, st, cb);
-    const R four_inv_dx = R(4) * D.inv_dx;
-    R gnv[3];
+    __shared__ tile_t tile[3 * TILE_WORDS];
+    SMAC_CHUNK_PROLOGUE
+    for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
+    __syncthreads();
+    if (valid) {
+        const R* Sf = frame(D.S, f, D.Npad);
+        const R* An = D.An;
+        R* Af = frame(D.A, f, D.Npad);
+        R x[3], gx1[3], gv1[3], gC1[9];
+        load_vec(Sf, CX, 3, D.Npad, p, x);
+        load_vec(An, CX, 3, D.Npad, p, gx1);
+        load_vec(An, CV, 3, D.Npad, p, gv1);
+        load_vec(An, CC, 9, D.Npad, p, gC1);
+        Stencil<R> st;
+        Nodes nd;
+        stencil_at(D, x, st, nd, ch.block);
+        const R four_inv_dx = R(4) * D.inv_dx;
+        R gnv[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) gnv[c] = gv1[c] + D.dt * gx1[c];                        // x' = x + dt v'
+        for (int c = 0; c < 3; ++c) gnv[c] = gv1[c] + D.dt * gx1[c];                        // x' = x + dt v'
 #pragma unroll
-    for (int c = 0; c < 9; ++c) gC1[c] *= four_inv_dx;
-    WGrad<R> wg;
-    wg.zero();
-    R gfx[3] = {R(0), R(0), R(0)};
+        for (int c = 0; c < 9; ++c) gC1[c] *= four_inv_dx;
+        WGrad<R> wg;
+        wg.zero();
+        R gfx[3] = {R(0), R(0), R(0)};
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
-                const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
-                R gw = R(0);
-                R gdp[3] = {R(0), R(0), R(0)};
+                for (int k = 0; k < 3; ++k) {
+                    const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
+                    const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
+                    const size_t cell = nd.cell(i, j, k);
+                    const bool in = nd.in_tile(i, j, k);
+                    tile_t* tp = tile + nd.tile(i, j, k);
+                    R gw = R(0);
+                    R gdp[3] = {R(0), R(0), R(0)};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const R gvn = D.gvout[c * D.G + cell];
-                    // d(out)/d g_v[c] = w (gnv[c] + sum_d gC[c][d] dp[d])
-                    const R t = gnv[c] + gC1[3 * c] * dp[0] + gC1[3 * c + 1] * dp[1] + gC1[3 * c + 2] * dp[2];
-                    atomic_add(D.agvout + c * D.G + cell, w * t);
-                    gw += gvn * t;
+                    for (int c = 0; c < 3; ++c) {
+                        const R gvn = D.gvout[c * D.G + cell];
+                        // d(out)/d g_v[c] = w (gnv[c] + sum_d gC[c][d] dp[d])
+                        const R tt = gnv[c] + gC1[3 * c] * dp[0] + gC1[3 * c + 1] * dp[1] + gC1[3 * c + 2] * dp[2];
+                        if (in) lds_add(tp + c * TILE_WORDS, w * tt);
+                        else atomic_add(D.agvout + c * D.G + cell, w * tt);
+                        gw += gvn * tt;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) gdp[d] += gvn * gC1[3 * c + d];
+                        for (int d = 0; d < 3; ++d) gdp[d] += gvn * gC1[3 * c + d];
+                    }
+                    wg.add(st, i, j, k, gw);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) gfx[d] -= w * gdp[d];                        // dpos = offset - fx
                 }
-                wg.add(st, i, j, k, gw);
+        wg.to_fx(st, gfx);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) gfx[d] -= w * gdp[d];                        // dpos = offset - fx
-            }
-    wg.to_fx(st, gfx);
+        for (int d = 0; d < 3; ++d) Af[(size_t)(CX + d) * D.Npad + p] += gx1[d] + D.inv_dx * gfx[d];
+    }
+    __syncthreads();
+    tile_store<R, 3>(D, tile);
+}
+
+// completes the G2P-adjoint scatter: agvout += sum of overlapping slabs
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_reduce_agvout(DevSim<R> D) {
+    int b, l, i, j, k;
+    size_t cell;
+    if (!active_cell(D, b, l, cell, i, j, k)) return;
+    R acc[3] = {D.agvout[cell], D.agvout[D.G + cell], D.agvout[2 * D.G + cell]};
+    slab_reduce<R, 3>(D, b, l, acc);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) Af[(size_t)(CX + d) * D.Npad + p] += gx1[d] + D.inv_dx * gfx[d];
+    for (int d = 0; d < 3; ++d) D.agvout[d * D.G + cell] = acc[d];
 }
 
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = p < D.N;
+    SMAC_CHUNK_PROLOGUE
     R x[3] = {R(0.5), R(0.5), R(0.5)};
     if (valid) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
     const int mask = valid ? contact_mask(D, f, x) : 0;
@@ -386,12 +550,12 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         for (int c = 0; c < 13; ++c) gst[i][c] = R(0);
     if (mask) {
         Stencil<R> st;
-        int cb[3];
-        stencil_at(D, x, st, cb);
+        Nodes nd;
+        stencil_at(D, x, st, nd, ch.block);
         const R life = R(1) / R(D.substeps - f % D.substeps);
         // recompute the forward chain, keeping the velocity entering each primitive
         R v_tmp[3], vin[MAX_PRIMS][3], vcur[3], dummy[6];
-        gather_vec(D, D.gvmix, st, cb, v_tmp);
+        gather_vec(D, D.gvmix, st, nd, v_tmp);
         vcur[0] = v_tmp[0]; vcur[1] = v_tmp[1]; vcur[2] = v_tmp[2];
 #pragma unroll
         for (int i = 0; i < MAX_PRIMS; ++i) {
@@ -414,7 +578,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
+                    const size_t cell = nd.cell(i, j, k);
                     if (D.gm[cell] > R(1e-10)) {
                         const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
                         R dg = R(0);
@@ -450,7 +614,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                    const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
+                    const size_t cell = nd.cell(i, j, k);
                     R gw = R(0);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -482,11 +646,11 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
 
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
-    const size_t cell = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (cell >= D.G) return;
+    int b, l, i, j, k;
+    size_t cell;
+    if (!active_cell(D, b, l, cell, i, j, k)) return;
     const R m = D.gm[cell];
     if (!(m > R(1e-10))) return;
-    const int k = cell % D.n, j = (cell / D.n) % D.n, i = cell / ((size_t)D.n * D.n);
     const R inv = R(1) / m;
     R v[3], vin[3], g[3];
 #pragma unroll
@@ -509,10 +673,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
 
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= D.N) return;
+    SMAC_CHUNK_PROLOGUE
+    if (!valid) return;
     const R* Sf = frame(D.S, f, D.Npad);
-    const R* An = frame(D.A, f + 1, D.Npad);
+    const R* An = D.An;
     R* Af = frame(D.A, f, D.Npad);
     R x[3], v[3], C[9], E[9], Et[9], En[9], stress[9], aff[9];
     load_vec(Sf, CX, 3, D.Npad, p, x);
@@ -527,13 +691,13 @@ __global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
     R imp[3] = {R(0), R(0), R(0)};
     int ci = -1;
     if (D.n_control > 0) {
-        ci = D.control_idx[p];
+        ci = D.control_idx[D.orig_id[p]];
         if (ci >= 0)
             for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
     }
     Stencil<R> st;
-    int cb[3];
-    stencil_at(D, x, st, cb);
+    Nodes nd;
+    stencil_at(D, x, st, nd, ch.block);
     WGrad<R> wg;
     wg.zero();
     R gvp[3] = {R(0), R(0), R(0)}, gfx[3] = {R(0), R(0), R(0)};
@@ -546,7 +710,7 @@ __global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
             for (int k = 0; k < 3; ++k) {
                 const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
                 const R dp[3] = {(R(i) - st.fx[0]) * D.dx, (R(j) - st.fx[1]) * D.dx, (R(k) - st.fx[2]) * D.dx};
-                const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
+                const size_t cell = nd.cell(i, j, k);
                 R gw = D.agm[cell] * D.p_mass;
                 R gdp[3] = {R(0), R(0), R(0)};
 #pragma unroll
@@ -600,20 +764,21 @@ __global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
 // ------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------
+// compute_grid_m_kernel :607-617 - dense (i,j,k) row-major output, particle order irrelevant
 template <class R>
-__global__ void k_grid_m_only(DevSim<R> D, int f) {                                    // compute_grid_m_kernel :607-617
+__global__ void k_grid_m_only(const R* x0, const R* x1, const R* x2, int N, int n, R inv_dx, R p_mass, R* out) {
     const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= D.N) return;
-    R x[3];
-    load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+    if (p >= N) return;
+    const R x[3] = {x0[p], x1[p], x2[p]};
     Stencil<R> st;
+    make_stencil(x, inv_dx, st);
     int cb[3];
-    stencil_at(D, x, st, cb);
+    for (int d = 0; d < 3; ++d) cb[d] = st.base[d] < 0 ? 0 : (st.base[d] > n - 3 ? n - 3 : st.base[d]);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
             for (int k = 0; k < 3; ++k) {
-                const size_t cell = ((size_t)(cb[0] + i) * D.n + (cb[1] + j)) * D.n + (cb[2] + k);
-                atomic_add(D.gm + cell, st.w[i][0] * st.w[j][1] * st.w[k][2] * D.p_mass);
+                const size_t cell = ((size_t)(cb[0] + i) * n + (cb[1] + j)) * n + (cb[2] + k);
+                atomic_add(out + cell, st.w[i][0] * st.w[j][1] * st.w[k][2] * p_mass);
             }
 }
 

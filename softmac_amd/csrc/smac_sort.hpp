@@ -1,0 +1,139 @@
+// Particle binning for the block-sparse grid (no reference counterpart: the reference keeps
+// particles in creation order and sweeps a dense grid; see DESIGN.md "layout").
+//
+//   grid   : cells grouped in 4x4x4 blocks, block-major:  cell = block*64 + (lx*16 + ly*4 + lz)
+//            -> one block = 64 consecutive scalars = one 256-B wave access per field
+//   sort   : counting sort with key = block*KMAX + min(rank_in_cell, KMAX-1).  All particles of one
+//            bin live in DIFFERENT cells, so the 64 lanes of a wave scatter to (mostly) distinct
+//            nodes: LDS / global float atomics do not serialise on one address.
+//   chunks : each non-empty block is cut into work items of <= 4 waves (256 particles);
+//            one workgroup per chunk, one LDS tile per workgroup.
+//   active : blocks within [-1,+2]^3 of a block that holds particle bases - every cell a particle can
+//            touch until the next re-sort (drift < 4 cells); only these are cleared / swept.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "smac_math.hpp"
+
+namespace smac {
+
+constexpr int KMAX = 16;        // rank-in-cell bins per block
+constexpr int CHUNK = 256;      // particles per work item (4 waves)
+
+struct Chunk { int block, start, count; };
+
+__host__ __device__ __forceinline__ int block_of(int nb, int i, int j, int k) { return ((i >> 2) * nb + (j >> 2)) * nb + (k >> 2); }
+__host__ __device__ __forceinline__ size_t cell_of(int nb, int i, int j, int k) {
+    return (size_t)block_of(nb, i, j, k) * 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
+}
+
+// pass 1: rank of each particle inside its cell, key, slot inside its (block, rank) bin
+template <class R>
+__global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, int N, int n, int nb, R inv_dx, int* cell_count,
+                            int* bin_count, int* key_out, int* slot_out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const R x[3] = {x0[p], x1[p], x2[p]};
+    int b[3];
+    for (int d = 0; d < 3; ++d) {
+        int v = (int)(x[d] * inv_dx - R(0.5));
+        b[d] = v < 0 ? 0 : (v > n - 3 ? n - 3 : v);
+    }
+    const size_t cell = cell_of(nb, b[0], b[1], b[2]);
+    const int r = atomicAdd(cell_count + cell, 1);
+    const int key = (int)(cell >> 6) * KMAX + (r < KMAX - 1 ? r : KMAX - 1);
+    key_out[p] = key;
+    slot_out[p] = atomicAdd(bin_count + key, 1);
+}
+
+// pass 2 (after an exclusive scan of bin_count): destination index + composed original id
+__global__ void k_sort_dest(int N, const int* key, const int* slot, const int* bin_start, const int* orig_old, int* dest,
+                            int* orig_new) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int q = bin_start[key[p]] + slot[p];
+    dest[p] = q;
+    orig_new[q] = orig_old ? orig_old[p] : p;
+}
+
+// pass 3: move one component row of a frame
+template <class R>
+__global__ void k_sort_move(int N, const int* dest, const R* src, R* dst, int Npad, int ncomp) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int q = dest[p];
+    for (int c = 0; c < ncomp; ++c) dst[(size_t)c * Npad + q] = src[(size_t)c * Npad + p];
+}
+
+// gather form, used to bring an adjoint frame from one epoch's order into another's:
+//   dst[q] = src[ map[q] ]
+template <class R>
+__global__ void k_gather_rows(int N, const int* map, const R* src, R* dst, int Npad, int ncomp) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const int p = map[q];
+    for (int c = 0; c < ncomp; ++c) dst[(size_t)c * Npad + q] = src[(size_t)c * Npad + p];
+}
+
+// inverse[orig[q]] = q
+__global__ void k_invert(int N, const int* orig, int* inv) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < N) inv[orig[q]] = q;
+}
+// map[q_to] = inv_from[ orig_to[q_to] ]  : position in epoch "from" of the particle at q_to in epoch "to"
+__global__ void k_compose(int N, const int* orig_to, const int* inv_from, int* map) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < N) map[q] = inv_from[orig_to[q]];
+}
+
+// per block: particle count (from the scanned bins), number of chunks, halo flags
+__global__ void k_block_info(int nblocks, int nb, const int* bin_start, int N, int* block_start, int* block_chunks,
+                             int* active_flag) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int s = bin_start[b * KMAX];
+    const int e = (b + 1 < nblocks) ? bin_start[(b + 1) * KMAX] : N;
+    const int cnt = e - s;
+    block_start[b] = s;
+    const int waves = (cnt + 63) / 64;
+    block_chunks[b] = (waves + 3) / 4;
+    if (cnt > 0) {
+        const int bz = b % nb, by = (b / nb) % nb, bx = b / (nb * nb);
+        for (int i = -1; i <= 2; ++i)
+            for (int j = -1; j <= 2; ++j)
+                for (int k = -1; k <= 2; ++k) {
+                    const int X = bx + i, Y = by + j, Z = bz + k;
+                    if (X < 0 || Y < 0 || Z < 0 || X >= nb || Y >= nb || Z >= nb) continue;
+                    active_flag[(X * nb + Y) * nb + Z] = 1;
+                }
+    }
+}
+
+// write the chunk list (chunk_start = exclusive scan of block_chunks) and the compacted active list
+__global__ void k_emit_lists(int nblocks, int N, const int* bin_start, const int* block_start, const int* block_chunks,
+                             const int* chunk_start, const int* active_flag, const int* active_start, Chunk* chunks,
+                             int* active) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int nch = block_chunks[b];
+    if (nch > 0) {
+        const int s = block_start[b];
+        const int e = (b + 1 < nblocks) ? bin_start[(b + 1) * KMAX] : N;
+        const int waves = (e - s + 63) / 64;
+        int w0 = 0;
+        for (int c = 0; c < nch; ++c) {
+            const int w = waves / nch + (c < waves % nch ? 1 : 0);       // waves of this chunk (<= 4)
+            Chunk ch;
+            ch.block = b;
+            ch.start = s + w0 * 64;
+            const int end = s + (w0 + w) * 64;
+            ch.count = (end < e ? end : e) - ch.start;
+            chunks[chunk_start[b] + c] = ch;
+            w0 += w;
+        }
+    }
+    if (active_flag[b]) active[active_start[b]] = b;
+}
+
+}  // namespace smac

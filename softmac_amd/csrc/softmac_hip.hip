@@ -33,9 +33,9 @@ static thread_local std::string g_create_error;
         }                                    \
     } while (0)
 
-enum KernelId { K_CLEAR = 0, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_COUNT };
-static const char* kKernelNames[K_COUNT] = {"clear_grid", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "contact_grad",
-                                            "grid_op_grad", "p2g_grad", "forward_kinematics"};
+enum KernelId { K_CLEAR = 0, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"clear_grid", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
+                                            "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint"};
 
 struct ISim {
     std::string err;
@@ -96,11 +96,47 @@ template <class R> struct Sim final : ISim {
     int64_t prof_n[K_COUNT] = {};
     std::vector<R> stage;
 
+    // ---- epochs: one per re-sort.  Epoch 0 is the identity order of user-provided frames.
+    struct Epoch {
+        int* orig = nullptr;        // sorted slot -> original id (device)
+        int* inv = nullptr;         // original id -> sorted slot (device, lazy)
+        Chunk* chunks = nullptr;
+        int nchunks = 0;
+        int* active = nullptr;
+        int nactive = 0;
+        int* block_chunk_start = nullptr;
+        int* block_chunks = nullptr;
+        int frame = 0;              // frame at which the sort happened
+        std::vector<int> h_orig;    // host copy (lazy) for IO
+        bool live = false;
+    };
+    std::vector<Epoch> epochs;      // [0] = identity
+    std::vector<int> frame_epoch;   // order tag of S[f]   (-1: never written)
+    std::vector<int> adj_epoch;     // order tag of A[f]   (-1: all zero, any order)
+    int grid_epoch = 0;             // epoch whose active blocks may hold non-zero grid data
+    int sort_interval = 8;
+    int nblocks = 0;
+    // sort scratch
+    int *d_cell_count = nullptr, *d_bin = nullptr, *d_bin_start = nullptr, *d_key = nullptr, *d_slot = nullptr, *d_dest = nullptr;
+    int *d_block_start = nullptr, *d_block_chunks = nullptr, *d_chunk_start = nullptr, *d_active_flag = nullptr, *d_active_start = nullptr;
+    int* d_map = nullptr;
+    void* d_cub = nullptr;
+    size_t cub_bytes = 0;
+    R* tmp_frame = nullptr;         // NCOMP*Npad scratch (sort moves, re-ordered adjoints)
+    R* slab = nullptr;
+    size_t slab_chunks = 0;
+    int* d_drift = nullptr;
+    R* dense_tmp = nullptr;
+
     ~Sim() override {
         if (stream) hipStreamSynchronize(stream);
         hipFree(D.S); hipFree(D.A); hipFree(grid_block); hipFree(D.prim_state); hipFree(D.prim_grad);
         hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);
         hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
+        for (auto& e : epochs) free_epoch(e);
+        hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
+        hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
+        hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
         for (auto e : pool) hipEventDestroy(e);
         for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -117,6 +153,7 @@ template <class R> struct Sim final : ISim {
         REQUIRE(c.n_particles > 0 && c.n_grid >= 8 && c.max_frames >= 2, "bad sizes");
         REQUIRE(c.n_primitives >= 0 && c.n_primitives <= SMAC_MAX_PRIMS, "n_primitives > SMAC_MAX_PRIMS");
         REQUIRE(c.substeps >= 1, "substeps < 1");
+        REQUIRE(c.n_grid % 4 == 0, "n_grid must be a multiple of 4 (4x4x4 grid blocks)");
         HIP_TRY(hipSetDevice(c.device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&t0));
@@ -174,6 +211,31 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(d_control_idx, 0, D.Npad * sizeof(int), stream));   // ti.field default 0 (:76)
         D.control_idx = d_control_idx;
         HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
+        // block-sparse grid + sort scratch
+        D.nb = c.n_grid / 4;
+        nblocks = D.nb * D.nb * D.nb;
+        sort_interval = c.sort_interval > 0 ? c.sort_interval : 8;
+        HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_bin, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_bin_start, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_key, D.Npad * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_slot, D.Npad * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_dest, D.Npad * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_map, D.Npad * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_block_start, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_block_chunks, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_chunk_start, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_active_flag, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_active_start, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&tmp_frame, fs));
+        HIP_TRY(hipMalloc((void**)&d_drift, sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
+        D.drift_flag = d_drift;
+        epochs.clear();
+        epochs.emplace_back();
+        epochs[0].live = true;
+        frame_epoch.assign(c.max_frames, -1);
+        adj_epoch.assign(c.max_frames, -1);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
             D.prim[i].sdf = nullptr; D.prim[i].normal = nullptr; D.prim[i].contact = 0;
             D.prim[i].friction = (R)0.9; D.prim[i].softness = (R)666.0; D.prim[i].inv_dx = (R)1;
@@ -217,31 +279,47 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
 
-    int sync() override { HIP_TRY(hipStreamSynchronize(stream)); return SMAC_OK; }
+    int sync() override { HIP_TRY(hipStreamSynchronize(stream)); return check_drift(); }
 
     // ---- IO -----------------------------------------------------------------------------
-    int upload_comp(R* base, int f, int c0, int cnt, const double* src, bool minus_identity) {
+    // host copy of an epoch's slot -> original-id table (identity for epoch 0)
+    const int* host_orig(int e) {
+        if (e <= 0) return nullptr;
+        Epoch& ep = epochs[e];
+        if (ep.h_orig.empty()) {
+            ep.h_orig.resize(D.N);
+            hipMemcpyAsync(ep.h_orig.data(), ep.orig, D.N * sizeof(int), hipMemcpyDeviceToHost, stream);
+            hipStreamSynchronize(stream);
+        }
+        return ep.h_orig.data();
+    }
+    // src is in ORIGINAL particle order; the frame is stored in the order of epoch `e`
+    int upload_comp(R* base, int f, int c0, int cnt, const double* src, bool minus_identity, int e) {
         stage.resize((size_t)cnt * D.Npad);
+        const int* orig = host_orig(e);
         for (int c = 0; c < cnt; ++c) {
             R* dst = stage.data() + (size_t)c * D.Npad;
             const double sub = (minus_identity && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
-            for (int p = 0; p < D.N; ++p) dst[p] = (R)(src[(size_t)p * cnt + c] - sub);
-            for (int p = D.N; p < D.Npad; ++p) dst[p] = 0;
+            if (orig) for (int q = 0; q < D.N; ++q) dst[q] = (R)(src[(size_t)orig[q] * cnt + c] - sub);
+            else for (int q = 0; q < D.N; ++q) dst[q] = (R)(src[(size_t)q * cnt + c] - sub);
+            for (int q = D.N; q < D.Npad; ++q) dst[q] = 0;
         }
         R* d = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
         HIP_TRY(hipMemcpyAsync(d, stage.data(), stage.size() * sizeof(R), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
     }
-    int download_comp(const R* base, int f, int c0, int cnt, double* dst, bool plus_identity) {
+    int download_comp(const R* base, int f, int c0, int cnt, double* dst, bool plus_identity, int e) {
         stage.resize((size_t)cnt * D.Npad);
         const R* s = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
         HIP_TRY(hipMemcpyAsync(stage.data(), s, stage.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        const int* orig = host_orig(e);
         for (int c = 0; c < cnt; ++c) {
             const R* src = stage.data() + (size_t)c * D.Npad;
             const double add = (plus_identity && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
-            for (int p = 0; p < D.N; ++p) dst[(size_t)p * cnt + c] = (double)src[p] + add;
+            if (orig) for (int q = 0; q < D.N; ++q) dst[(size_t)orig[q] * cnt + c] = (double)src[q] + add;
+            else for (int q = 0; q < D.N; ++q) dst[(size_t)q * cnt + c] = (double)src[q] + add;
         }
         return SMAC_OK;
     }
@@ -253,19 +331,22 @@ template <class R> struct Sim final : ISim {
     int set_frame(int f, const double* x, const double* v, const double* F, const double* C) override {
         int rc = check_frame(f);
         if (rc) return rc;
-        if (x && (rc = upload_comp(D.S, f, CX, 3, x, false))) return rc;
-        if (v && (rc = upload_comp(D.S, f, CV, 3, v, false))) return rc;
-        if (C && (rc = upload_comp(D.S, f, CC, 9, C, false))) return rc;
-        if (F && (rc = upload_comp(D.S, f, CF, 9, F, true))) return rc;
+        if (frame_epoch[f] < 0) frame_epoch[f] = 0;          // first write: identity order
+        const int e = frame_epoch[f];
+        if (x && (rc = upload_comp(D.S, f, CX, 3, x, false, e))) return rc;
+        if (v && (rc = upload_comp(D.S, f, CV, 3, v, false, e))) return rc;
+        if (C && (rc = upload_comp(D.S, f, CC, 9, C, false, e))) return rc;
+        if (F && (rc = upload_comp(D.S, f, CF, 9, F, true, e))) return rc;
         return SMAC_OK;
     }
     int get_frame(int f, double* x, double* v, double* F, double* C) override {
         int rc = check_frame(f);
         if (rc) return rc;
-        if (x && (rc = download_comp(D.S, f, CX, 3, x, false))) return rc;
-        if (v && (rc = download_comp(D.S, f, CV, 3, v, false))) return rc;
-        if (C && (rc = download_comp(D.S, f, CC, 9, C, false))) return rc;
-        if (F && (rc = download_comp(D.S, f, CF, 9, F, true))) return rc;
+        const int e = frame_epoch[f] < 0 ? 0 : frame_epoch[f];
+        if (x && (rc = download_comp(D.S, f, CX, 3, x, false, e))) return rc;
+        if (v && (rc = download_comp(D.S, f, CV, 3, v, false, e))) return rc;
+        if (C && (rc = download_comp(D.S, f, CC, 9, C, false, e))) return rc;
+        if (F && (rc = download_comp(D.S, f, CF, 9, F, true, e))) return rc;
         return SMAC_OK;
     }
     int reset(const double* state, int cols) override {                       // mpm_simulator.py:494-519
@@ -282,6 +363,7 @@ template <class R> struct Sim final : ISim {
                 F[(size_t)p * 9] = F[(size_t)p * 9 + 4] = F[(size_t)p * 9 + 8] = 1.0;
             }
         }
+        frame_epoch[0] = 0;                                                   // user data: identity order, re-binned at the next substep
         return set_frame(0, x.data(), v.data(), F.data(), C.data());
     }
     int copy_frame(int src, int dst) override {                               // :468-479
@@ -290,6 +372,7 @@ template <class R> struct Sim final : ISim {
         if (src == dst) return SMAC_OK;
         HIP_TRY(hipMemcpyAsync(D.S + (size_t)dst * frame_scalars(), D.S + (size_t)src * frame_scalars(),
                                frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        frame_epoch[dst] = frame_epoch[src];
         for (int i = 0; i < D.P; ++i)
             for (int j = 0; j < cfg.substeps; ++j) {
                 if (src + j >= cfg.max_frames || dst + j >= cfg.max_frames) break;
@@ -309,29 +392,33 @@ template <class R> struct Sim final : ISim {
     int get_grad(int f, double* gx, double* gv, double* gF, double* gC) override {
         int rc;
         if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
-        if (gx && (rc = download_comp(D.A, f, CX, 3, gx, false))) return rc;
-        if (gv && (rc = download_comp(D.A, f, CV, 3, gv, false))) return rc;
-        if (gC && (rc = download_comp(D.A, f, CC, 9, gC, false))) return rc;
-        if (gF && (rc = download_comp(D.A, f, CF, 9, gF, false))) return rc;
+        const int e = adj_epoch[f] < 0 ? 0 : adj_epoch[f];
+        if (gx && (rc = download_comp(D.A, f, CX, 3, gx, false, e))) return rc;
+        if (gv && (rc = download_comp(D.A, f, CV, 3, gv, false, e))) return rc;
+        if (gC && (rc = download_comp(D.A, f, CC, 9, gC, false, e))) return rc;
+        if (gF && (rc = download_comp(D.A, f, CF, 9, gF, false, e))) return rc;
         return SMAC_OK;
     }
     int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) override {
         int rc;
         if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
+        if (adj_epoch[f] < 0) adj_epoch[f] = frame_epoch[f] < 0 ? 0 : frame_epoch[f];   // empty adjoint frame: adopt the state's order
+        const int e = adj_epoch[f];
         const double* src[4] = {gx, gv, gC, gF};
         const int c0[4] = {CX, CV, CC, CF}, cnt[4] = {3, 3, 9, 9};
         std::vector<double> cur;
         for (int a = 0; a < 4; ++a) {
             if (!src[a]) continue;
             cur.resize((size_t)D.N * cnt[a]);
-            if ((rc = download_comp(D.A, f, c0[a], cnt[a], cur.data(), false))) return rc;
+            if ((rc = download_comp(D.A, f, c0[a], cnt[a], cur.data(), false, e))) return rc;
             for (size_t i = 0; i < cur.size(); ++i) cur[i] += src[a][i];
-            if ((rc = upload_comp(D.A, f, c0[a], cnt[a], cur.data(), false))) return rc;
+            if ((rc = upload_comp(D.A, f, c0[a], cnt[a], cur.data(), false, e))) return rc;
         }
         return SMAC_OK;
     }
     int clear_grads() override {
         if (D.A) HIP_TRY(hipMemsetAsync(D.A, 0, frame_scalars() * sizeof(R) * cfg.max_frames, stream));
+        adj_epoch.assign(cfg.max_frames, -1);
         const int Pn = D.P > 0 ? D.P : 1;
         HIP_TRY(hipMemsetAsync(D.prim_grad, 0, (size_t)Pn * cfg.max_frames * 13 * sizeof(R), stream));
         HIP_TRY(hipMemsetAsync(action_buf_grad, 0, (size_t)Pn * cfg.max_frames * 6 * sizeof(R), stream));
@@ -348,30 +435,184 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
     }
+    int dense_grid_m(int f) {                                                 // dense row-major grid_m of frame f in dense_tmp
+        if (!dense_tmp) HIP_TRY(hipMalloc((void**)&dense_tmp, D.G * sizeof(R)));
+        HIP_TRY(hipMemsetAsync(dense_tmp, 0, D.G * sizeof(R), stream));
+        const R* Sf = D.S + (size_t)f * frame_scalars();
+        hipLaunchKernelGGL(k_grid_m_only<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad, D.N,
+                           D.n, D.inv_dx, D.p_mass, dense_tmp);
+        return check_launch();
+    }
     int compute_grid_m(int f, double* out) override {
         int rc = check_frame(f);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(D.gm, 0, D.G * sizeof(R), stream));
-        hipLaunchKernelGGL(k_grid_m_only<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
-        if ((rc = check_launch())) return rc;
+        if ((rc = dense_grid_m(f))) return rc;
         if (out) {
             std::vector<R> tmp(D.G);
-            HIP_TRY(hipMemcpyAsync(tmp.data(), D.gm, D.G * sizeof(R), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(tmp.data(), dense_tmp, D.G * sizeof(R), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             for (size_t i = 0; i < D.G; ++i) out[i] = (double)tmp[i];
         }
         return SMAC_OK;
     }
     int count_active_cells(int f, int64_t* cells) override {
-        int rc = compute_grid_m(f, nullptr);
+        int rc = check_frame(f);
         if (rc) return rc;
+        if ((rc = dense_grid_m(f))) return rc;
         HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(k_count_active<R>, dim3(nblk(D.G)), dim3(BLOCK), 0, stream, D.gm, D.G, d_counter);
+        hipLaunchKernelGGL(k_count_active<R>, dim3(nblk(D.G)), dim3(BLOCK), 0, stream, (const R*)dense_tmp, D.G, d_counter);
         if ((rc = check_launch())) return rc;
         unsigned long long h = 0;
         HIP_TRY(hipMemcpyAsync(&h, d_counter, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         *cells = (int64_t)h;
+        return SMAC_OK;
+    }
+
+    // ---- epochs / sorting ------------------------------------------------------------------
+    static void free_epoch(Epoch& e) {
+        hipFree(e.orig); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks);
+        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = nullptr;
+        e.chunks = nullptr;
+        e.h_orig.clear(); e.h_orig.shrink_to_fit();
+        e.live = false;
+    }
+    void gc_epochs() {                                   // drop epochs no frame refers to any more
+        std::vector<char> used(epochs.size(), 0);
+        used[0] = 1;
+        used[grid_epoch] = 1;
+        for (int e : frame_epoch) if (e > 0) used[e] = 1;
+        for (int e : adj_epoch) if (e > 0) used[e] = 1;
+        for (size_t e = 1; e < epochs.size(); ++e)
+            if (!used[e] && epochs[e].live) free_epoch(epochs[e]);
+    }
+    int new_epoch_slot() {
+        for (size_t e = 1; e < epochs.size(); ++e)
+            if (!epochs[e].live) return (int)e;
+        epochs.emplace_back();
+        return (int)epochs.size() - 1;
+    }
+    int scan(const int* in, int* out, int n) {
+        size_t need = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, n, stream);
+        if (need > cub_bytes) {
+            hipFree(d_cub);
+            HIP_TRY(hipMalloc(&d_cub, need));
+            cub_bytes = need;
+        }
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_cub, need, in, out, n, stream));
+        return SMAC_OK;
+    }
+    // Re-bin frame f (smac_sort.hpp).  The frame is rewritten in the new order and gets a new epoch.
+    int sort_frame(int f) {
+        const int e_old = frame_epoch[f];
+        gc_epochs();
+        const int e_new = new_epoch_slot();
+        prof_begin(K_SORT);
+        const int nbins = nblocks * KMAX;
+        R* Sf = D.S + (size_t)f * frame_scalars();
+        HIP_TRY(hipMemsetAsync(d_cell_count, 0, D.G * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(d_bin, 0, ((size_t)nbins + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + D.Npad),
+                           (const R*)(Sf + 2 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_bin, d_key, d_slot);
+        int rc = scan(d_bin, d_bin_start, nbins + 1);
+        if (rc) return rc;
+        Epoch ep;
+        HIP_TRY(hipMalloc((void**)&ep.orig, D.Npad * sizeof(int)));
+        hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot,
+                           (const int*)d_bin_start, (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig);
+        hipLaunchKernelGGL(k_sort_move<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_dest, (const R*)Sf, tmp_frame,
+                           D.Npad, (int)NCOMP);
+        HIP_TRY(hipMemcpyAsync(Sf, tmp_frame, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        // block info, chunk list, active list
+        HIP_TRY(hipMemsetAsync(d_active_flag, 0, (nblocks + 1) * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(d_block_chunks, 0, (nblocks + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_block_info, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.nb, (const int*)d_bin_start, D.N,
+                           d_block_start, d_block_chunks, d_active_flag);
+        if ((rc = scan(d_block_chunks, d_chunk_start, nblocks + 1))) return rc;
+        if ((rc = scan(d_active_flag, d_active_start, nblocks + 1))) return rc;
+        int totals[2];
+        HIP_TRY(hipMemcpyAsync(&totals[0], d_chunk_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&totals[1], d_active_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        ep.nchunks = totals[0];
+        ep.nactive = totals[1];
+        HIP_TRY(hipMalloc((void**)&ep.chunks, (size_t)(ep.nchunks > 0 ? ep.nchunks : 1) * sizeof(Chunk)));
+        HIP_TRY(hipMalloc((void**)&ep.active, (size_t)(ep.nactive > 0 ? ep.nactive : 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.block_chunk_start, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.block_chunks, (nblocks + 1) * sizeof(int)));
+        hipLaunchKernelGGL(k_emit_lists, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.N, (const int*)d_bin_start,
+                           (const int*)d_block_start, (const int*)d_block_chunks, (const int*)d_chunk_start,
+                           (const int*)d_active_flag, (const int*)d_active_start, ep.chunks, ep.active);
+        HIP_TRY(hipMemcpyAsync(ep.block_chunk_start, d_chunk_start, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(ep.block_chunks, d_block_chunks, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        prof_end();
+        ep.frame = f;
+        ep.live = true;
+        epochs[e_new] = std::move(ep);
+        frame_epoch[f] = e_new;
+        if ((size_t)epochs[e_new].nchunks > slab_chunks) {
+            hipFree(slab);
+            slab_chunks = (size_t)epochs[e_new].nchunks + epochs[e_new].nchunks / 8 + 16;
+            HIP_TRY(hipMalloc((void**)&slab, slab_chunks * 4 * TILE_WORDS * sizeof(R)));
+        }
+        return check_launch();
+    }
+    // make epoch e the one the kernels see; the grid blocks the previous epoch may have dirtied are zeroed
+    int bind_epoch(int e) {
+        if (e != grid_epoch && grid_epoch > 0 && epochs[grid_epoch].live && epochs[grid_epoch].nactive > 0) {
+            DevSim<R> Do = D;
+            Do.active = epochs[grid_epoch].active;
+            Do.nactive = epochs[grid_epoch].nactive;
+            hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 20);
+        }
+        grid_epoch = e;
+        const Epoch& ep = epochs[e];
+        D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
+        D.orig_id = ep.orig; D.block_chunk_start = ep.block_chunk_start; D.block_chunks = ep.block_chunks;
+        D.slab = slab;
+        return check_launch();
+    }
+    int ensure_inverse(int e) {
+        Epoch& ep = epochs[e];
+        if (!ep.inv) {
+            HIP_TRY(hipMalloc((void**)&ep.inv, D.Npad * sizeof(int)));
+            hipLaunchKernelGGL(k_invert, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)ep.orig, ep.inv);
+        }
+        return check_launch();
+    }
+    // adjoint frame f re-ordered from its own epoch into epoch `to` -> tmp_frame (returns pointer to use)
+    int adjoint_in_order(int f, int to, const R** out) {
+        const R* Af = D.A + (size_t)f * frame_scalars();
+        const int from = adj_epoch[f];
+        if (from < 0 || from == to) { *out = Af; return SMAC_OK; }   // all-zero frames have no order
+        int rc;
+        const int* map;
+        if (from == 0) map = epochs[to].orig;                          // identity -> sorted: src index = original id
+        else {
+            if ((rc = ensure_inverse(from))) return rc;
+            if (to == 0) map = epochs[from].inv;
+            else {
+                hipLaunchKernelGGL(k_compose, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)epochs[to].orig,
+                                   (const int*)epochs[from].inv, d_map);
+                map = d_map;
+            }
+        }
+        prof_begin(K_REORDER);
+        hipLaunchKernelGGL(k_gather_rows<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, map, Af, tmp_frame, D.Npad, (int)NCOMP);
+        prof_end();
+        *out = tmp_frame;
+        return check_launch();
+    }
+    int check_drift() {
+        int h = 0;
+        HIP_TRY(hipMemcpyAsync(&h, d_drift, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h) {
+            HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
+            err = "a particle moved more than one grid block between two re-sorts: lower sort_interval (or dt)";
+            return SMAC_ERR_INVALID;
+        }
         return SMAC_OK;
     }
 
@@ -400,53 +641,67 @@ template <class R> struct Sim final : ISim {
         }
         return SMAC_OK;
     }
-    int forward_grid(int f, bool store_F, bool is_recompute) {
-        int rc;
-        prof_begin(K_CLEAR);
-        // clear_grid :93-114 (values; adjoints are cleared in substep_grad where they are used)
-        hipMemsetAsync(grid_block, 0, 10 * D.G * sizeof(R), stream);
-        prof_end();
-        prof_begin(K_P2G);
-        if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
-        else hipLaunchKernelGGL((k_p2g<R, false>), dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
-        prof_end();
-        if (!is_recompute && cfg.rigid_velocity_control) {                                 // rigid_velocity_control, :329-331
-            for (int i = 0; i < D.P; ++i)
-                if ((rc = prim_fk(i, f))) return rc;
-        }
-        prof_begin(K_GRID_OP);
-        hipLaunchKernelGGL(k_grid_op<R>, dim3(nblk(D.G)), dim3(BLOCK), 0, stream, D);
-        prof_end();
-        if (D.collision_type == CONTACT_MIXED && any_contact()) {
-            prof_begin(K_CONTACT);
-            DevSim<R> Dc = D;
-            if (is_recompute) Dc.ext_f = scratch_ext();
-            hipLaunchKernelGGL(k_contact<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, Dc, f);
-            prof_end();
-        }
-        return check_launch();
-    }
     // the recompute pass of substep_grad must not double-count ext_f: send its wrench sums to a scratch slot
     R* scratch = nullptr;
     R* scratch_ext() {
         if (!scratch) hipMalloc((void**)&scratch, SMAC_MAX_PRIMS * 6 * sizeof(R));
         return scratch;
     }
+    int ngrid_blocks() const { return (D.nactive + 3) / 4; }
+    // clear_grid :93-114 on the active blocks; p2g; (forward kinematics); slab reduce + grid_op; contact
+    int forward_grid(int f, bool store_F, bool is_recompute) {
+        int rc;
+        if (D.nchunks == 0 || D.nactive == 0) return SMAC_OK;
+        prof_begin(K_CLEAR);
+        hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 20 : 10);
+        prof_end();
+        prof_begin(K_P2G);
+        if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+        else hipLaunchKernelGGL((k_p2g<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+        prof_end();
+        if (!is_recompute && cfg.rigid_velocity_control) {                    // :329-331
+            for (int i = 0; i < D.P; ++i)
+                if ((rc = prim_fk(i, f))) return rc;
+        }
+        prof_begin(K_GRID_OP);
+        hipLaunchKernelGGL(k_grid_op<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+        prof_end();
+        if (D.collision_type == CONTACT_MIXED && any_contact()) {
+            prof_begin(K_CONTACT);
+            DevSim<R> Dc = D;
+            if (is_recompute) Dc.ext_f = scratch_ext();
+            hipLaunchKernelGGL(k_contact<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, Dc, f);
+            prof_end();
+        }
+        return check_launch();
+    }
     int substep(int f, const double* action) override {
         int rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
+        REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
         if ((rc = check_contact_supported())) return rc;
         if (action && (rc = set_action(action))) return rc;
+        int e = frame_epoch[f];
+        if (e == 0 || f - epochs[e].frame >= sort_interval || f < epochs[e].frame) {
+            if (e > 0 && (rc = check_drift())) return rc;
+            if ((rc = sort_frame(f))) return rc;
+            e = frame_epoch[f];
+        }
+        if ((rc = bind_epoch(e))) return rc;
         if ((rc = forward_grid(f, true, false))) return rc;
-        prof_begin(K_G2P);
-        hipLaunchKernelGGL(k_g2p<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
-        prof_end();
+        if (D.nchunks > 0) {
+            prof_begin(K_G2P);
+            hipLaunchKernelGGL(k_g2p<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+            prof_end();
+        }
+        frame_epoch[f + 1] = e;
         return check_launch();
     }
     int substep_grad(int f, const double* action, const double* ext_f_grad, double* action_grad_out) override {
         int rc;
         if ((rc = need_grad())) return rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep_grad: frame f+1 exceeds max_frames");
+        REQUIRE(frame_epoch[f] > 0, "substep_grad: frame f was not produced/consumed by a forward substep");
         if ((rc = check_contact_supported())) return rc;
         if (action && (rc = set_action(action))) return rc;
         if (ext_f_grad && D.P > 0) {                                          // :342-344
@@ -455,27 +710,44 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMemcpyAsync(D.ext_f_grad, tmp, 6 * D.P * sizeof(R), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
-        prof_begin(K_CLEAR);
-        hipMemsetAsync(grid_block + 10 * D.G, 0, 10 * D.G * sizeof(R), stream);   // grid adjoints, :101-107
-        prof_end();
-        if ((rc = forward_grid(f, false, true))) return rc;                   // :352-359
-        prof_begin(K_G2P_GRAD);
-        hipLaunchKernelGGL(k_g2p_grad<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);   // :361
-        prof_end();
-        if (D.collision_type == CONTACT_MIXED && any_contact()) {             // :362-363, 389-393
-            prof_begin(K_CONTACT_GRAD);
-            hipLaunchKernelGGL(k_contact_grad<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);
+        const int e = frame_epoch[f];
+        if ((rc = bind_epoch(e))) return rc;
+        // adjoint of frame f+1 in this epoch's particle order; adjoint of frame f must be in it too
+        const R* An = nullptr;
+        if ((rc = adjoint_in_order(f + 1, e, &An))) return rc;
+        if (adj_epoch[f] >= 0 && adj_epoch[f] != e) {                         // seeds stored in another order: convert in place
+            const R* tmp = nullptr;
+            REQUIRE(An != tmp_frame, "adjoint frames f and f+1 both need re-ordering (unsupported seed placement)");
+            if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
+            HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        }
+        adj_epoch[f] = e;
+        D.An = An;
+        if ((rc = forward_grid(f, false, true))) return rc;                   // :347-359 (clears values + adjoints, recomputes)
+        if (D.nchunks > 0) {
+            prof_begin(K_G2P_GRAD);
+            hipLaunchKernelGGL(k_g2p_grad<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :361
+            prof_end();
+            prof_begin(K_REDUCE);
+            hipLaunchKernelGGL(k_reduce_agvout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+            prof_end();
+            if (D.collision_type == CONTACT_MIXED && any_contact()) {             // :362-363, 389-393
+                prof_begin(K_CONTACT_GRAD);
+                hipLaunchKernelGGL(k_contact_grad<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                prof_end();
+            }
+            prof_begin(K_GRID_OP_GRAD);
+            hipLaunchKernelGGL(k_grid_op_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);   // :394 / :365
             prof_end();
         }
-        prof_begin(K_GRID_OP_GRAD);
-        hipLaunchKernelGGL(k_grid_op_grad<R>, dim3(nblk(D.G)), dim3(BLOCK), 0, stream, D);   // :394 / :365
-        prof_end();
-        if (cfg.rigid_velocity_control)                                                    // :367-369
+        if (cfg.rigid_velocity_control)                                       // :367-369
             for (int i = D.P - 1; i >= 0; --i)
                 if ((rc = prim_fk_grad(i, f))) return rc;
-        prof_begin(K_P2G_GRAD);
-        hipLaunchKernelGGL(k_p2g_grad<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f);   // :371-374
-        prof_end();
+        if (D.nchunks > 0) {
+            prof_begin(K_P2G_GRAD);
+            hipLaunchKernelGGL(k_p2g_grad<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :371-374
+            prof_end();
+        }
         if ((rc = check_launch())) return rc;
         if (action_grad_out && D.n_control > 0) {                             // :378
             R tmp[3 * 64];

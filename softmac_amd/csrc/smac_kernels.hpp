@@ -30,6 +30,9 @@ namespace smac {
 constexpr int BLOCK = 256;
 enum { CX = 0, CV = 3, CC = 6, CF = 15, NCOMP = 24 };
 
+template <class R> struct alignas(4 * sizeof(R)) Vec4 { R x, y, z, w; };
+struct Hit;
+
 template <class R> struct DevSim {
     int N, Npad, n, P, n_control, substeps, collision_type, sticky, max_frames;
     R dt, inv_dx, dx, p_mass, stress_scale;
@@ -37,8 +40,9 @@ template <class R> struct DevSim {
     Material<R> mat;
     R* S;
     R* A;
-    R *gm, *gvin, *gvmix, *gvout;       // grid values  (vectors: [3][G])
-    R *agm, *agvin, *agvmix, *agvout;   // grid adjoints
+    // grid: one 4-scalar record per cell and field, so a stencil node is ONE 16-byte access
+    Vec4<R> *vin, *vmix, *vout;         // {m, p_x, p_y, p_z} / {v_mixed, 0} / {v_out, 0}
+    Vec4<R> *ain, *amix, *aout;         // adjoints: {grid_m.grad, grid_v_in.grad} / {grid_v_mixed.grad, 0} / {grid_v_out.grad, 0}
     PrimTable<R> prim[MAX_PRIMS];
     R* prim_state;
     R* prim_grad;
@@ -56,7 +60,9 @@ template <class R> struct DevSim {
     int nactive;
     const int* orig_id;          // sorted slot -> original particle id
     const R* An;                 // adjoint of frame f+1 in THIS epoch's particle order (A[f+1] or a re-ordered copy)
-    R* slab;                     // [nchunks][4][TILE_WORDS] per-chunk tiles (P2G: m,vin ; G2P adjoint: agvout)
+    Vec4<R>* slab;               // [nchunks][TILE_WORDS] per-chunk tiles (P2G: {m,p} ; G2P adjoint: {grid_v_out.grad,0})
+    const struct Hit* hits;      // particles inside a contact band this frame (k_contact_mask)
+    int* nhits;
     const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
     const int* block_chunks;
     int* drift_flag;
@@ -78,6 +84,16 @@ template <class R> __device__ __forceinline__ void lds_add(tile_t* p, R v) {
 }
 
 template <class R> __device__ __forceinline__ void atomic_add(R* p, R v) { unsafeAtomicAdd(p, v); }
+
+// Grid accesses use a wave-uniform base pointer + a 32-bit per-lane BYTE offset, which maps to the
+// saddr form of global_load/global_atomic (one VGPR per address instead of a 64-bit pair): with 27
+// stencil nodes x several fields per particle the 64-bit form alone overflowed the register budget.
+template <class R> __device__ __forceinline__ Vec4<R> gld(const Vec4<R>* base, unsigned cell) {
+    return *(const Vec4<R>*)((const char*)base + cell * (unsigned)sizeof(Vec4<R>));
+}
+template <class R> __device__ __forceinline__ void gatomic(Vec4<R>* base, unsigned cell, int comp, R v) {
+    unsafeAtomicAdd((R*)((char*)base + cell * (unsigned)sizeof(Vec4<R>)) + comp, v);
+}
 
 template <class R> __device__ __forceinline__ R wave_sum(R v) {
 #pragma unroll
@@ -105,7 +121,7 @@ struct Nodes {
     int cx[3], cy[3], cz[3];
     int tx[3], ty[3], tz[3];
     int okx, oky, okz;
-    __device__ __forceinline__ int cell(int i, int j, int k) const { return cx[i] + cy[j] + cz[k]; }
+    __device__ __forceinline__ unsigned cell(int i, int j, int k) const { return (unsigned)(cx[i] + cy[j] + cz[k]); }
     __device__ __forceinline__ bool in_tile(int i, int j, int k) const { return ((okx >> i) & (oky >> j) & (okz >> k) & 1) != 0; }
     __device__ __forceinline__ int tile(int i, int j, int k) const { return tx[i] + ty[j] + tz[k]; }
 };
@@ -146,22 +162,28 @@ template <class R> __device__ __forceinline__ void f_tmp(const R* C, const R* E,
 // ------------------------------------------------------------------------------------------
 // chunk prologue shared by the particle kernels
 // ------------------------------------------------------------------------------------------
-#define SMAC_CHUNK_PROLOGUE                                   \
-    const Chunk ch = D.chunks[blockIdx.x];                    \
+#define SMAC_CHUNK_PROLOGUE_AT(ci)                            \
+    const Chunk ch = D.chunks[ci];                            \
     const int t = threadIdx.x;                                \
     const bool valid = t < ch.count;                          \
     const int p = ch.start + (valid ? t : 0);
+#define SMAC_CHUNK_PROLOGUE SMAC_CHUNK_PROLOGUE_AT(blockIdx.x)
 
-// store this chunk's LDS tile (NS scalars) to its slab, coalesced
+// store this chunk's f64 LDS tile (NS scalars, tile[s][word]) to its slab as 16-byte records, coalesced
 template <class R, int NS> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const tile_t* tile) {
-    R* dst = D.slab + (size_t)blockIdx.x * 4 * TILE_WORDS;
-    for (int i = threadIdx.x; i < NS * TILE_WORDS; i += BLOCK) dst[i] = (R)tile[i];
+    Vec4<R>* dst = D.slab + (size_t)blockIdx.x * TILE_WORDS;
+    for (int i = threadIdx.x; i < TILE_WORDS; i += BLOCK) {
+        Vec4<R> v;
+        v.x = (R)tile[i]; v.y = (R)tile[TILE_WORDS + i]; v.z = (R)tile[2 * TILE_WORDS + i];
+        v.w = NS > 3 ? (R)tile[3 * TILE_WORDS + i] : R(0);
+        dst[i] = v;
+    }
 }
 
-// Sum, for one cell of block `b`, scalar `c` of every slab that overlaps it (own block and the
-// blocks at -1 along each dimension in which the cell's local coordinate is <= 1).
-template <class R, int NS>
-__device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, R* acc) {
+// Sum, for one cell of block `b`, every slab record that overlaps it (own block and the blocks at -1
+// along each dimension in which the cell's local coordinate is <= 1).
+template <class R>
+__device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, Vec4<R>& acc) {
     const int nb = D.nb;
     const int bz = b % nb, by = (b / nb) % nb, bx = b / (nb * nb);
     const int lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
@@ -173,20 +195,37 @@ __device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, R*
                 const int nch = D.block_chunks[src];
                 if (nch == 0) continue;
                 const int w = tile_index(lx + 4 * dx, ly + 4 * dy, lz + 4 * dz);
-                const R* sl = D.slab + (size_t)D.block_chunk_start[src] * 4 * TILE_WORDS + w;
-                for (int c = 0; c < nch; ++c, sl += 4 * TILE_WORDS)
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[s] += sl[s * TILE_WORDS];
+                const Vec4<R>* sl = D.slab + (size_t)D.block_chunk_start[src] * TILE_WORDS + w;
+                for (int c = 0; c < nch; ++c, sl += TILE_WORDS) {
+                    const Vec4<R> v = *sl;
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
             }
 }
 
-// zero `nfields` consecutive grid fields (starting at field0 of the 20-field block) on the active blocks
+// Stage the 6x6x6 node records of `field` around this chunk's block into LDS (gather tile).
+// Nodes outside the grid read as zero (they are never addressed: bases are clamped).
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_clear_active(DevSim<R> D, R* base, int nfields) {
+__device__ __forceinline__ void gather_tile_load(const DevSim<R>& D, const Vec4<R>* field, int block, Vec4<R>* gt) {
+    const int nb = D.nb;
+    const int bz = block % nb, by = (block / nb) % nb, bx = block / (nb * nb);
+    for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
+        const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
+        const int i = 4 * bx + li, j = 4 * by + lj, k = 4 * bz + lk;
+        Vec4<R> v = {R(0), R(0), R(0), R(0)};
+        if (i < D.n && j < D.n && k < D.n) v = field[cell_of(nb, i, j, k)];
+        gt[idx] = v;
+    }
+}
+
+// zero `nfields` consecutive 4-scalar grid fields on the active blocks
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_clear_active(DevSim<R> D, Vec4<R>* base, int nfields) {
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= D.nactive) return;
     const size_t cell = (size_t)D.active[a] * 64 + (threadIdx.x & 63);
-    for (int f = 0; f < nfields; ++f) base[(size_t)f * D.G + cell] = R(0);
+    const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+    for (int f = 0; f < nfields; ++f) base[(size_t)f * D.G + cell] = z;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -215,41 +254,54 @@ __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
-        R imp[3] = {R(0), R(0), R(0)};
+        R pv[3] = {D.p_mass * v[0], D.p_mass * v[1], D.p_mass * v[2]};
         if (D.n_control > 0) {                                                            // :209-213
             int ci = D.control_idx[D.orig_id[p]];
             if (ci >= 0)
-                for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
+                for (int d = 0; d < 3; ++d) pv[d] += R(6e-4) * D.action[3 * ci + d] * D.dt;
         }
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, ch.block);
-        const size_t G = D.G;
+        if ((nd.okx & nd.oky & nd.okz) == 7) {             // whole stencil inside the tile: straight-line LDS atomics
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                    const R d0 = (R(i) - st.fx[0]) * D.dx, d1 = (R(j) - st.fx[1]) * D.dx, d2 = (R(k) - st.fx[2]) * D.dx;
-                    R mom[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        mom[c] = w * (D.p_mass * v[c] + aff[3 * c] * d0 + aff[3 * c + 1] * d1 + aff[3 * c + 2] * d2 + imp[c]);   // :261
-                    if (nd.in_tile(i, j, k)) {
+                    for (int k = 0; k < 3; ++k) {
+                        const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
+                        const R d0 = (R(i) - st.fx[0]) * D.dx, d1 = (R(j) - st.fx[1]) * D.dx, d2 = (R(k) - st.fx[2]) * D.dx;
                         tile_t* tp = tile + nd.tile(i, j, k);
                         lds_add(tp, w * D.p_mass);                                         // :262
-                        lds_add(tp + TILE_WORDS, mom[0]);
-                        lds_add(tp + 2 * TILE_WORDS, mom[1]);
-                        lds_add(tp + 3 * TILE_WORDS, mom[2]);
-                    } else {                                                               // drifted out of the block
-                        const size_t cell = nd.cell(i, j, k);
-                        atomic_add(D.gm + cell, w * D.p_mass);
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) atomic_add(D.gvin + c * G + cell, mom[c]);
+                        for (int c = 0; c < 3; ++c)
+                            lds_add(tp + (1 + c) * TILE_WORDS, w * (pv[c] + aff[3 * c] * d0 + aff[3 * c + 1] * d1 + aff[3 * c + 2] * d2));   // :261
                     }
+        } else {                                            // drifted out of the block since the last sort
+#pragma unroll 1
+            for (int n = 0; n < 27; ++n) {
+                const int i = n / 9, j = (n / 3) % 3, k = n % 3;
+                const R w = (i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0])) *
+                            (j == 0 ? st.w[0][1] : (j == 1 ? st.w[1][1] : st.w[2][1])) *
+                            (k == 0 ? st.w[0][2] : (k == 1 ? st.w[1][2] : st.w[2][2]));
+                const int cxi = i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2]);
+                const int cyj = j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2]);
+                const int czk = k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2]);
+                const int tw = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
+                               (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
+                const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
+                const R d0 = (R(i) - st.fx[0]) * D.dx, d1 = (R(j) - st.fx[1]) * D.dx, d2 = (R(k) - st.fx[2]) * D.dx;
+                const unsigned cell = (unsigned)(cxi + cyj + czk);
+                if (in) lds_add(tile + tw, w * D.p_mass);
+                else gatomic(D.vin, cell, 0, w * D.p_mass);
+                for (int c = 0; c < 3; ++c) {
+                    const R val = w * (pv[c] + aff[3 * c] * d0 + aff[3 * c + 1] * d1 + aff[3 * c + 2] * d2);
+                    if (in) lds_add(tile + tw + (1 + c) * TILE_WORDS, val);
+                    else gatomic(D.vin, cell, 1 + c, val);
                 }
+            }
+        }
     }
     __syncthreads();
     tile_store<R, 4>(D, tile);
@@ -288,23 +340,17 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    R acc[4] = {D.gm[cell], D.gvin[cell], D.gvin[D.G + cell], D.gvin[2 * D.G + cell]};   // drift fallback part
-    slab_reduce<R, 4>(D, b, l, acc);
-    const R m = acc[0];
-    D.gm[cell] = m;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) D.gvin[d * D.G + cell] = acc[1 + d];
+    Vec4<R> acc = D.vin[cell];                                                          // drift fallback part
+    slab_reduce(D, b, l, acc);
+    D.vin[cell] = acc;
+    const R m = acc.x;
     if (!(m > R(1e-10))) return;                                                       // :286 / :399
     const R inv = R(1) / m;
-    R v[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) v[d] = inv * acc[1 + d] + D.dt * D.g[d];               // :287-288
+    R v[3] = {inv * acc.y + D.dt * D.g[0], inv * acc.z + D.dt * D.g[1], inv * acc.w + D.dt * D.g[2]};   // :287-288
     boundary(D, i, j, k, v);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (D.collision_type == CONTACT_MIXED) D.gvmix[d * D.G + cell] = v[d];          // :403
-        D.gvout[d * D.G + cell] = v[d];                                                 // :404 / :297
-    }
+    const Vec4<R> o = {v[0], v[1], v[2], R(0)};
+    if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = o;                            // :403
+    D.vout[cell] = o;                                                                   // :404 / :297
 }
 
 // band test shared by k_contact and k_contact_grad: which primitives see this particle
@@ -320,7 +366,7 @@ template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& 
     return mask;
 }
 
-template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D, const R* field, const Stencil<R>& st,
+template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D, const Vec4<R>* field, const Stencil<R>& st,
                                                               const Nodes& nd, R* out) {
     out[0] = out[1] = out[2] = R(0);
 #pragma unroll
@@ -330,72 +376,93 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                const size_t cell = nd.cell(i, j, k);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) out[c] += w * field[c * D.G + cell];
+                const Vec4<R> g = gld(field, nd.cell(i, j, k));
+                out[0] += w * g.x; out[1] += w * g.y; out[2] += w * g.z;
             }
 }
 
+// Contact is sparse: only particles inside a primitive's 5e-3 band do anything in grid_op_mixed2-4
+// (for the others v_tgt == v_tmp and the mixed4 correction is exactly zero).  A light kernel evaluates
+// the band test for every particle and appends the hits to a compact list {particle, mask, block}; the
+// heavy forward / adjoint contact kernels then walk that list with a small fixed grid.
+struct Hit { int p, mask, block, pad; };
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f, Hit* hits, int* nhits) {
+    SMAC_CHUNK_PROLOGUE
+    if (!valid) return;
+    R x[3];
+    load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+    const int mask = contact_mask(D, f, x);
+    if (mask) {
+        Hit h = {p, mask, ch.block, 0};
+        hits[atomicAdd(nhits, 1)] = h;
+    }
+}
+
+// grid_op_mixed2 + mixed3 + mixed4 for the listed particles.  The primitive loop is rolled (one copy of
+// collide_mixed in the instruction stream: these kernels run a handful of waves and would otherwise be
+// bound by instruction fetch) and each primitive's wrench is wave-reduced before ONE atomic per wave.
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
-    SMAC_CHUNK_PROLOGUE
-    R x[3] = {R(0.5), R(0.5), R(0.5)};
-    if (valid) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
-    const int mask = valid ? contact_mask(D, f, x) : 0;
-    R ext[MAX_PRIMS][6];
-#pragma unroll
-    for (int i = 0; i < MAX_PRIMS; ++i)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) ext[i][c] = R(0);
-    if (mask) {
+    const int nh = *D.nhits;
+    for (int base = blockIdx.x * BLOCK; base < nh; base += gridDim.x * BLOCK) {
+        const int hi = base + threadIdx.x;
+        Hit h = {0, 0, 0, 0};
+        if (hi < nh) h = D.hits[hi];
+        const int mask = h.mask, p = h.p;
+        R x[3] = {R(0.5), R(0.5), R(0.5)};
+        R v_tmp[3] = {R(0), R(0), R(0)}, v_tgt[3] = {R(0), R(0), R(0)};
         Stencil<R> st;
         Nodes nd;
-        stencil_at(D, x, st, nd, ch.block);
-        R v_tmp[3], v_tgt[3];
-        gather_vec(D, D.gvmix, st, nd, v_tmp);                                          // mixed2
-        v_tgt[0] = v_tmp[0]; v_tgt[1] = v_tmp[1]; v_tgt[2] = v_tmp[2];
-        const R life = R(1) / R(D.substeps - f % D.substeps);                           // :425
-#pragma unroll
-        for (int i = 0; i < MAX_PRIMS; ++i)                                             // mixed3
-            if (mask & (1 << i)) {
+        if (mask) {
+            load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+            stencil_at(D, x, st, nd, h.block);
+            gather_vec(D, D.vmix, st, nd, v_tmp);                                           // mixed2
+            v_tgt[0] = v_tmp[0]; v_tgt[1] = v_tmp[1]; v_tgt[2] = v_tmp[2];
+        }
+        const R life = R(1) / R(D.substeps - f % D.substeps);                               // :425
+#pragma unroll 1
+        for (int i = 0; i < D.P; ++i) {                                                     // mixed3
+            const bool act = (mask >> i) & 1;
+            if (!__ballot(act)) continue;
+            R ext[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+            if (act) {
                 const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                 R s13[13];
                 for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, ext[i]);
+                collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, ext);
             }
-        const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
-#pragma unroll
-        for (int i = 0; i < 3; ++i)                                                     // mixed4
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const size_t cell = nd.cell(i, j, k);
-                    if (D.gm[cell] > R(1e-10)) {
-                        const R w = R(2) * st.w[i][0] * st.w[j][1] * st.w[k][2];        // alpha = 2, :437
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) atomic_add(D.gvout + c * D.G + cell, -w * diff[c]);
-                    }
-                }
-    }
-    // ext_f: one atomic per wave per component instead of one per contacting particle
-    const unsigned long long any = __ballot(mask != 0);
-    if (any) {
-#pragma unroll
-        for (int i = 0; i < MAX_PRIMS; ++i) {
-            if (i >= D.P || !__ballot(mask & (1 << i))) continue;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                R s = wave_sum(ext[i][c]);
-                if ((threadIdx.x & 63) == 0) atomic_add(D.ext_f + i * 6 + c, s);
+                const R sum = wave_sum(ext[c]);
+                if ((threadIdx.x & 63) == 0) atomic_add(D.ext_f + i * 6 + c, sum);
             }
+        }
+        if (mask) {
+            const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)                                                     // mixed4
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const unsigned cell = nd.cell(i, j, k);
+                        if (gld(D.vin, cell).x > R(1e-10)) {
+                            const R w = R(2) * st.w[i][0] * st.w[j][1] * st.w[k][2];        // alpha = 2, :437
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) gatomic(D.vout, cell, c, -w * diff[c]);
+                        }
+                    }
         }
     }
 }
 
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_g2p(DevSim<R> D, int f) {
+    __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
+    gather_tile_load(D, D.vout, ch.block, gt);
+    __syncthreads();
     if (!valid) return;
     const R* Sf = frame(D.S, f, D.Npad);
     R* Sn = frame(D.S, f + 1, D.Npad);
@@ -404,7 +471,8 @@ __global__ __launch_bounds__(BLOCK) void k_g2p(DevSim<R> D, int f) {
     Stencil<R> st;
     Nodes nd;
     stencil_at(D, x, st, nd, ch.block);
-    if ((nd.okx & nd.oky & nd.okz) != 7) {          // stencil left the chunk's tile: how far has this particle drifted?
+    const bool all_in = (nd.okx & nd.oky & nd.okz) == 7;
+    if (!all_in) {          // stencil left the chunk's tile: how far has this particle drifted?
         const int nb = D.nb;
         const int pb[3] = {st.base[0] >> 2, st.base[1] >> 2, st.base[2] >> 2};
         const int cbk[3] = {ch.block / (nb * nb), (ch.block / nb) % nb, ch.block % nb};
@@ -420,13 +488,13 @@ __global__ __launch_bounds__(BLOCK) void k_g2p(DevSim<R> D, int f) {
             for (int k = 0; k < 3; ++k) {
                 const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
                 const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
-                const size_t cell = nd.cell(i, j, k);
+                const Vec4<R> g = all_in ? gt[nd.tile(i, j, k)] : gld(D.vout, nd.cell(i, j, k));
+                const R gv[3] = {w * g.x, w * g.y, w * g.z};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const R gv = w * D.gvout[c * D.G + cell];
-                    nv[c] += gv;
+                    nv[c] += gv[c];
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) nC[3 * c + d] += gv * dp[d];
+                    for (int d = 0; d < 3; ++d) nC[3 * c + d] += gv[c] * dp[d];
                 }
             }
     const R four_inv_dx = R(4) * D.inv_dx;
@@ -442,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) void k_g2p(DevSim<R> D, int f) {
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
-// adjoint of the three per-dimension weight factors -> adjoint of fx.  gw[i][j][k] folded on the fly:
+// adjoint of the three per-dimension weight factors -> adjoint of fx
 template <class R> struct WGrad {
     R g[3][3];   // g[k][d]: adjoint of st.w[k][d]
     __device__ __forceinline__ void zero() {
@@ -462,11 +530,13 @@ template <class R> struct WGrad {
     }
 };
 
-template <class R>
-__global__ __launch_bounds__(BLOCK) void k_g2p_grad(DevSim<R> D, int f) {
+template <class R, bool ACC_X>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? 3 : 2)) void k_g2p_grad(DevSim<R> D, int f) {
     __shared__ tile_t tile[3 * TILE_WORDS];
+    __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
+    gather_tile_load(D, D.vout, ch.block, gt);
     __syncthreads();
     if (valid) {
         const R* Sf = frame(D.S, f, D.Npad);
@@ -489,156 +559,213 @@ __global__ __launch_bounds__(BLOCK) void k_g2p_grad(DevSim<R> D, int f) {
         WGrad<R> wg;
         wg.zero();
         R gfx[3] = {R(0), R(0), R(0)};
+        if ((nd.okx & nd.oky & nd.okz) == 7) {
+            // whole stencil inside the tile: scatter d(out)/d grid_v_out = w (gnv + gC dp) with LDS atomics and
+            // gather grid_v_out from the LDS copy for the weight / dpos adjoints, one node at a time
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                    const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
-                    const size_t cell = nd.cell(i, j, k);
-                    const bool in = nd.in_tile(i, j, k);
-                    tile_t* tp = tile + nd.tile(i, j, k);
-                    R gw = R(0);
-                    R gdp[3] = {R(0), R(0), R(0)};
+                    for (int k = 0; k < 3; ++k) {
+                        const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
+                        const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
+                        const int tw = nd.tile(i, j, k);
+                        const Vec4<R> g = gt[tw];
+                        const R gvn[3] = {g.x, g.y, g.z};
+                        R gw = R(0);
+                        R gdp[3] = {R(0), R(0), R(0)};
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const R gvn = D.gvout[c * D.G + cell];
-                        // d(out)/d g_v[c] = w (gnv[c] + sum_d gC[c][d] dp[d])
-                        const R tt = gnv[c] + gC1[3 * c] * dp[0] + gC1[3 * c + 1] * dp[1] + gC1[3 * c + 2] * dp[2];
-                        if (in) lds_add(tp + c * TILE_WORDS, w * tt);
-                        else atomic_add(D.agvout + c * D.G + cell, w * tt);
-                        gw += gvn * tt;
+                        for (int c = 0; c < 3; ++c) {
+                            const R tt = gnv[c] + gC1[3 * c] * dp[0] + gC1[3 * c + 1] * dp[1] + gC1[3 * c + 2] * dp[2];
+                            lds_add(tile + tw + c * TILE_WORDS, w * tt);
+                            gw += gvn[c] * tt;
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) gdp[d] += gvn * gC1[3 * c + d];
+                            for (int d = 0; d < 3; ++d) gdp[d] += gvn[c] * gC1[3 * c + d];
+                        }
+                        wg.add(st, i, j, k, gw);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) gfx[d] -= w * gdp[d];                    // dpos = offset - fx
                     }
-                    wg.add(st, i, j, k, gw);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) gfx[d] -= w * gdp[d];                        // dpos = offset - fx
+        } else {
+#pragma unroll 1
+            for (int n = 0; n < 27; ++n) {                 // drifted particle: per-node test, global memory outside the tile
+                const int i = n / 9, j = (n / 3) % 3, k = n % 3;
+                const R wx = i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0]);
+                const R wy = j == 0 ? st.w[0][1] : (j == 1 ? st.w[1][1] : st.w[2][1]);
+                const R wz = k == 0 ? st.w[0][2] : (k == 1 ? st.w[1][2] : st.w[2][2]);
+                const int cxi = i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2]);
+                const int cyj = j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2]);
+                const int czk = k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2]);
+                const int tw = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
+                               (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
+                const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
+                const R w = wx * wy * wz;
+                const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
+                const unsigned cell = (unsigned)(cxi + cyj + czk);
+                const Vec4<R> g = gld(D.vout, cell);
+                const R gvn[3] = {g.x, g.y, g.z};
+                R gw = R(0);
+                R gdp[3] = {R(0), R(0), R(0)};
+                for (int c = 0; c < 3; ++c) {
+                    const R tt = gnv[c] + gC1[3 * c] * dp[0] + gC1[3 * c + 1] * dp[1] + gC1[3 * c + 2] * dp[2];
+                    if (in) lds_add(tile + tw + c * TILE_WORDS, w * tt);
+                    else gatomic(D.aout, cell, c, w * tt);
+                    gw += gvn[c] * tt;
+                    for (int d = 0; d < 3; ++d) gdp[d] += gvn[c] * gC1[3 * c + d];
                 }
+                // weight adjoints with runtime offsets (rare path)
+                for (int a = 0; a < 3; ++a) {
+                    wg.g[a][0] += (a == i) ? gw * wy * wz : R(0);
+                    wg.g[a][1] += (a == j) ? gw * wx * wz : R(0);
+                    wg.g[a][2] += (a == k) ? gw * wx * wy : R(0);
+                }
+                for (int d = 0; d < 3; ++d) gfx[d] -= w * gdp[d];
+            }
+        }
         wg.to_fx(st, gfx);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) Af[(size_t)(CX + d) * D.Npad + p] += gx1[d] + D.inv_dx * gfx[d];
+        for (int d = 0; d < 3; ++d) {
+            const R g = gx1[d] + D.inv_dx * gfx[d];
+            if (ACC_X) Af[(size_t)(CX + d) * D.Npad + p] += g;
+            else Af[(size_t)(CX + d) * D.Npad + p] = g;
+        }
     }
     __syncthreads();
     tile_store<R, 3>(D, tile);
 }
 
-// completes the G2P-adjoint scatter: agvout += sum of overlapping slabs
+// completes the G2P-adjoint scatter: grid_v_out.grad += sum of overlapping slabs
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_reduce_agvout(DevSim<R> D) {
+__global__ __launch_bounds__(BLOCK) void k_reduce_aout(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    R acc[3] = {D.agvout[cell], D.agvout[D.G + cell], D.agvout[2 * D.G + cell]};
-    slab_reduce<R, 3>(D, b, l, acc);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) D.agvout[d * D.G + cell] = acc[d];
+    Vec4<R> acc = D.aout[cell];
+    slab_reduce(D, b, l, acc);
+    D.aout[cell] = acc;
 }
 
+// Adjoint of grid_op_mixed4 / mixed3 / mixed2 for the listed particles.  One hit = one group of 32 lanes:
+// every lane of the group recomputes the (cheap) shared forward quantities, and the 19 forward-mode
+// directions of collide_mixed's adjoint (p_pos3, p_v3, state13) run in 19 different lanes instead of 19
+// times in one lane.  Lane n < 27 then owns stencil node n for the mixed2 scatter and the weight adjoints.
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
-    SMAC_CHUNK_PROLOGUE
-    R x[3] = {R(0.5), R(0.5), R(0.5)};
-    if (valid) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
-    const int mask = valid ? contact_mask(D, f, x) : 0;
-    R gst[MAX_PRIMS][13];
-#pragma unroll
-    for (int i = 0; i < MAX_PRIMS; ++i)
-#pragma unroll
-        for (int c = 0; c < 13; ++c) gst[i][c] = R(0);
-    if (mask) {
+    const int nh = *D.nhits;
+    const int grp = threadIdx.x >> 5, d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
+    for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
+        const int hi = base + grp;
+        Hit h = {0, 0, 0, 0};
+        if (hi < nh) h = D.hits[hi];
+        const int mask = h.mask, p = h.p;
+        R x[3] = {R(0.5), R(0.5), R(0.5)};
+        if (mask) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
         Stencil<R> st;
         Nodes nd;
-        stencil_at(D, x, st, nd, ch.block);
+        stencil_at(D, x, st, nd, h.block);
         const R life = R(1) / R(D.substeps - f % D.substeps);
-        // recompute the forward chain, keeping the velocity entering each primitive
-        R v_tmp[3], vin[MAX_PRIMS][3], vcur[3], dummy[6];
-        gather_vec(D, D.gvmix, st, nd, v_tmp);
-        vcur[0] = v_tmp[0]; vcur[1] = v_tmp[1]; vcur[2] = v_tmp[2];
+        // this lane's stencil node (lanes 27..31 idle in the node-parallel parts)
+        const int n = d < 27 ? d : 0;
+        const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+        const R wx = ni == 0 ? st.w[0][0] : (ni == 1 ? st.w[1][0] : st.w[2][0]);
+        const R wy = nj == 0 ? st.w[0][1] : (nj == 1 ? st.w[1][1] : st.w[2][1]);
+        const R wz = nk == 0 ? st.w[0][2] : (nk == 1 ? st.w[1][2] : st.w[2][2]);
+        const R wn = d < 27 ? wx * wy * wz : R(0);
+        const unsigned cell = (unsigned)((ni == 0 ? nd.cx[0] : (ni == 1 ? nd.cx[1] : nd.cx[2])) + (nj == 0 ? nd.cy[0] : (nj == 1 ? nd.cy[1] : nd.cy[2])) +
+                                         (nk == 0 ? nd.cz[0] : (nk == 1 ? nd.cz[1] : nd.cz[2])));
+        // node-parallel gathers, group-reduced (xor shuffles stay inside the 32-lane group)
+        Vec4<R> vm = {R(0), R(0), R(0), R(0)}, G = {R(0), R(0), R(0), R(0)};
+        R has = R(0);
+        if (mask && d < 27) {
+            vm = gld(D.vmix, cell);
+            G = gld(D.aout, cell);
+            has = gld(D.vin, cell).x > R(1e-10) ? R(1) : R(0);
+        }
+        R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2 forward
+        R gd[3] = {-R(2) * wn * has * G.x, -R(2) * wn * has * G.y, -R(2) * wn * has * G.z};   // mixed4.grad: d/d(v_tmp - v_tgt)
 #pragma unroll
-        for (int i = 0; i < MAX_PRIMS; ++i) {
-            vin[i][0] = vcur[0]; vin[i][1] = vcur[1]; vin[i][2] = vcur[2];
-            if (mask & (1 << i)) {
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { v_tmp[c] += __shfl_xor(v_tmp[c], o, 64); gd[c] += __shfl_xor(gd[c], o, 64); }
+        // forward chain (every lane), then its adjoint primitive by primitive in reverse
+        R v_tgt[3] = {v_tmp[0], v_tmp[1], v_tmp[2]};
+        R dummy[6];
+#pragma unroll 1
+        for (int i = 0; i < D.P; ++i)
+            if ((mask >> i) & 1) {
                 const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                 R s13[13];
                 for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                collide_mixed(D.prim[i], s13, x, vcur, D.p_mass, D.dt, life, dummy);
+                collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, dummy);
             }
-        }
-        const R diff[3] = {v_tmp[0] - vcur[0], v_tmp[1] - vcur[1], v_tmp[2] - vcur[2]};
-        // mixed4.grad: gd = d/d(v_tmp - v_tgt), weight adjoints
-        WGrad<R> wg;
-        wg.zero();
-        R gd[3] = {R(0), R(0), R(0)};
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const size_t cell = nd.cell(i, j, k);
-                    if (D.gm[cell] > R(1e-10)) {
-                        const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                        R dg = R(0);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const R G = D.agvout[c * D.G + cell];
-                            gd[c] -= R(2) * w * G;
-                            dg += diff[c] * G;
-                        }
-                        wg.add(st, i, j, k, -R(2) * dg);
-                    }
-                }
-        R gpos[3] = {R(0), R(0), R(0)};
+        const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
         R g[3] = {-gd[0], -gd[1], -gd[2]};             // adjoint of v_tgt
-        // mixed3.grad: reverse the primitive chain
-#pragma unroll
-        for (int i = MAX_PRIMS - 1; i >= 0; --i)
-            if (mask & (1 << i)) {
+        R gpos[3] = {R(0), R(0), R(0)};
+#pragma unroll 1
+        for (int i = D.P - 1; i >= 0; --i) {
+            const bool act = (mask >> i) & 1;
+            if (!__ballot(act)) continue;
+            R out = R(0);
+            if (act) {
                 const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-                R s13[13], ge[6], gin[3];
-                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                for (int c = 0; c < 6; ++c) ge[c] = D.ext_f_grad[i * 6 + c];
-                collide_mixed_adjoint(D.prim[i], s13, x, vin[i], D.p_mass, D.dt, life, g, ge, gpos, gin, gst[i]);
-                g[0] = gin[0]; g[1] = gin[1]; g[2] = gin[2];
-            }
-        // adjoint of v_tmp = direct (mixed4) + through the chain (mixed3)
-        const R gvt[3] = {gd[0] + g[0], gd[1] + g[1], gd[2] + g[2]};
-        // mixed2.grad
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                    const size_t cell = nd.cell(i, j, k);
-                    R gw = R(0);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        atomic_add(D.agvmix + c * D.G + cell, w * gvt[c]);
-                        gw += D.gvmix[c * D.G + cell] * gvt[c];
+                // velocity entering primitive i: replay the chain up to i
+                R vin[3] = {v_tmp[0], v_tmp[1], v_tmp[2]};
+                for (int q = 0; q < i; ++q)
+                    if ((mask >> q) & 1) {
+                        const R* pq = D.prim_state + ((size_t)q * D.max_frames + f) * 13;
+                        R sq[13];
+                        for (int c = 0; c < 13; ++c) sq[c] = pq[c];
+                        collide_mixed(D.prim[q], sq, x, vin, D.p_mass, D.dt, life, dummy);
                     }
-                    wg.add(st, i, j, k, gw);
+                if (d < 19) {
+                    Dual<R> pos[3], v[3], stt[13], ext[6];
+                    for (int c = 0; c < 3; ++c) pos[c] = Dual<R>(x[c], d == c ? R(1) : R(0));
+                    for (int c = 0; c < 3; ++c) v[c] = Dual<R>(vin[c], d == 3 + c ? R(1) : R(0));
+                    for (int c = 0; c < 13; ++c) stt[c] = Dual<R>(ps[c], d == 6 + c ? R(1) : R(0));
+                    collide_mixed(D.prim[i], stt, pos, v, D.p_mass, D.dt, life, ext);
+                    for (int c = 0; c < 3; ++c) out += g[c] * v[c].d;
+                    for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * ext[c].d;
                 }
-        R gfx[3] = {R(0), R(0), R(0)};
-        wg.to_fx(st, gfx);
-        R* Af = frame(D.A, f, D.Npad);
+            }
+            // direction d of this group's hit sits in lane lane0 + d
+            const R o0 = __shfl(out, lane0 + 0, 64), o1 = __shfl(out, lane0 + 1, 64), o2 = __shfl(out, lane0 + 2, 64);
+            const R o3 = __shfl(out, lane0 + 3, 64), o4 = __shfl(out, lane0 + 4, 64), o5 = __shfl(out, lane0 + 5, 64);
+            if (act) {
+                gpos[0] += o0; gpos[1] += o1; gpos[2] += o2;
+                g[0] = o3; g[1] = o4; g[2] = o5;
+            }
+            // state adjoint: lanes 6..18 hold component d-6; sum the two groups of the wave, one atomic per wave
+            R sg = (act && d >= 6 && d < 19) ? out : R(0);
+            sg += __shfl_xor(sg, 32, 64);
+            if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != R(0))
+                atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + (d - 6), sg);
+        }
+        if (mask) {
+            // adjoint of v_tmp = direct (mixed4) + through the chain (mixed3); mixed2.grad scatter by node
+            const R gvt[3] = {gd[0] + g[0], gd[1] + g[1], gd[2] + g[2]};
+            R gw = R(0);
+            if (d < 27) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) Af[(size_t)(CX + d) * D.Npad + p] += gpos[d] + D.inv_dx * gfx[d];
-    }
-    const unsigned long long any = __ballot(mask != 0);
-    if (any) {
+                for (int c = 0; c < 3; ++c) gatomic(D.amix, cell, c, wn * gvt[c]);
+                gw = vm.x * gvt[0] + vm.y * gvt[1] + vm.z * gvt[2]                           // mixed2: d/dw
+                     - R(2) * has * (diff[0] * G.x + diff[1] * G.y + diff[2] * G.z);        // mixed4: d/dw
+            }
+            // weight adjoint -> fx adjoint: this node contributes to one factor per dimension
+            R gfx[3];
+            gfx[0] = gw * wy * wz * (ni == 0 ? st.dw[0][0] : (ni == 1 ? st.dw[1][0] : st.dw[2][0]));
+            gfx[1] = gw * wx * wz * (nj == 0 ? st.dw[0][1] : (nj == 1 ? st.dw[1][1] : st.dw[2][1]));
+            gfx[2] = gw * wx * wy * (nk == 0 ? st.dw[0][2] : (nk == 1 ? st.dw[1][2] : st.dw[2][2]));
+            if (d >= 27) gfx[0] = gfx[1] = gfx[2] = R(0);
 #pragma unroll
-        for (int i = 0; i < MAX_PRIMS; ++i) {
-            if (i >= D.P || !__ballot(mask & (1 << i))) continue;
-            R* pg = D.prim_grad + ((size_t)i * D.max_frames + f) * 13;
+            for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-            for (int c = 0; c < 13; ++c) {
-                R s = wave_sum(gst[i][c]);
-                if ((threadIdx.x & 63) == 0) atomic_add(pg + c, s);
+                for (int c = 0; c < 3; ++c) gfx[c] += __shfl_xor(gfx[c], o, 64);
+            if (d < 3) {
+                R* Af = frame(D.A, f, D.Npad);
+                const R gp = d == 0 ? gpos[0] : (d == 1 ? gpos[1] : gpos[2]);
+                const R gf = d == 0 ? gfx[0] : (d == 1 ? gfx[1] : gfx[2]);
+                Af[(size_t)(CX + d) * D.Npad + p] += gp + D.inv_dx * gf;
             }
         }
     }
@@ -649,45 +776,70 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    const R m = D.gm[cell];
+    const Vec4<R> in = D.vin[cell];
+    const R m = in.x;
     if (!(m > R(1e-10))) return;
     const R inv = R(1) / m;
-    R v[3], vin[3], g[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        vin[d] = D.gvin[d * D.G + cell];
-        v[d] = inv * vin[d] + D.dt * D.g[d];
-        g[d] = D.agvout[d * D.G + cell];
-        if (D.collision_type == CONTACT_MIXED) g[d] += D.agvmix[d * D.G + cell];       // grid_v_out += grid_v_mixed
+    const R vin[3] = {in.y, in.z, in.w};
+    const Vec4<R> go = D.aout[cell];
+    R g[3] = {go.x, go.y, go.z};
+    if (D.collision_type == CONTACT_MIXED) {                                           // grid_v_out += grid_v_mixed
+        const Vec4<R> gm_ = D.amix[cell];
+        g[0] += gm_.x; g[1] += gm_.y; g[2] += gm_.z;
     }
+    R v[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) v[d] = inv * vin[d] + D.dt * D.g[d];
     const int mask = boundary(D, i, j, k, v);
     R gm = R(0);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (mask & (1 << d)) g[d] = R(0);
-        D.agvin[d * D.G + cell] = g[d] * inv;
         gm -= vin[d] * g[d];
     }
-    D.agm[cell] = gm * inv * inv;
+    const Vec4<R> o = {gm * inv * inv, g[0] * inv, g[1] * inv, g[2] * inv};
+    D.ain[cell] = o;
 }
 
-template <class R>
-__global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
+// Register budget: the unrolled 27-node gather, the SVD factors and the adjoint accumulators do not fit
+// 128 VGPRs together, and at 1 wave/SIMD the kernel is latency-bound.  The SVD factors (kept for the
+// constitutive adjoint) are parked in LDS across the gather loop, and the loop is fenced per x-plane so
+// that at most 9 nodes of loads are in flight: 4 waves/SIMD instead of 1.
+constexpr int STASH = 34;   // U9 V9 e3 ep3 Et9 Jm1
+template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? 3 : 2; };   // waves/SIMD asked of the register allocator
+template <class R, bool ACC_VCF>
+__global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
+    __shared__ R stash[STASH * BLOCK];
+    __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
+    gather_tile_load(D, D.ain, ch.block, gt);
+    __syncthreads();
     if (!valid) return;
     const R* Sf = frame(D.S, f, D.Npad);
     const R* An = D.An;
     R* Af = frame(D.A, f, D.Npad);
-    R x[3], v[3], C[9], E[9], Et[9], En[9], stress[9], aff[9];
+    R x[3], v[3], aff[9];
+    {
+        R C[9], E[9], Et[9], En[9], stress[9];
+        load_vec(Sf, CC, 9, D.Npad, p, C);
+        load_vec(Sf, CF, 9, D.Npad, p, E);
+        f_tmp(C, E, D.dt, Et);
+        ConstState<R> cs;
+        constitutive_fwd(D.mat, Et, En, stress, cs);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            stash[i * BLOCK + t] = cs.U[i];
+            stash[(9 + i) * BLOCK + t] = cs.V[i];
+            stash[(24 + i) * BLOCK + t] = Et[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { stash[(18 + i) * BLOCK + t] = cs.e[i]; stash[(21 + i) * BLOCK + t] = cs.ep[i]; }
+        stash[33 * BLOCK + t] = cs.Jm1;
+    }
     load_vec(Sf, CX, 3, D.Npad, p, x);
     load_vec(Sf, CV, 3, D.Npad, p, v);
-    load_vec(Sf, CC, 9, D.Npad, p, C);
-    load_vec(Sf, CF, 9, D.Npad, p, E);
-    f_tmp(C, E, D.dt, Et);
-    ConstState<R> cs;
-    constitutive_fwd(D.mat, Et, En, stress, cs);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];
     R imp[3] = {R(0), R(0), R(0)};
     int ci = -1;
     if (D.n_control > 0) {
@@ -695,6 +847,7 @@ __global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
         if (ci >= 0)
             for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
     }
+    R pv[3] = {D.p_mass * v[0] + imp[0], D.p_mass * v[1] + imp[1], D.p_mass * v[2] + imp[2]};
     Stencil<R> st;
     Nodes nd;
     stencil_at(D, x, st, nd, ch.block);
@@ -702,21 +855,31 @@ __global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
     wg.zero();
     R gvp[3] = {R(0), R(0), R(0)}, gfx[3] = {R(0), R(0), R(0)};
     R gaff[9] = {R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0)};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
+    const bool all_in = (nd.okx & nd.oky & nd.okz) == 7;
+    // x-planes are a REAL loop (not unrolled) to bound the live range of the node records; the plane's
+    // x-weight / offsets are selected with v_cndmask instead of register indexing.
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+        const R wi = i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0]);
+        const int cxi = i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2]);
+        const int txi = i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2]);
+        const R dp0 = (R(i) - st.fx[0]) * D.dx;
+        R gwx = R(0);          // adjoint of w[i][0] from this plane
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const R w = st.w[i][0] * st.w[j][1] * st.w[k][2];
-                const R dp[3] = {(R(i) - st.fx[0]) * D.dx, (R(j) - st.fx[1]) * D.dx, (R(k) - st.fx[2]) * D.dx};
-                const size_t cell = nd.cell(i, j, k);
-                R gw = D.agm[cell] * D.p_mass;
+                const R wjk = st.w[j][1] * st.w[k][2];
+                const R w = wi * wjk;
+                const R dp[3] = {dp0, (R(j) - st.fx[1]) * D.dx, (R(k) - st.fx[2]) * D.dx};
+                const Vec4<R> a = all_in ? gt[txi + nd.ty[j] + nd.tz[k]] : gld(D.ain, (unsigned)(cxi + nd.cy[j] + nd.cz[k]));
+                const R gvv[3] = {a.y, a.z, a.w};
+                R gw = a.x * D.p_mass;
                 R gdp[3] = {R(0), R(0), R(0)};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const R gv = D.agvin[c * D.G + cell];
-                    const R mom = D.p_mass * v[c] + aff[3 * c] * dp[0] + aff[3 * c + 1] * dp[1] + aff[3 * c + 2] * dp[2] + imp[c];
+                    const R gv = gvv[c];
+                    const R mom = pv[c] + aff[3 * c] * dp[0] + aff[3 * c + 1] * dp[1] + aff[3 * c + 2] * dp[2];
                     gw += gv * mom;
                     gvp[c] += w * gv;
 #pragma unroll
@@ -725,39 +888,67 @@ __global__ __launch_bounds__(BLOCK) void k_p2g_grad(DevSim<R> D, int f) {
                         gdp[d] += aff[3 * c + d] * gv;
                     }
                 }
-                wg.add(st, i, j, k, gw);
+                gwx += gw * wjk;
+                wg.g[j][1] += gw * wi * st.w[k][2];
+                wg.g[k][2] += gw * wi * st.w[j][1];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) gfx[d] -= w * gdp[d] * D.dx;                 // dpos = (offset - fx) dx
             }
+        wg.g[0][0] += i == 0 ? gwx : R(0);
+        wg.g[1][0] += i == 1 ? gwx : R(0);
+        wg.g[2][0] += i == 2 ? gwx : R(0);
+    }
     wg.to_fx(st, gfx);
     // impulse adjoint = sum_nodes w gv = gvp  -> action.grad
     if (ci >= 0)
         for (int d = 0; d < 3; ++d) atomic_add(D.action_grad + 3 * ci + d, R(6e-4) * D.dt * gvp[d]);
-    // constitutive adjoint
-    R G[9], gFn[9], gEt[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) G[i] = D.stress_scale * gaff[i];
-    load_vec(An, CF, 9, D.Npad, p, gFn);
-    constitutive_bwd(D.mat, Et, cs, G, gFn, gEt);
+    for (int d = 0; d < 3; ++d) {
+        Af[(size_t)(CX + d) * D.Npad + p] += D.inv_dx * gfx[d];
+        const R gvv = D.p_mass * gvp[d];
+        if (ACC_VCF) Af[(size_t)(CV + d) * D.Npad + p] += gvv;
+        else Af[(size_t)(CV + d) * D.Npad + p] = gvv;
+    }
+    // constitutive adjoint
+    R gEt[9], Et[9];
+    {
+        ConstState<R> cs;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            cs.U[i] = stash[i * BLOCK + t];
+            cs.V[i] = stash[(9 + i) * BLOCK + t];
+            Et[i] = stash[(24 + i) * BLOCK + t];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { cs.e[i] = stash[(18 + i) * BLOCK + t]; cs.ep[i] = stash[(21 + i) * BLOCK + t]; }
+        cs.Jm1 = stash[33 * BLOCK + t];
+        cs.has_svd = true;
+        R G[9], gFn[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) G[i] = D.stress_scale * gaff[i];
+        load_vec(An, CF, 9, D.Npad, p, gFn);
+        constitutive_bwd(D.mat, Et, cs, G, gFn, gEt);
+    }
     // compute_F_tmp.grad: F_tmp = (I + dt C)(I + E)
     R gC[9], gE[9], Ft[9], A1[9];
+    load_vec(Sf, CF, 9, D.Npad, p, Ft);
+    load_vec(Sf, CC, 9, D.Npad, p, A1);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { Ft[i] = E[i]; A1[i] = D.dt * C[i]; }
+    for (int i = 0; i < 9; ++i) A1[i] *= D.dt;
     Ft[0] += R(1); Ft[4] += R(1); Ft[8] += R(1);
     A1[0] += R(1); A1[4] += R(1); A1[8] += R(1);
     mmt(gEt, Ft, gC);          // gEt (I+E)^T
     mtm(A1, gEt, gE);          // (I + dt C)^T gEt
 #pragma unroll
-    for (int i = 0; i < 9; ++i) gC[i] = D.dt * gC[i] + D.p_mass * gaff[i];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        Af[(size_t)(CX + d) * D.Npad + p] += D.inv_dx * gfx[d];
-        Af[(size_t)(CV + d) * D.Npad + p] += D.p_mass * gvp[d];
-    }
-#pragma unroll
     for (int i = 0; i < 9; ++i) {
-        Af[(size_t)(CC + i) * D.Npad + p] += gC[i];
-        Af[(size_t)(CF + i) * D.Npad + p] += gE[i];
+        const R gc = D.dt * gC[i] + D.p_mass * gaff[i];
+        if (ACC_VCF) {
+            Af[(size_t)(CC + i) * D.Npad + p] += gc;
+            Af[(size_t)(CF + i) * D.Npad + p] += gE[i];
+        } else {
+            Af[(size_t)(CC + i) * D.Npad + p] = gc;
+            Af[(size_t)(CF + i) * D.Npad + p] = gE[i];
+        }
     }
 }
 

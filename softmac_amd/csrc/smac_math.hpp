@@ -369,19 +369,47 @@ template <class R> SMAC_HD void cofactor(const R* E, R* K) {
     K[6] = F[1] * F[5] - F[2] * F[4]; K[7] = F[2] * F[3] - F[0] * F[5]; K[8] = F[0] * F[4] - F[1] * F[3];
 }
 
+// Jacobi stops when the off-diagonal mass is at the rounding floor of the rotations themselves
+// (a few ulp of |H|); asking for less only burns sweeps.  The f32 rotations use the hardware
+// reciprocal / rsqrt (1 ulp): a rotation that is 1e-7 off is corrected by the next sweep.
 template <class R> struct eps_of;
-template <> struct eps_of<float> { static constexpr float v = 1.0e-7f; static constexpr int sweeps = 8; };
-template <> struct eps_of<double> { static constexpr double v = 1.0e-16; static constexpr int sweeps = 12; };
+template <> struct eps_of<float> { static constexpr float v = 4.0e-7f; static constexpr int sweeps = 6; };
+template <> struct eps_of<double> { static constexpr double v = 1.0e-15; static constexpr int sweeps = 10; };
+
+SMAC_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+SMAC_HD double fast_rcp(double x) { return 1.0 / x; }
+SMAC_HD float fast_rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / std::sqrt(x);
+#endif
+}
+SMAC_HD double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+SMAC_HD float fast_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return std::sqrt(x);
+#endif
+}
+SMAC_HD double fast_sqrt(double x) { return std::sqrt(x); }
 
 // One Jacobi rotation on the symmetric matrix {a00,a01,a02,a11,a12,a22} in the (p,q) plane,
 // accumulated into V (columns = eigenvectors).  Written out per pair to keep everything in registers.
 template <class R> SMAC_HD void jacobi_cs(R app, R aqq, R apq, R& c, R& s, R& t) {
     if (apq == R(0)) { c = R(1); s = R(0); t = R(0); return; }
-    R tau = (aqq - app) / (R(2) * apq);
+    R tau = (aqq - app) * fast_rcp(R(2) * apq);
     R at = tau < R(0) ? -tau : tau;
-    t = R(1) / (at + std::sqrt(R(1) + tau * tau));
+    t = at > R(1e18) ? R(0) : fast_rcp(at + fast_sqrt(R(1) + tau * tau));     // huge tau: rotation is the identity
     if (tau < R(0)) t = -t;
-    c = R(1) / std::sqrt(R(1) + t * t);
+    c = fast_rsqrt(R(1) + t * t);
     s = t * c;
 }
 
@@ -402,7 +430,7 @@ template <class R> SMAC_HD void svd_I_plus_E(const R* E, R* U, R* e, R* V) {
     for (int sweep = 0; sweep < eps_of<R>::sweeps; ++sweep) {
         R off = std::fabs(a01) + std::fabs(a02) + std::fabs(a12);
         R dia = std::fabs(a00) + std::fabs(a11) + std::fabs(a22);
-        if (off <= eps_of<R>::v * R(1e-2) * dia || off == R(0)) break;
+        if (off <= eps_of<R>::v * dia || off == R(0)) break;
         R c, s, t;
         // (0,1)
         jacobi_cs(a00, a11, a01, c, s, t);

@@ -81,7 +81,7 @@ template <class R> struct Sim final : ISim {
     smac_config cfg{};
     DevSim<R> D{};
     hipStream_t stream = nullptr;
-    R* grid_block = nullptr;      // 20 * G scalars: values (10G) then adjoints (10G)
+    Vec4<R>* grid_block = nullptr;   // 6 fields of G 4-scalar records: vin, vmix, vout, then their adjoints
     R* prim_tables[SMAC_MAX_PRIMS][2] = {};
     R* action_buf = nullptr;      // per-primitive velocity-control action buffer [P][max_frames][6] + its grad
     R* action_buf_grad = nullptr;
@@ -123,8 +123,10 @@ template <class R> struct Sim final : ISim {
     void* d_cub = nullptr;
     size_t cub_bytes = 0;
     R* tmp_frame = nullptr;         // NCOMP*Npad scratch (sort moves, re-ordered adjoints)
-    R* slab = nullptr;
+    Vec4<R>* slab = nullptr;
     size_t slab_chunks = 0;
+    Hit* d_hits = nullptr;           // capacity Npad
+    int* d_nhits = nullptr;
     int* d_drift = nullptr;
     R* dense_tmp = nullptr;
 
@@ -137,6 +139,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
+        hipFree(d_hits); hipFree(d_nhits);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
         for (auto e : pool) hipEventDestroy(e);
         for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -182,12 +185,15 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMalloc((void**)&D.A, fs * c.max_frames));
             HIP_TRY(hipMemsetAsync(D.A, 0, fs * c.max_frames, stream));
         }
-        HIP_TRY(hipMalloc((void**)&grid_block, 20 * D.G * sizeof(R)));
-        HIP_TRY(hipMemsetAsync(grid_block, 0, 20 * D.G * sizeof(R), stream));
-        R* g = grid_block;
-        D.gm = g; D.gvin = g + D.G; D.gvmix = g + 4 * D.G; D.gvout = g + 7 * D.G;
-        g += 10 * D.G;
-        D.agm = g; D.agvin = g + D.G; D.agvmix = g + 4 * D.G; D.agvout = g + 7 * D.G;
+        HIP_TRY(hipMalloc((void**)&grid_block, 6 * D.G * sizeof(Vec4<R>)));
+        HIP_TRY(hipMemsetAsync(grid_block, 0, 6 * D.G * sizeof(Vec4<R>), stream));
+        D.vin = grid_block; D.vmix = grid_block + D.G; D.vout = grid_block + 2 * D.G;
+        D.ain = grid_block + 3 * D.G; D.amix = grid_block + 4 * D.G; D.aout = grid_block + 5 * D.G;
+        HIP_TRY(hipMalloc((void**)&d_nhits, sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_nhits, 0, sizeof(int), stream));
+        HIP_TRY(hipMalloc((void**)&d_hits, (size_t)D.Npad * sizeof(Hit)));
+        D.nhits = d_nhits;
+        D.hits = d_hits;
         const int Pn = c.n_primitives > 0 ? c.n_primitives : 1;
         const size_t ps = (size_t)Pn * c.max_frames * 13 * sizeof(R);
         HIP_TRY(hipMalloc((void**)&D.prim_state, ps));
@@ -424,7 +430,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(action_buf_grad, 0, (size_t)Pn * cfg.max_frames * 6 * sizeof(R), stream));
         HIP_TRY(hipMemsetAsync(D.ext_f_grad, 0, Pn * 6 * sizeof(R), stream));
         HIP_TRY(hipMemsetAsync(D.action_grad, 0, (D.n_control > 0 ? D.n_control : 1) * 3 * sizeof(R), stream));
-        HIP_TRY(hipMemsetAsync(grid_block + 10 * D.G, 0, 10 * D.G * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(grid_block + 3 * D.G, 0, 3 * D.G * sizeof(Vec4<R>), stream));
         return SMAC_OK;
     }
     int set_control_idx(const int32_t* idx) override {
@@ -554,7 +560,7 @@ template <class R> struct Sim final : ISim {
         if ((size_t)epochs[e_new].nchunks > slab_chunks) {
             hipFree(slab);
             slab_chunks = (size_t)epochs[e_new].nchunks + epochs[e_new].nchunks / 8 + 16;
-            HIP_TRY(hipMalloc((void**)&slab, slab_chunks * 4 * TILE_WORDS * sizeof(R)));
+            HIP_TRY(hipMalloc((void**)&slab, slab_chunks * TILE_WORDS * sizeof(Vec4<R>)));
         }
         return check_launch();
     }
@@ -564,7 +570,7 @@ template <class R> struct Sim final : ISim {
             DevSim<R> Do = D;
             Do.active = epochs[grid_epoch].active;
             Do.nactive = epochs[grid_epoch].nactive;
-            hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 20);
+            hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 6);
         }
         grid_epoch = e;
         const Epoch& ep = epochs[e];
@@ -648,12 +654,13 @@ template <class R> struct Sim final : ISim {
         return scratch;
     }
     int ngrid_blocks() const { return (D.nactive + 3) / 4; }
+    int contact_grid() const { return 64; }                                   // small fixed grid walking the hit list
     // clear_grid :93-114 on the active blocks; p2g; (forward kinematics); slab reduce + grid_op; contact
     int forward_grid(int f, bool store_F, bool is_recompute) {
         int rc;
         if (D.nchunks == 0 || D.nactive == 0) return SMAC_OK;
         prof_begin(K_CLEAR);
-        hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 20 : 10);
+        hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 3);
         prof_end();
         prof_begin(K_P2G);
         if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
@@ -670,7 +677,9 @@ template <class R> struct Sim final : ISim {
             prof_begin(K_CONTACT);
             DevSim<R> Dc = D;
             if (is_recompute) Dc.ext_f = scratch_ext();
-            hipLaunchKernelGGL(k_contact<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, Dc, f);
+            hipMemsetAsync(d_nhits, 0, sizeof(int), stream);
+            hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f, d_hits, d_nhits);
+            hipLaunchKernelGGL(k_contact<R>, dim3(contact_grid()), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
         }
         return check_launch();
@@ -721,19 +730,21 @@ template <class R> struct Sim final : ISim {
             if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
             HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
         }
+        const bool adj_zero = adj_epoch[f] < 0;                                // A[f] is known to be all zero: write instead of +=
         adj_epoch[f] = e;
         D.An = An;
         if ((rc = forward_grid(f, false, true))) return rc;                   // :347-359 (clears values + adjoints, recomputes)
         if (D.nchunks > 0) {
             prof_begin(K_G2P_GRAD);
-            hipLaunchKernelGGL(k_g2p_grad<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :361
+            if (adj_zero) hipLaunchKernelGGL((k_g2p_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :361
+            else hipLaunchKernelGGL((k_g2p_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
             prof_end();
             prof_begin(K_REDUCE);
-            hipLaunchKernelGGL(k_reduce_agvout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+            hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
             prof_end();
             if (D.collision_type == CONTACT_MIXED && any_contact()) {             // :362-363, 389-393
                 prof_begin(K_CONTACT_GRAD);
-                hipLaunchKernelGGL(k_contact_grad<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                hipLaunchKernelGGL(k_contact_grad<R>, dim3(256), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
             }
             prof_begin(K_GRID_OP_GRAD);
@@ -745,7 +756,8 @@ template <class R> struct Sim final : ISim {
                 if ((rc = prim_fk_grad(i, f))) return rc;
         if (D.nchunks > 0) {
             prof_begin(K_P2G_GRAD);
-            hipLaunchKernelGGL(k_p2g_grad<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :371-374
+            if (adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :371-374
+            else hipLaunchKernelGGL((k_p2g_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
             prof_end();
         }
         if ((rc = check_launch())) return rc;
@@ -940,10 +952,11 @@ template <class R> struct Sim final : ISim {
     }
     int grid_ptr(const char* field, void** p, int64_t* n, int32_t* bytes) override {
         REQUIRE(field && p, "null argument");
+        // 4-scalar records per cell, block-major (smac_sort.hpp): {m,p} / {v_mixed,0} / {v_out,0} and adjoints
         struct { const char* name; R* ptr; int64_t n; } tab[] = {
-            {"grid_m", D.gm, (int64_t)D.G}, {"grid_v_in", D.gvin, (int64_t)(3 * D.G)}, {"grid_v_mixed", D.gvmix, (int64_t)(3 * D.G)},
-            {"grid_v_out", D.gvout, (int64_t)(3 * D.G)}, {"grid_m.grad", D.agm, (int64_t)D.G}, {"grid_v_in.grad", D.agvin, (int64_t)(3 * D.G)},
-            {"grid_v_mixed.grad", D.agvmix, (int64_t)(3 * D.G)}, {"grid_v_out.grad", D.agvout, (int64_t)(3 * D.G)}};
+            {"grid_in", (R*)D.vin, (int64_t)(4 * D.G)}, {"grid_mixed", (R*)D.vmix, (int64_t)(4 * D.G)}, {"grid_out", (R*)D.vout, (int64_t)(4 * D.G)},
+            {"grid_in.grad", (R*)D.ain, (int64_t)(4 * D.G)}, {"grid_mixed.grad", (R*)D.amix, (int64_t)(4 * D.G)},
+            {"grid_out.grad", (R*)D.aout, (int64_t)(4 * D.G)}};
         for (auto& t : tab)
             if (!strcmp(t.name, field)) {
                 *p = t.ptr;

@@ -61,11 +61,16 @@ template <class R> struct DevSim {
     const int* orig_id;          // sorted slot -> original particle id
     const R* An;                 // adjoint of frame f+1 in THIS epoch's particle order (A[f+1] or a re-ordered copy)
     Vec4<R>* slab;               // [nchunks][TILE_WORDS] per-chunk tiles (P2G: {m,p} ; G2P adjoint: {grid_v_out.grad,0})
-    const struct Hit* hits;      // particles inside a contact band this frame (k_contact_mask)
+    struct Hit* hits;            // particles inside a contact band this frame (written by k_p2g)
     int* nhits;
+    int* cand;                   // chunks holding at least one such particle
+    int* ncand;
+    int* pmask;                  // per particle slot: bit i = inside primitive i's band (valid for candidate chunks)
+    int any_contact;
     const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
     const int* block_chunks;
     int* drift_flag;
+    int debug;                   // SMAC_DEBUG env: timing experiments only
 };
 
 // LDS tile: the 6x6x6 nodes a particle whose base lies in a 4x4x4 block can touch (origin = 4*block).
@@ -221,11 +226,51 @@ __device__ __forceinline__ void gather_tile_load(const DevSim<R>& D, const Vec4<
 // zero `nfields` consecutive 4-scalar grid fields on the active blocks
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_clear_active(DevSim<R> D, Vec4<R>* base, int nfields) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }   // contact lists are rebuilt by k_p2g
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= D.nactive) return;
     const size_t cell = (size_t)D.active[a] * 64 + (threadIdx.x & 63);
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
     for (int f = 0; f < nfields; ++f) base[(size_t)f * D.G + cell] = z;
+}
+
+// band test shared by k_contact and k_contact_grad: which primitives see this particle
+template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const R* x) {
+    int mask = 0;
+#pragma unroll
+    for (int i = 0; i < MAX_PRIMS; ++i) {
+        if (i >= D.P || !D.prim[i].contact) continue;
+        const R* st = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+        R d = prim_sdf(D.prim[i], st, x);
+        if (d <= R(5e-3)) mask |= 1 << i;
+    }
+    return mask;
+}
+
+// Contact is sparse: only particles inside a primitive's 5e-3 band do anything in grid_op_mixed2-4
+// (for the others v_tgt == v_tmp and the mixed4 correction is exactly zero).  k_p2g evaluates the band
+// test while it has x in registers and builds (a) a compact hit list {particle, mask, block} walked by
+// the contact adjoint and (b) the list of chunks holding hits + a per-particle mask, walked by k_contact.
+struct Hit { int p, mask, block, pad; };
+// stand-alone form of the same test (used when the forward grid is restored from a checkpoint)
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
+    SMAC_CHUNK_PROLOGUE
+    int cmask = 0;
+    if (valid) {
+        R x[3];
+        load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+        cmask = contact_mask(D, f, x);
+        if (cmask) {
+            Hit h = {p, cmask, ch.block, 0};
+            D.hits[atomicAdd(D.nhits, 1)] = h;
+        }
+    }
+    const int any = __syncthreads_or(cmask);
+    if (any) {
+        if (valid) D.pmask[p] = cmask;
+        if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = blockIdx.x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -237,6 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
     SMAC_CHUNK_PROLOGUE
     for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
     __syncthreads();
+    int cmask = 0;
     if (valid) {
         const R* Sf = frame(D.S, f, D.Npad);
         R x[3], v[3], C[9], E[9], Et[9], En[9], stress[9], aff[9];
@@ -244,6 +290,13 @@ __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
+        if (D.any_contact) {                               // contact band test (x is at hand): build the sparse contact lists
+            cmask = contact_mask(D, f, x);
+            if (cmask) {
+                Hit h = {p, cmask, ch.block, 0};
+                D.hits[atomicAdd(D.nhits, 1)] = h;
+            }
+        }
         f_tmp(C, E, D.dt, Et);
         ConstState<R> cs;
         constitutive_fwd(D.mat, Et, En, stress, cs);
@@ -303,7 +356,15 @@ __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
             }
         }
     }
-    __syncthreads();
+    if (D.any_contact) {
+        const int any = __syncthreads_or(cmask);
+        if (any) {
+            if (valid) D.pmask[p] = cmask;
+            if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = blockIdx.x;
+        }
+    } else {
+        __syncthreads();
+    }
     tile_store<R, 4>(D, tile);
 }
 
@@ -353,19 +414,6 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D) {
     D.vout[cell] = o;                                                                   // :404 / :297
 }
 
-// band test shared by k_contact and k_contact_grad: which primitives see this particle
-template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const R* x) {
-    int mask = 0;
-#pragma unroll
-    for (int i = 0; i < MAX_PRIMS; ++i) {
-        if (i >= D.P || !D.prim[i].contact) continue;
-        const R* st = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-        R d = prim_sdf(D.prim[i], st, x);
-        if (d <= R(5e-3)) mask |= 1 << i;
-    }
-    return mask;
-}
-
 template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D, const Vec4<R>* field, const Stencil<R>& st,
                                                               const Nodes& nd, R* out) {
     out[0] = out[1] = out[2] = R(0);
@@ -381,42 +429,26 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
             }
 }
 
-// Contact is sparse: only particles inside a primitive's 5e-3 band do anything in grid_op_mixed2-4
-// (for the others v_tgt == v_tmp and the mixed4 correction is exactly zero).  A light kernel evaluates
-// the band test for every particle and appends the hits to a compact list {particle, mask, block}; the
-// heavy forward / adjoint contact kernels then walk that list with a small fixed grid.
-struct Hit { int p, mask, block, pad; };
-template <class R>
-__global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f, Hit* hits, int* nhits) {
-    SMAC_CHUNK_PROLOGUE
-    if (!valid) return;
-    R x[3];
-    load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
-    const int mask = contact_mask(D, f, x);
-    if (mask) {
-        Hit h = {p, mask, ch.block, 0};
-        hits[atomicAdd(nhits, 1)] = h;
-    }
-}
-
-// grid_op_mixed2 + mixed3 + mixed4 for the listed particles.  The primitive loop is rolled (one copy of
-// collide_mixed in the instruction stream: these kernels run a handful of waves and would otherwise be
-// bound by instruction fetch) and each primitive's wrench is wave-reduced before ONE atomic per wave.
+// grid_op_mixed2 + mixed3 + mixed4 for the chunks that hold particles inside a contact band.
+// The velocity corrections of a chunk are pre-reduced in an LDS tile and flushed once: contacting
+// particles share a few hundred grid nodes, and per-particle global atomics serialise on their cache lines.
+// The primitive loop is rolled (one copy of collide_mixed in the instruction stream).
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
-    const int nh = *D.nhits;
-    for (int base = blockIdx.x * BLOCK; base < nh; base += gridDim.x * BLOCK) {
-        const int hi = base + threadIdx.x;
-        Hit h = {0, 0, 0, 0};
-        if (hi < nh) h = D.hits[hi];
-        const int mask = h.mask, p = h.p;
+    __shared__ tile_t tile[3 * TILE_WORDS];
+    const int nc = *D.ncand;
+    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+        SMAC_CHUNK_PROLOGUE_AT(D.cand[ci])
+        for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
+        __syncthreads();
+        const int mask = valid ? D.pmask[p] : 0;
         R x[3] = {R(0.5), R(0.5), R(0.5)};
         R v_tmp[3] = {R(0), R(0), R(0)}, v_tgt[3] = {R(0), R(0), R(0)};
         Stencil<R> st;
         Nodes nd;
         if (mask) {
             load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
-            stencil_at(D, x, st, nd, h.block);
+            stencil_at(D, x, st, nd, ch.block);
             gather_vec(D, D.vmix, st, nd, v_tmp);                                           // mixed2
             v_tgt[0] = v_tmp[0]; v_tgt[1] = v_tmp[1]; v_tgt[2] = v_tmp[2];
         }
@@ -440,20 +472,40 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
         }
         if (mask) {
             const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
-#pragma unroll
-            for (int i = 0; i < 3; ++i)                                                     // mixed4
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const unsigned cell = nd.cell(i, j, k);
-                        if (gld(D.vin, cell).x > R(1e-10)) {
-                            const R w = R(2) * st.w[i][0] * st.w[j][1] * st.w[k][2];        // alpha = 2, :437
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) gatomic(D.vout, cell, c, -w * diff[c]);
-                        }
+#pragma unroll 1
+            for (int n = 0; n < 27; ++n) {                                                  // mixed4
+                const int i = n / 9, j = (n / 3) % 3, k = n % 3;
+                const R w = R(2) * (i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0])) *
+                            (j == 0 ? st.w[0][1] : (j == 1 ? st.w[1][1] : st.w[2][1])) *
+                            (k == 0 ? st.w[0][2] : (k == 1 ? st.w[1][2] : st.w[2][2]));         // alpha = 2, :437
+                const unsigned cell = (unsigned)((i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2])) + (j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2])) +
+                                                 (k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2])));
+                const int tw = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
+                               (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
+                const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
+                if (gld(D.vin, cell).x > R(1e-10)) {
+                    for (int c = 0; c < 3; ++c) {
+                        if (in) lds_add(tile + tw + c * TILE_WORDS, -w * diff[c]);
+                        else gatomic(D.vout, cell, c, -w * diff[c]);
                     }
+                }
+            }
         }
+        __syncthreads();
+        // flush the non-zero corrections of this chunk's tile
+        {
+            const int nb = D.nb;
+            const int bz = ch.block % nb, by = (ch.block / nb) % nb, bx = ch.block / (nb * nb);
+            for (int idx = t; idx < TILE_WORDS; idx += BLOCK) {
+                const R a0 = (R)tile[idx], a1 = (R)tile[TILE_WORDS + idx], a2 = (R)tile[2 * TILE_WORDS + idx];
+                if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
+                    const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
+                    const unsigned cell = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
+                    gatomic(D.vout, cell, 0, a0); gatomic(D.vout, cell, 1, a1); gatomic(D.vout, cell, 2, a2);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

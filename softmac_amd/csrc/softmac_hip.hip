@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -126,7 +127,9 @@ template <class R> struct Sim final : ISim {
     Vec4<R>* slab = nullptr;
     size_t slab_chunks = 0;
     Hit* d_hits = nullptr;           // capacity Npad
-    int* d_nhits = nullptr;
+    int* d_nhits = nullptr;          // [0] = nhits, [1] = ncand
+    int* d_cand = nullptr;
+    int* d_pmask = nullptr;
     int* d_drift = nullptr;
     R* dense_tmp = nullptr;
 
@@ -139,7 +142,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
-        hipFree(d_hits); hipFree(d_nhits);
+        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
         for (auto e : pool) hipEventDestroy(e);
         for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -189,11 +192,14 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(grid_block, 0, 6 * D.G * sizeof(Vec4<R>), stream));
         D.vin = grid_block; D.vmix = grid_block + D.G; D.vout = grid_block + 2 * D.G;
         D.ain = grid_block + 3 * D.G; D.amix = grid_block + 4 * D.G; D.aout = grid_block + 5 * D.G;
-        HIP_TRY(hipMalloc((void**)&d_nhits, sizeof(int)));
-        HIP_TRY(hipMemsetAsync(d_nhits, 0, sizeof(int), stream));
+        HIP_TRY(hipMalloc((void**)&d_nhits, 2 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
         HIP_TRY(hipMalloc((void**)&d_hits, (size_t)D.Npad * sizeof(Hit)));
+        HIP_TRY(hipMalloc((void**)&d_pmask, (size_t)D.Npad * sizeof(int)));
         D.nhits = d_nhits;
+        D.ncand = d_nhits + 1;
         D.hits = d_hits;
+        D.pmask = d_pmask;
         const int Pn = c.n_primitives > 0 ? c.n_primitives : 1;
         const size_t ps = (size_t)Pn * c.max_frames * 13 * sizeof(R);
         HIP_TRY(hipMalloc((void**)&D.prim_state, ps));
@@ -218,6 +224,7 @@ template <class R> struct Sim final : ISim {
         D.control_idx = d_control_idx;
         HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
         // block-sparse grid + sort scratch
+        D.debug = getenv("SMAC_DEBUG") ? atoi(getenv("SMAC_DEBUG")) : 0;
         D.nb = c.n_grid / 4;
         nblocks = D.nb * D.nb * D.nb;
         sort_interval = c.sort_interval > 0 ? c.sort_interval : 8;
@@ -559,8 +566,10 @@ template <class R> struct Sim final : ISim {
         frame_epoch[f] = e_new;
         if ((size_t)epochs[e_new].nchunks > slab_chunks) {
             hipFree(slab);
+            hipFree(d_cand);
             slab_chunks = (size_t)epochs[e_new].nchunks + epochs[e_new].nchunks / 8 + 16;
             HIP_TRY(hipMalloc((void**)&slab, slab_chunks * TILE_WORDS * sizeof(Vec4<R>)));
+            HIP_TRY(hipMalloc((void**)&d_cand, slab_chunks * sizeof(int)));
         }
         return check_launch();
     }
@@ -577,6 +586,7 @@ template <class R> struct Sim final : ISim {
         D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
         D.orig_id = ep.orig; D.block_chunk_start = ep.block_chunk_start; D.block_chunks = ep.block_chunks;
         D.slab = slab;
+        D.cand = d_cand;
         return check_launch();
     }
     int ensure_inverse(int e) {
@@ -654,11 +664,12 @@ template <class R> struct Sim final : ISim {
         return scratch;
     }
     int ngrid_blocks() const { return (D.nactive + 3) / 4; }
-    int contact_grid() const { return 64; }                                   // small fixed grid walking the hit list
+    int contact_grid() const { return D.nchunks < 512 ? D.nchunks : 512; }    // fixed grid walking the candidate-chunk list
     // clear_grid :93-114 on the active blocks; p2g; (forward kinematics); slab reduce + grid_op; contact
     int forward_grid(int f, bool store_F, bool is_recompute) {
         int rc;
         if (D.nchunks == 0 || D.nactive == 0) return SMAC_OK;
+        D.any_contact = (D.collision_type == CONTACT_MIXED && any_contact()) ? 1 : 0;
         prof_begin(K_CLEAR);
         hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 3);
         prof_end();
@@ -677,8 +688,6 @@ template <class R> struct Sim final : ISim {
             prof_begin(K_CONTACT);
             DevSim<R> Dc = D;
             if (is_recompute) Dc.ext_f = scratch_ext();
-            hipMemsetAsync(d_nhits, 0, sizeof(int), stream);
-            hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f, d_hits, d_nhits);
             hipLaunchKernelGGL(k_contact<R>, dim3(contact_grid()), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
         }

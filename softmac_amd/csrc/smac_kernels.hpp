@@ -273,6 +273,31 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
     }
 }
 
+// Grid checkpoint: the three value fields of the active blocks, packed [active slot][field][64 cells].
+// Saved after the forward substep's contact pass, restored (with the adjoint fields zeroed) at the start
+// of substep_grad instead of recomputing compute_F_tmp/svd/p2g/grid_op (mpm_simulator.py:352-359).
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck) {
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= D.nactive) return;
+    const int l = threadIdx.x & 63;
+    const size_t cell = (size_t)D.active[a] * 64 + l;
+    Vec4<R>* dst = ck + (size_t)a * 192 + l;
+    dst[0] = D.vin[cell]; dst[64] = D.vmix[cell]; dst[128] = D.vout[cell];
+}
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<R>* ck) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= D.nactive) return;
+    const int l = threadIdx.x & 63;
+    const size_t cell = (size_t)D.active[a] * 64 + l;
+    const Vec4<R>* src = ck + (size_t)a * 192 + l;
+    const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+    D.vin[cell] = src[0]; D.vmix[cell] = src[64]; D.vout[cell] = src[128];
+    D.ain[cell] = z; D.amix[cell] = z; D.aout[cell] = z;
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------

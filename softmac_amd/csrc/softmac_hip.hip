@@ -34,8 +34,8 @@ static thread_local std::string g_create_error;
         }                                    \
     } while (0)
 
-enum KernelId { K_CLEAR = 0, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_COUNT };
-static const char* kKernelNames[K_COUNT] = {"clear_grid", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
+enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"clear_grid", "grid_checkpoint", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
                                             "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint"};
 
 struct ISim {
@@ -132,6 +132,13 @@ template <class R> struct Sim final : ISim {
     int* d_pmask = nullptr;
     int* d_drift = nullptr;
     R* dense_tmp = nullptr;
+    // grid checkpoints (one slot per frame in one arena); see k_grid_save
+    Vec4<R>* ck_arena = nullptr;
+    size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
+    bool ck_enabled = true, ck_tried = false;
+    std::vector<int> ck_epoch;       // epoch the slot of frame f was saved in (-1: invalid)
+    std::vector<long long> ck_gen;   // configuration generation at save time
+    long long config_gen = 0;        // bumped whenever something the forward grid depends on may have changed
 
     ~Sim() override {
         if (stream) hipStreamSynchronize(stream);
@@ -142,7 +149,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
-        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask);
+        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
         for (auto e : pool) hipEventDestroy(e);
         for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -249,6 +256,10 @@ template <class R> struct Sim final : ISim {
         epochs[0].live = true;
         frame_epoch.assign(c.max_frames, -1);
         adj_epoch.assign(c.max_frames, -1);
+        ck_epoch.assign(c.max_frames, -1);
+        ck_gen.assign(c.max_frames, -1);
+        ck_enabled = c.grad_enabled && !(getenv("SMAC_NO_CHECKPOINT") && atoi(getenv("SMAC_NO_CHECKPOINT")));
+        if (c.flags & 1) ck_enabled = false;                    // bit 0 of flags: recompute in substep_grad like the reference
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
             D.prim[i].sdf = nullptr; D.prim[i].normal = nullptr; D.prim[i].contact = 0;
             D.prim[i].friction = (R)0.9; D.prim[i].softness = (R)666.0; D.prim[i].inv_dx = (R)1;
@@ -345,6 +356,7 @@ template <class R> struct Sim final : ISim {
         int rc = check_frame(f);
         if (rc) return rc;
         if (frame_epoch[f] < 0) frame_epoch[f] = 0;          // first write: identity order
+        ck_epoch[f] = -1;                                    // the saved forward grid of this frame is stale
         const int e = frame_epoch[f];
         if (x && (rc = upload_comp(D.S, f, CX, 3, x, false, e))) return rc;
         if (v && (rc = upload_comp(D.S, f, CV, 3, v, false, e))) return rc;
@@ -386,6 +398,8 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemcpyAsync(D.S + (size_t)dst * frame_scalars(), D.S + (size_t)src * frame_scalars(),
                                frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
         frame_epoch[dst] = frame_epoch[src];
+        ck_epoch[dst] = -1;
+        ++config_gen;                                         // primitive frames were copied too
         for (int i = 0; i < D.P; ++i)
             for (int j = 0; j < cfg.substeps; ++j) {
                 if (src + j >= cfg.max_frames || dst + j >= cfg.max_frames) break;
@@ -693,6 +707,25 @@ template <class R> struct Sim final : ISim {
         }
         return check_launch();
     }
+    // one arena for all frames, sized at the first forward substep from the current active-block count
+    bool ck_prepare() {
+        if (!ck_enabled) return false;
+        if (!ck_arena && !ck_tried) {
+            ck_tried = true;
+            ck_slot_blocks = (size_t)D.nactive + D.nactive / 4 + 64;
+            const size_t bytes = (size_t)cfg.max_frames * ck_slot_blocks * 192 * sizeof(Vec4<R>);
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2 ||
+                hipMalloc((void**)&ck_arena, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                ck_arena = nullptr;
+                ck_enabled = false;                        // not enough memory: substep_grad recomputes the forward grid
+            }
+        }
+        return ck_arena != nullptr && (size_t)D.nactive <= ck_slot_blocks;
+    }
+    Vec4<R>* ck_slot(int f) { return ck_arena + (size_t)f * ck_slot_blocks * 192; }
+
     int substep(int f, const double* action) override {
         int rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
@@ -707,6 +740,14 @@ template <class R> struct Sim final : ISim {
         }
         if ((rc = bind_epoch(e))) return rc;
         if ((rc = forward_grid(f, true, false))) return rc;
+        ck_epoch[f] = -1;
+        if (D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {              // keep the forward grid for substep_grad
+            prof_begin(K_CKPT);
+            hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f));
+            prof_end();
+            ck_epoch[f] = e;
+            ck_gen[f] = config_gen;
+        }
         if (D.nchunks > 0) {
             prof_begin(K_G2P);
             hipLaunchKernelGGL(k_g2p<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
@@ -742,7 +783,14 @@ template <class R> struct Sim final : ISim {
         const bool adj_zero = adj_epoch[f] < 0;                                // A[f] is known to be all zero: write instead of +=
         adj_epoch[f] = e;
         D.An = An;
-        if ((rc = forward_grid(f, false, true))) return rc;                   // :347-359 (clears values + adjoints, recomputes)
+        if (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0) {
+            // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing
+            D.any_contact = (D.collision_type == CONTACT_MIXED && any_contact()) ? 1 : 0;
+            prof_begin(K_CKPT);
+            hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f));
+            if (D.any_contact) hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+            prof_end();
+        } else if ((rc = forward_grid(f, false, true))) return rc;            // :347-359 (clears values + adjoints, recomputes)
         if (D.nchunks > 0) {
             prof_begin(K_G2P_GRAD);
             if (adj_zero) hipLaunchKernelGGL((k_g2p_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :361
@@ -805,18 +853,21 @@ template <class R> struct Sim final : ISim {
         T.sdf = prim_tables[prim][0]; T.normal = prim_tables[prim][1];
         for (int d = 0; d < 3; ++d) { T.res[d] = res[d]; T.lower[d] = (R)lower[d]; T.upper[d] = (R)upper[d]; }
         T.inv_dx = (R)(1.0 / dx);                                             // mesh.py:29
+        ++config_gen;
         return SMAC_OK;
     }
     int prim_set_params(int prim, double friction, double softness, int contact) override {
         int rc = check_prim(prim);
         if (rc) return rc;
         D.prim[prim].friction = (R)friction; D.prim[prim].softness = (R)softness; D.prim[prim].contact = contact ? 1 : 0;
+        ++config_gen;
         return SMAC_OK;
     }
     int prim_set_state(int prim, int f0, int f1, const double* s13) override {
         int rc = check_prim(prim);
         if (rc) return rc;
         REQUIRE(s13 && f0 >= 0 && f1 <= cfg.max_frames && f0 < f1, "prim_set_state: bad frame range");
+        for (int f = f0; f < f1; ++f) ck_epoch[f] = -1;
         std::vector<R> tmp((size_t)(f1 - f0) * 13);
         for (int f = 0; f < f1 - f0; ++f)
             for (int c = 0; c < 13; ++c) tmp[(size_t)f * 13 + c] = (R)s13[c];
@@ -895,6 +946,7 @@ template <class R> struct Sim final : ISim {
         int rc = check_prim(prim);
         if (rc) return rc;
         REQUIRE(a6 && s >= 0 && n >= 1 && (s + 1) * n <= cfg.max_frames, "prim_set_action: frames out of range");
+        for (int f = s * n; f < (s + 1) * n; ++f) ck_epoch[f] = -1;
         R a[6];
         for (int c = 0; c < 6; ++c) a[c] = (R)a6[c];
         HIP_TRY(hipMemcpyAsync(action_buf + ((size_t)prim * cfg.max_frames + s) * 6, a, sizeof a, hipMemcpyHostToDevice, stream));
@@ -927,6 +979,7 @@ template <class R> struct Sim final : ISim {
     int prim_reset(int prim) override {                                       // :271-275
         int rc = check_prim(prim);
         if (rc) return rc;
+        ++config_gen;
         HIP_TRY(hipMemsetAsync(pstate(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(R), stream));
         HIP_TRY(hipMemsetAsync(pgrad(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(R), stream));
         HIP_TRY(hipMemsetAsync(action_buf + (size_t)prim * cfg.max_frames * 6, 0, (size_t)cfg.max_frames * 6 * sizeof(R), stream));

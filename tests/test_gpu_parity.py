@@ -134,6 +134,28 @@ def test_grip_fixture_forecast_contact(precision):
     _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg, tol=tol)
 
 
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_backward_recompute_path(precision):
+    """substep_grad with the reference's recompute (flags bit 0) instead of the saved forward grid."""
+    d = np.load(H.GOLDEN / "grip_state_2k.npz")
+    state = d["state"]
+    specs, pstates = _palm_scene(state, 4)
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, precision=precision, recompute_backward=True)
+    tol = None if precision == "float64" else dict(state=5e-4, grad=5e-3)
+    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, tol=tol)
+
+
+def test_resort_every_substep_and_long_window():
+    """Epoch changes inside the window: re-sort every substep (adjoint re-ordering across epochs) and a
+    window longer than the default sort interval; particle ids must stay stable for the caller."""
+    n_grid, N = 32, 3000
+    state = H.make_cloud(N, n_grid, seed=4, lo=(0.3, 0.05, 0.3), hi=(0.7, 0.4, 0.7), v_std=1.0)
+    for interval, steps in ((1, 4), (8, 11)):
+        cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, ground_friction=0.0, precision="float64",
+                        sort_interval=interval, max_steps=16)
+        _compare_rollout(cfg, 1e-3, state, steps)
+
+
 @pytest.mark.parametrize("precision", ["float64"])
 def test_two_primitives_one_disabled(precision):
     d = np.load(H.GOLDEN / "grip_state_2k.npz")

@@ -1,0 +1,168 @@
+"""CPU tests of the oracle itself (-m "not gpu"): it has no reference tests to be pinned against
+("parity unpinned", see oracle/softmac_oracle.py), so it is pinned by analytic invariants, by central
+finite differences of every adjoint, by the reference's own data files as inputs, and by the committed
+golden vectors (regression)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import scenes_golden as G
+from helpers import O
+
+
+def _cloud(N=400, n_grid=32, seed=0, **kw):
+    x, v, C, F = O.state24_split(H.make_cloud(N, n_grid, seed=seed, lo=(0.35, 0.2, 0.35), hi=(0.65, 0.5, 0.65), **kw))
+    return x, v, C, F
+
+
+def test_p2g_conserves_mass_and_momentum():
+    P = O.SimParams(n_grid=32, dt=2e-4, ptype=1)
+    x, v, C, F = _cloud()
+    C = torch.zeros_like(C); F = torch.eye(3, dtype=O.DT).expand_as(F).clone()      # no stress, no affine term
+    Ft = O.compute_F_tmp(C, F, P.dt)
+    U, sig, V = O.svd3(Ft)
+    _, gv, gm, _ = O.p2g(x, v, C, Ft, U, sig, V, P)
+    assert abs(gm.sum().item() - len(x) * P.p_mass) < 1e-15
+    assert torch.allclose(gv.sum((0, 1, 2)), P.p_mass * v.sum(0), atol=1e-15)
+
+
+def test_svd_contract_and_adjoint_formula():
+    rng = np.random.default_rng(0)
+    F = torch.tensor(np.eye(3) + 0.2 * rng.standard_normal((50, 3, 3)))
+    W = torch.tensor(rng.standard_normal((50, 3, 3)))
+    U, sig, V = O.svd3(F)
+    assert torch.allclose(U @ sig @ V.transpose(-1, -2), F, atol=1e-13)
+    one = torch.ones(50, dtype=O.DT)
+    assert torch.allclose(torch.linalg.det(U), one) and torch.allclose(torch.linalg.det(V), one)
+    # away from the +-1e-6 clamp the reference's backward_svd is the true derivative: compare with autograd of a
+    # gauge-invariant function (the polar rotation) evaluated through torch's own SVD
+    Fl = F.clone().requires_grad_(True)
+    U, sig, V = O.svd3(Fl)
+    (g_ref,) = torch.autograd.grad(((U @ V.transpose(-1, -2)) * W).sum(), Fl)
+    Fl2 = F.clone().requires_grad_(True)
+    U2, S2, Vh2 = torch.linalg.svd(Fl2)
+    (g_true,) = torch.autograd.grad(((U2 @ Vh2) * W).sum(), Fl2)
+    assert torch.allclose(g_ref, g_true, rtol=1e-7, atol=1e-9)
+
+
+def test_liquid_projection_and_elastic_identity():
+    rng = np.random.default_rng(1)
+    Ft = torch.tensor(np.eye(3) + 0.05 * rng.standard_normal((20, 3, 3)))
+    U, sig, V = O.svd3(Ft)
+    nF, _ = O.constitutive(Ft, U, sig, V, O.SimParams(ptype=2, E=22.0))
+    J = torch.linalg.det(Ft)
+    assert torch.allclose(nF, torch.eye(3, dtype=O.DT) * (J ** (1 / 3))[:, None, None])       # mpm_simulator.py:233
+    nF, _ = O.constitutive(Ft, U, sig, V, O.SimParams(ptype=1))
+    assert torch.equal(nF, Ft)                                                                  # :230-231
+    nF, _ = O.constitutive(Ft, U, sig, V, O.SimParams(ptype=0))
+    s = torch.linalg.svdvals(nF)
+    assert s.max() <= 1 + 3e-3 + 1e-12 and s.min() >= 1 - 2e-3 - 1e-12                          # :226-229
+
+
+def test_affine_field_is_reproduced_by_p2g_g2p():
+    """G2P(P2G(rigid affine velocity field)) returns that field's C (APIC property of the transfer)."""
+    P = O.SimParams(n_grid=32, dt=1e-5, ptype=1, gravity=(0, 0, 0), ground_friction=0.0, E=1e-9)
+    rng = np.random.default_rng(3)
+    g = (np.arange(24) + 0.5) / 2 / 32 + 0.3            # a regular lattice, 8 per cell, away from the walls
+    X = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    A = 0.3 * rng.standard_normal((3, 3)); b = rng.standard_normal(3)
+    x = torch.tensor(X); v = torch.tensor(X @ A.T + b)
+    C = torch.tensor(A).expand(len(X), 3, 3).clone(); F = torch.eye(3, dtype=O.DT).expand(len(X), 3, 3).clone()
+    nx, nv, nC, nF, _ = O.substep(x, v, C, F, P)
+    inner = torch.tensor(((X > 0.36) & (X < 0.61)).all(1))
+    assert torch.allclose(nC[inner], torch.tensor(A).expand_as(nC[inner]), atol=1e-6)
+    assert torch.allclose(nv[inner], v[inner], atol=1e-6)
+
+
+def test_mixed_contact_without_primitive_in_range_is_plain_grid_op():
+    P = O.SimParams(n_grid=32, dt=2e-4, ptype=0)
+    x, v, C, F = _cloud()
+    palm = H.load_palm()
+    far = O.make_prim([0.5, 5.0, 0.5], [1, 0, 0, 0], [0, 0, 0], [0, 0, 0], palm["sdf"], palm["normal"], palm["lower"],
+                      palm["upper"], palm["dx"])
+    a = O.substep(x, v, C, F, P, (), 0)
+    b = O.substep(x, v, C, F, P, (far,), 0)
+    for t, u in zip(a[:4], b[:4]):
+        assert torch.equal(t, u)
+    assert torch.equal(b[4][0], torch.zeros(6, dtype=O.DT))
+
+
+@pytest.mark.parametrize("ptype,model", [(0, 0), (1, 0), (2, 0), (1, 1)])
+def test_substep_adjoint_finite_differences(ptype, model):
+    P = O.SimParams(n_grid=32, dt=2e-4, ptype=ptype, material_model=model, E=22.0 if ptype == 2 else 3e3)
+    x, v, C, F = _cloud(N=300, seed=ptype + 3 * model)
+    rng = np.random.default_rng(5)
+    g = [torch.tensor(rng.standard_normal(t.shape)) for t in (x, v, C, F)]
+    out = O.substep_grad(x, v, C, F, P, (), 0, *g)
+
+    def L(**kw):
+        a = dict(x=x, v=v, C=C, F=F); a.update(kw)
+        r = O.substep(a["x"], a["v"], a["C"], a["F"], P, (), 0)
+        return sum((t * gg).sum() for t, gg in zip(r[:4], g)).item()
+    eps = 1e-6
+    for name, t, gr in (("x", x, out["gx"]), ("v", v, out["gv"]), ("C", C, out["gC"]), ("F", F, out["gF"])):
+        d = torch.tensor(rng.standard_normal(t.shape))
+        fd = (L(**{name: t + eps * d}) - L(**{name: t - eps * d})) / (2 * eps)
+        an = (gr * d).sum().item()
+        assert abs(fd - an) <= 2e-6 * max(abs(fd), abs(an), 1.0), (name, fd, an)
+
+
+def test_contact_adjoint_finite_differences_reference_fixture():
+    """collide_mixed adjoint (primitive pose/velocity, ext_f seeds) on the grip fixture + palm SDF."""
+    sc = G.build("grip_contact")
+    P = H.oracle_params(sc["cfg"], sc["env_dt"])
+    x, v, C, F = O.state24_split(sc["state"])
+    prims = H.OracleRollout(P, sc["state"], sc["specs"], sc["pstates"]).prims_at(0)
+    rng = np.random.default_rng(9)
+    g = [torch.tensor(rng.standard_normal(t.shape)) for t in (x, v, C, F)]
+    eg = [torch.tensor(rng.standard_normal(6))]
+    out = O.substep_grad(x, v, C, F, P, prims, 0, *g, ext_f_grad=eg)
+    gp = torch.cat(out["prims"][0]).numpy()
+
+    def L(st13):
+        s = sc["specs"][0]
+        pr = [O.make_prim(st13[:3], st13[3:7], st13[7:10], st13[10:], s["sdf"], s["normal"], s["lower"], s["upper"], s["dx"],
+                          s["friction"], s["softness"])]
+        r = O.substep(x, v, C, F, P, pr, 0)
+        return (sum((t * gg).sum() for t, gg in zip(r[:4], g)) + (r[4][0] * eg[0]).sum()).item()
+    s0 = np.asarray(sc["pstates"][0][0])
+    # velocity components enter smoothly (no band edges): tight check; pose components cross band edges: loose
+    for sel, eps, tol in ((slice(7, 13), 1e-6, 1e-5), (slice(0, 7), 1e-8, 2e-2)):
+        d = np.zeros(13); d[sel] = rng.standard_normal(len(d[sel]))
+        fd = (L(s0 + eps * d) - L(s0 - eps * d)) / (2 * eps)
+        an = float(gp @ d)
+        assert abs(fd - an) <= tol * max(abs(fd), abs(an)), (sel, fd, an)
+
+
+def test_forward_kinematics_and_quaternions():
+    q = torch.tensor([0.9, 0.1, -0.3, 0.2], dtype=O.DT); q = q / q.norm()
+    p, r = O.forward_kinematics(torch.tensor([0.1, 0.2, 0.3], dtype=O.DT), q, torch.tensor([1., 2., 3.], dtype=O.DT),
+                                torch.zeros(3, dtype=O.DT), 1e-3)
+    assert torch.allclose(p, torch.tensor([0.101, 0.202, 0.303], dtype=O.DT)) and torch.allclose(r, q, atol=1e-6)
+    vv = torch.tensor([[0.3, -0.2, 0.5]], dtype=O.DT)
+    back = O.inv_trans(O.qrot(q, vv) + 1.0, torch.ones(3, dtype=O.DT), q)
+    assert torch.allclose(back, vv, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", G.SCENES)
+def test_golden_vectors_regression(name):
+    sc = G.build(name)
+    got = G.run_oracle(sc)
+    ref = np.load(H.GOLDEN / f"oracle_{name}.npz")
+    for k in ref.files:
+        scale = max(np.abs(ref[k]).max(), 1e-30)
+        assert np.abs(got[k] - ref[k]).max() / scale < 1e-9, k
+
+
+def test_reference_fixtures_are_what_the_survey_says():
+    g = np.load(H.GOLDEN / "grip_state_2k.npz")["state"]
+    assert g.shape == (2000, 24) and 0.41 < g[:, 0].min() and g[:, 0].max() < 0.59
+    assert np.abs(g[:, 6:15] - np.eye(3).reshape(9)).max() < 0.05
+    p = np.load(H.GOLDEN / "pour_state_1k.npz")["state"]
+    assert np.allclose(p[:, 6], p[:, 10]) and np.allclose(p[:, 6], p[:, 14]) and np.abs(p[:, [7, 8, 9, 11, 12, 13]]).max() == 0  # liquid: F = c I
+    palm = H.load_palm()
+    assert tuple(palm["res"]) == (86, 46, 27) and abs(palm["dx"] - 0.0075) < 1e-12
+    # the reference's voxeliser rule (mesh.py:170-233) reproduced analytically for the palm box
+    from softmac_amd import scenes
+    assert np.abs(scenes.box_sdf()["sdf"] - palm["sdf"]).max() < 1e-12

@@ -33,6 +33,8 @@ def build_sim(args, rank, world):
         cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, frames, args.precision, dev, seed=1 + rank)
     else:
         cfg, env_dt, state, specs, s13 = scenes.s_elastic(args.particles, args.grid, frames, args.precision, dev, seed=rank)
+    cfg.recompute_backward = args.recompute_backward
+    cfg.sort_interval = args.sort_interval
     meshes = []
     for s in specs:
         pc = CfgNode(); pc.friction = s["friction"]; pc.enable_external_force = True; pc.urdf_path = ""
@@ -59,41 +61,43 @@ def algorithmic_bytes(N, G_t, s):
 
 # compulsory bytes of each kernel taken alone (DESIGN.md "kernels"): scalars per particle, scalars per touched cell
 KERNEL_BYTES = {
-    "p2g": (24 + 9, 4), "grid_op": (0, 4 + 6), "contact": (3, 0), "g2p": (3 + 15, 3),
-    "g2p_grad": (3 + 15 + 3, 3 + 3), "contact_grad": (3, 0), "grid_op_grad": (0, 4 + 6 + 4), "p2g_grad": (24 + 9 + 3 + 24, 4),
-    "clear_grid": (0, 10), "forward_kinematics": (0, 0),
+    "p2g": (24 + 9, 4), "grid_op": (0, 4 + 6), "contact": (0, 0), "g2p": (3 + 15, 3),
+    "g2p_grad": (3 + 15 + 3, 3 + 3), "contact_grad": (0, 0), "grid_op_grad": (0, 4 + 6 + 4), "p2g_grad": (24 + 9 + 3 + 24, 4),
+    "clear_grid": (0, 10), "grid_checkpoint": (0, 20), "reduce_agvout": (0, 6), "forward_kinematics": (0, 0),
+    "sort": (48, 0), "reorder_adjoint": (48, 0),
 }
 
 
 def cpu_baseline(args):
-    """Oracle (CPU restatement, f64) timed on a bounded sample of the same workload on this box's host cores."""
-    import torch
+    """The plain C++/OpenMP f64 oracle port (oracle/mpm_cpu.cpp: the reference's decomposition - dense grid,
+    one pass per Taichi kernel, atomics) timed on this box's host cores on a bounded sample of the SAME workload."""
     from softmac_amd import scenes
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
-    from oracle import softmac_oracle as O
-    n_s, grid_s = args.cpu_particles, args.cpu_grid
-    cfg, env_dt, state, specs, s13 = scenes.s_grip(n_s, grid_s, 8, "float64", 0, seed=1)
+    from oracle import mpm_cpu
+    cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, "float64", 0, seed=1)
     P = H.oracle_params(cfg, env_dt)
+    port = mpm_cpu.CpuPort(P, specs)
+    N = args.particles
+    x, v = state[:, 0:3].copy(), state[:, 3:6].copy()
+    F, C = state[:, 6:15].reshape(N, 3, 3).copy(), state[:, 15:24].reshape(N, 3, 3).copy()
     nsub = args.cpu_steps
-    pstates = []
-    for f in range(nsub + 1):
-        row = []
-        for st in s13:
-            a = st.copy(); a[:3] += f * cfg.dt * a[7:10]; row.append(a)
-        pstates.append(row)
-    threads = torch.get_num_threads()
-    t0 = time.perf_counter()
-    orc = H.OracleRollout(P, state, specs, pstates).forward(nsub)
     rng = np.random.default_rng(0)
-    seeds = {nsub: (rng.standard_normal((n_s, 3)), None, None, None)}
-    orc.backward(seeds)
+    frames = [(x, v, C, F)]
+    psts = []
+    t0 = time.perf_counter()
+    for f in range(nsub):
+        pst = np.array([a + np.concatenate([f * cfg.dt * a[7:10], np.zeros(10)]) for a in s13])
+        psts.append(pst)
+        nx, nv, nC, nF, _ = port.substep(f, *frames[-1], pst)
+        frames.append((nx, nv, nC, nF))
+    g = [rng.standard_normal((N, 3)), np.zeros((N, 3)), np.zeros((N, 3, 3)), np.zeros((N, 3, 3))]
+    for f in range(nsub - 1, -1, -1):
+        g = list(port.substep_grad(f, *frames[f], *g, pst=psts[f])[:4])
     dt = time.perf_counter() - t0
-    per_particle_rate = nsub * n_s / dt                       # particle-substeps / s (fwd+bwd)
-    value = per_particle_rate / args.particles                # scaled to substeps/s at the benchmark's N
-    return {"value": value, "unit": "substeps/s (fwd+bwd)", "cores": threads, "kind": "port",
-            "sample": f"{nsub} fwd+bwd substeps of S-grip at {n_s} particles / {grid_s}^3 (same 8 ppc, same primitives), "
-                      f"f64 torch oracle, {dt:.1f}s, scaled by particle count to {args.particles}"}
+    return {"value": nsub / dt, "unit": "substeps/s (fwd+bwd)", "cores": port.threads(), "kind": "port",
+            "sample": f"{nsub} forward + {nsub} backward substeps of the full workload ({N} particles, {args.grid}^3, 3 primitives), "
+                      f"f64 C++/OpenMP restatement of the reference's kernel decomposition (not Taichi), {dt:.1f} s on {port.threads()} threads"}
 
 
 def main():
@@ -106,9 +110,9 @@ def main():
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--precision", default="float32", choices=["float32", "float64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-particles", type=int, default=1 << 16)
-    ap.add_argument("--cpu-grid", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
+    ap.add_argument("--sort-interval", type=int, default=0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -193,6 +197,8 @@ def main():
             "config": {"workload": f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
                                    f"3 gripper SDF primitives (2 in forecast contact), fwd+bwd",
                        "particles_per_gpu": N, "n_grid": args.grid, "touched_cells": G_t,
+                       "backward": "forward grid recomputed in substep_grad (reference style)" if args.recompute_backward
+                       else "forward grid restored from the per-frame checkpoint saved by substep",
                        "parallelism": "1 gpu" if world == 1 else f"{world} independent slabs (no halo yet)"},
             "device_ms_per_step": dev_ms / K,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -64,7 +64,8 @@ typedef struct smac_config {
     int32_t rigid_velocity_control; /* 1: substep() advances primitive poses with forward_kinematics (:329-331, 367-369) */
     int32_t sort_interval;    /* re-bin particles every this many substeps (0 = default 8); no reference counterpart */
     int32_t flags;            /* bit 0: substep_grad recomputes the forward grid like the reference (:352-359) instead of
-                                 restoring the copy saved by substep (DESIGN.md "grid checkpoint") */
+                                 restoring the copy saved by substep (DESIGN.md "grid checkpoint");
+                                 bit 1 / bit 2: slab decomposition - no wall at the low / high x end */
     double dt;
     double mu, lam;
     double p_vol, p_mass;
@@ -131,6 +132,21 @@ int smac_count_active_cells(smac_handle h, int f, int64_t* cells); /* cells with
  * torch tensors for torch.distributed/RCCL; no reference counterpart - SURVEY 8e). */
 int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64_t* n_scalars, int32_t* scalar_bytes);
 int smac_stream_handle(smac_handle h, void** hip_stream);
+int smac_set_stream(smac_handle h, void* hip_stream);   /* run on the caller's stream (e.g. torch's current stream, so RCCL ops order with the kernels) */
+
+/* ---- slab decomposition over several GPUs (softmac_amd/parallel.py drives it with torch.distributed).
+ * config.flags bit 1 / bit 2: a neighbour slab sits at the low / high x end (no wall there).
+ * smac_substep_phase: phase 0 = clear + p2g + slab reduction  -> then sum "grid_in" halo planes with the neighbours
+ *                     phase 1 = grid_op + contact            -> then sum the contact corrections of "grid_out" (minus_mixed = 1)
+ *                     phase 2 = grid checkpoint + g2p
+ * smac_substep_grad_phase: phase 0 = restore forward grid + g2p.grad -> then sum "grid_out.grad" halo planes
+ *                          phase 1 = contact adjoint                -> then sum "grid_mixed.grad" halo planes
+ *                          phase 2 = grid_op.grad + p2g.grad
+ * Halo buffers are dense (nplanes, n, n) arrays of 4-scalar records in the handle's precision, in DEVICE memory. */
+int smac_substep_phase(smac_handle h, int f, int phase);
+int smac_substep_grad_phase(smac_handle h, int f, const double* ext_f_grad, int phase);
+int smac_halo_pack(smac_handle h, const char* field, int plane0, int nplanes, void* dev_out, int minus_mixed);
+int smac_halo_unpack_add(smac_handle h, const char* field, int plane0, int nplanes, const void* dev_in);
 
 #ifdef __cplusplus
 }

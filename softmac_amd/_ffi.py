@@ -78,6 +78,11 @@ SIGNATURES = {
     "smac_count_active_cells": (C.c_int, [H, C.c_int, C.POINTER(C.c_int64)]),
     "smac_grid_device_ptr": (C.c_int, [H, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "smac_stream_handle": (C.c_int, [H, C.POINTER(C.c_void_p)]),
+    "smac_set_stream": (C.c_int, [H, C.c_void_p]),
+    "smac_substep_phase": (C.c_int, [H, C.c_int, C.c_int]),
+    "smac_substep_grad_phase": (C.c_int, [H, C.c_int, c_double_p, C.c_int]),
+    "smac_halo_pack": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "smac_halo_unpack_add": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 

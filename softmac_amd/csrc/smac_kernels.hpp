@@ -71,6 +71,8 @@ template <class R> struct DevSim {
     const int* block_chunks;
     int* drift_flag;
     int debug;                   // SMAC_DEBUG env: timing experiments only
+    int open_x;                  // slab decomposition: bit 0 / bit 1 = no wall at the low / high x end (neighbour slab there)
+    const int* block_active;     // dense per-block flag of the current epoch (halo packing)
 };
 
 // LDS tile: the 6x6x6 nodes a particle whose base lies in a 4x4x4 block can touch (origin = 4*block).
@@ -399,8 +401,9 @@ template <class R> __device__ __forceinline__ int boundary(const DevSim<R>& D, i
     int mask = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        if (I[d] < 3 && v[d] < R(0)) { v[d] = R(0); mask |= 1 << d; }
-        if (I[d] > D.n - 3 && v[d] > R(0)) { v[d] = R(0); mask |= 1 << d; }
+        const bool wall_lo = !(d == 0 && (D.open_x & 1)), wall_hi = !(d == 0 && (D.open_x & 2));
+        if (wall_lo && I[d] < 3 && v[d] < R(0)) { v[d] = R(0); mask |= 1 << d; }
+        if (wall_hi && I[d] > D.n - 3 && v[d] > R(0)) { v[d] = R(0); mask |= 1 << d; }
     }
     if (D.sticky && j < 3) { v[0] = v[1] = v[2] = R(0); mask = 7; }                   // :278-279
     return mask;
@@ -421,14 +424,19 @@ template <class R> __device__ __forceinline__ bool active_cell(const DevSim<R>& 
 }
 
 // slab reduction (completes P2G) fused with grid_op :283-297 / grid_op_mixed1 :396-404
+// phase 0: both; 1: slab reduction only (multi-GPU: the halo planes of {m,p} are summed across slabs next);
+// 2: normalisation only
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D) {
+__global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
     Vec4<R> acc = D.vin[cell];                                                          // drift fallback part
-    slab_reduce(D, b, l, acc);
-    D.vin[cell] = acc;
+    if (phase != 2) {
+        slab_reduce(D, b, l, acc);
+        D.vin[cell] = acc;
+    }
+    if (phase == 1) return;
     const R m = acc.x;
     if (!(m > R(1e-10))) return;                                                       // :286 / :399
     const R inv = R(1) / m;
@@ -1027,6 +1035,37 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
             Af[(size_t)(CF + i) * D.Npad + p] = gE[i];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// halo planes for the slab decomposition: x-planes [plane0, plane0+np) of one 4-scalar field,
+// packed dense (np, n, n) for RCCL send/recv.  Cells of blocks that are not active in this epoch read as
+// zero / are not written (their storage may hold stale data from another epoch).
+// ------------------------------------------------------------------------------------------
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_halo_pack(DevSim<R> D, const Vec4<R>* field, const Vec4<R>* minus, int plane0, int np, Vec4<R>* out) {
+    const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= np * D.n * D.n) return;
+    const int k = idx % D.n, j = (idx / D.n) % D.n, i = plane0 + idx / (D.n * D.n);
+    Vec4<R> v = {R(0), R(0), R(0), R(0)};
+    if (D.block_active[block_of(D.nb, i, j, k)]) {
+        const size_t c = cell_of(D.nb, i, j, k);
+        v = field[c];
+        if (minus) { const Vec4<R> m = minus[c]; v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
+    }
+    out[idx] = v;
+}
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_halo_unpack_add(DevSim<R> D, Vec4<R>* field, int plane0, int np, const Vec4<R>* in) {
+    const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= np * D.n * D.n) return;
+    const int k = idx % D.n, j = (idx / D.n) % D.n, i = plane0 + idx / (D.n * D.n);
+    if (!D.block_active[block_of(D.nb, i, j, k)]) return;
+    const size_t c = cell_of(D.nb, i, j, k);
+    const Vec4<R> a = in[idx];
+    Vec4<R> v = field[c];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    field[c] = v;
 }
 
 // ------------------------------------------------------------------------------------------

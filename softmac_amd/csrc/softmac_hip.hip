@@ -75,6 +75,11 @@ struct ISim {
     virtual int profile_get(int i, char* name, int cap, double* ms, int64_t* launches) = 0;
     virtual int count_active_cells(int f, int64_t* cells) = 0;
     virtual int grid_ptr(const char* field, void** p, int64_t* n, int32_t* bytes) = 0;
+    virtual int substep_phase_v(int f, int phase) = 0;
+    virtual int substep_grad_phase_v(int f, const double* ext_f_grad, int phase) = 0;
+    virtual int halo_pack(const char* field, int plane0, int np, void* dev_out, int minus_mixed) = 0;
+    virtual int halo_unpack_add(const char* field, int plane0, int np, const void* dev_in) = 0;
+    virtual int set_stream(void* s) = 0;
     virtual int stream_handle(void** s) = 0;
 };
 
@@ -107,6 +112,7 @@ template <class R> struct Sim final : ISim {
         int nactive = 0;
         int* block_chunk_start = nullptr;
         int* block_chunks = nullptr;
+        int* block_active = nullptr;
         int frame = 0;              // frame at which the sort happened
         std::vector<int> h_orig;    // host copy (lazy) for IO
         bool live = false;
@@ -155,7 +161,7 @@ template <class R> struct Sim final : ISim {
         for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
         if (t0) hipEventDestroy(t0);
         if (t1) hipEventDestroy(t1);
-        if (stream) hipStreamDestroy(stream);
+        if (stream && own_stream) hipStreamDestroy(stream);
     }
 
     size_t frame_scalars() const { return (size_t)NCOMP * D.Npad; }
@@ -232,6 +238,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
         // block-sparse grid + sort scratch
         D.debug = getenv("SMAC_DEBUG") ? atoi(getenv("SMAC_DEBUG")) : 0;
+        D.open_x = (c.flags >> 1) & 3;                               // flags bits 1,2: neighbour slab at the low / high x end
         D.nb = c.n_grid / 4;
         nblocks = D.nb * D.nb * D.nb;
         sort_interval = c.sort_interval > 0 ? c.sort_interval : 8;
@@ -498,8 +505,8 @@ template <class R> struct Sim final : ISim {
 
     // ---- epochs / sorting ------------------------------------------------------------------
     static void free_epoch(Epoch& e) {
-        hipFree(e.orig); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks);
-        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = nullptr;
+        hipFree(e.orig); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
+        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = nullptr;
         e.chunks = nullptr;
         e.h_orig.clear(); e.h_orig.shrink_to_fit();
         e.live = false;
@@ -573,6 +580,8 @@ template <class R> struct Sim final : ISim {
                            (const int*)d_active_flag, (const int*)d_active_start, ep.chunks, ep.active);
         HIP_TRY(hipMemcpyAsync(ep.block_chunk_start, d_chunk_start, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipMemcpyAsync(ep.block_chunks, d_block_chunks, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMalloc((void**)&ep.block_active, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(ep.block_active, d_active_flag, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         prof_end();
         ep.frame = f;
         ep.live = true;
@@ -599,6 +608,7 @@ template <class R> struct Sim final : ISim {
         const Epoch& ep = epochs[e];
         D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
         D.orig_id = ep.orig; D.block_chunk_start = ep.block_chunk_start; D.block_chunks = ep.block_chunks;
+        D.block_active = ep.block_active;
         D.slab = slab;
         D.cand = d_cand;
         return check_launch();
@@ -679,26 +689,30 @@ template <class R> struct Sim final : ISim {
     }
     int ngrid_blocks() const { return (D.nactive + 3) / 4; }
     int contact_grid() const { return D.nchunks < 512 ? D.nchunks : 512; }    // fixed grid walking the candidate-chunk list
-    // clear_grid :93-114 on the active blocks; p2g; (forward kinematics); slab reduce + grid_op; contact
-    int forward_grid(int f, bool store_F, bool is_recompute) {
+    // Forward grid passes.  stage 0: everything; stage 1: clear_grid :93-114 on the active blocks, p2g, (forward
+    // kinematics), slab reduction; stage 2: grid_op + contact.  Stages 1/2 exist for the slab decomposition, which
+    // sums the {m,p} halo planes across neighbouring GPUs between them.
+    int forward_grid(int f, bool store_F, bool is_recompute, int stage = 0) {
         int rc;
         if (D.nchunks == 0 || D.nactive == 0) return SMAC_OK;
         D.any_contact = (D.collision_type == CONTACT_MIXED && any_contact()) ? 1 : 0;
-        prof_begin(K_CLEAR);
-        hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 3);
-        prof_end();
-        prof_begin(K_P2G);
-        if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
-        else hipLaunchKernelGGL((k_p2g<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
-        prof_end();
-        if (!is_recompute && cfg.rigid_velocity_control) {                    // :329-331
-            for (int i = 0; i < D.P; ++i)
-                if ((rc = prim_fk(i, f))) return rc;
+        if (stage != 2) {
+            prof_begin(K_CLEAR);
+            hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 3);
+            prof_end();
+            prof_begin(K_P2G);
+            if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+            else hipLaunchKernelGGL((k_p2g<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+            prof_end();
+            if (!is_recompute && cfg.rigid_velocity_control) {                    // :329-331
+                for (int i = 0; i < D.P; ++i)
+                    if ((rc = prim_fk(i, f))) return rc;
+            }
         }
         prof_begin(K_GRID_OP);
-        hipLaunchKernelGGL(k_grid_op<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+        hipLaunchKernelGGL(k_grid_op<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, stage);
         prof_end();
-        if (D.collision_type == CONTACT_MIXED && any_contact()) {
+        if (stage != 1 && D.any_contact) {
             prof_begin(K_CONTACT);
             DevSim<R> Dc = D;
             if (is_recompute) Dc.ext_f = scratch_ext();
@@ -726,104 +740,167 @@ template <class R> struct Sim final : ISim {
     }
     Vec4<R>* ck_slot(int f) { return ck_arena + (size_t)f * ck_slot_blocks * 192; }
 
-    int substep(int f, const double* action) override {
+    // substep :320-337.  phase -1: whole substep; 0 / 1 / 2: the three pieces between which the slab decomposition
+    // exchanges halo planes (after 0: {m,p}; after 1: the contact corrections of v_out).
+    int substep_phase(int f, const double* action, int phase) {
         int rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
-        if ((rc = check_contact_supported())) return rc;
-        if (action && (rc = set_action(action))) return rc;
-        int e = frame_epoch[f];
-        if (e == 0 || f - epochs[e].frame >= sort_interval || f < epochs[e].frame) {
-            if (e > 0 && (rc = check_drift())) return rc;
-            if ((rc = sort_frame(f))) return rc;
-            e = frame_epoch[f];
+        if (phase <= 0) {
+            if ((rc = check_contact_supported())) return rc;
+            if (action && (rc = set_action(action))) return rc;
+            int e = frame_epoch[f];
+            if (e == 0 || f - epochs[e].frame >= sort_interval || f < epochs[e].frame) {
+                if (e > 0 && (rc = check_drift())) return rc;
+                if ((rc = sort_frame(f))) return rc;
+                e = frame_epoch[f];
+            }
+            if ((rc = bind_epoch(e))) return rc;
+            ck_epoch[f] = -1;
+            if ((rc = forward_grid(f, true, false, phase < 0 ? 0 : 1))) return rc;
         }
-        if ((rc = bind_epoch(e))) return rc;
-        if ((rc = forward_grid(f, true, false))) return rc;
-        ck_epoch[f] = -1;
-        if (D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {              // keep the forward grid for substep_grad
-            prof_begin(K_CKPT);
-            hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f));
-            prof_end();
-            ck_epoch[f] = e;
-            ck_gen[f] = config_gen;
+        if (phase == 1 && (rc = forward_grid(f, true, false, 2))) return rc;
+        if (phase < 0 || phase == 2) {
+            const int e = frame_epoch[f];
+            if (D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {              // keep the forward grid for substep_grad
+                prof_begin(K_CKPT);
+                hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f));
+                prof_end();
+                ck_epoch[f] = e;
+                ck_gen[f] = config_gen;
+            }
+            if (D.nchunks > 0) {
+                prof_begin(K_G2P);
+                hipLaunchKernelGGL(k_g2p<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                prof_end();
+            }
+            frame_epoch[f + 1] = e;
         }
-        if (D.nchunks > 0) {
-            prof_begin(K_G2P);
-            hipLaunchKernelGGL(k_g2p<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
-            prof_end();
-        }
-        frame_epoch[f + 1] = e;
         return check_launch();
     }
-    int substep_grad(int f, const double* action, const double* ext_f_grad, double* action_grad_out) override {
+    int substep(int f, const double* action) override { return substep_phase(f, action, -1); }
+
+    // substep_grad :339-378.  phase -1: whole; 0: restore/recompute + g2p.grad (+ slab reduction of grid_v_out.grad);
+    // 1: contact adjoint; 2: grid_op.grad, kinematics adjoint, p2g.grad.  Halo sums of grid_v_out.grad follow phase 0,
+    // of grid_v_mixed.grad phase 1.
+    bool pending_adj_zero = false;
+    int substep_grad_phase(int f, const double* action, const double* ext_f_grad, double* action_grad_out, int phase) {
         int rc;
         if ((rc = need_grad())) return rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep_grad: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] > 0, "substep_grad: frame f was not produced/consumed by a forward substep");
-        if ((rc = check_contact_supported())) return rc;
-        if (action && (rc = set_action(action))) return rc;
-        if (ext_f_grad && D.P > 0) {                                          // :342-344
-            R tmp[6 * SMAC_MAX_PRIMS];
-            for (int i = 0; i < 6 * D.P; ++i) tmp[i] = (R)ext_f_grad[i];
-            HIP_TRY(hipMemcpyAsync(D.ext_f_grad, tmp, 6 * D.P * sizeof(R), hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-        }
         const int e = frame_epoch[f];
-        if ((rc = bind_epoch(e))) return rc;
-        // adjoint of frame f+1 in this epoch's particle order; adjoint of frame f must be in it too
-        const R* An = nullptr;
-        if ((rc = adjoint_in_order(f + 1, e, &An))) return rc;
-        if (adj_epoch[f] >= 0 && adj_epoch[f] != e) {                         // seeds stored in another order: convert in place
-            const R* tmp = nullptr;
-            REQUIRE(An != tmp_frame, "adjoint frames f and f+1 both need re-ordering (unsupported seed placement)");
-            if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
-            HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
-        }
-        const bool adj_zero = adj_epoch[f] < 0;                                // A[f] is known to be all zero: write instead of +=
-        adj_epoch[f] = e;
-        D.An = An;
-        if (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0) {
-            // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing
-            D.any_contact = (D.collision_type == CONTACT_MIXED && any_contact()) ? 1 : 0;
-            prof_begin(K_CKPT);
-            hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f));
-            if (D.any_contact) hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
-            prof_end();
-        } else if ((rc = forward_grid(f, false, true))) return rc;            // :347-359 (clears values + adjoints, recomputes)
-        if (D.nchunks > 0) {
-            prof_begin(K_G2P_GRAD);
-            if (adj_zero) hipLaunchKernelGGL((k_g2p_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :361
-            else hipLaunchKernelGGL((k_g2p_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
-            prof_end();
-            prof_begin(K_REDUCE);
-            hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
-            prof_end();
-            if (D.collision_type == CONTACT_MIXED && any_contact()) {             // :362-363, 389-393
-                prof_begin(K_CONTACT_GRAD);
-                hipLaunchKernelGGL(k_contact_grad<R>, dim3(256), dim3(BLOCK), 0, stream, D, f);
+        if (phase <= 0) {
+            if ((rc = check_contact_supported())) return rc;
+            if (action && (rc = set_action(action))) return rc;
+            if (ext_f_grad && D.P > 0) {                                          // :342-344
+                R tmp[6 * SMAC_MAX_PRIMS];
+                for (int i = 0; i < 6 * D.P; ++i) tmp[i] = (R)ext_f_grad[i];
+                HIP_TRY(hipMemcpyAsync(D.ext_f_grad, tmp, 6 * D.P * sizeof(R), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
+            if ((rc = bind_epoch(e))) return rc;
+            // adjoint of frame f+1 in this epoch's particle order; adjoint of frame f must be in it too
+            const R* An = nullptr;
+            if ((rc = adjoint_in_order(f + 1, e, &An))) return rc;
+            if (adj_epoch[f] >= 0 && adj_epoch[f] != e) {                         // seeds stored in another order: convert in place
+                const R* tmp = nullptr;
+                REQUIRE(An != tmp_frame, "adjoint frames f and f+1 both need re-ordering (unsupported seed placement)");
+                if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
+                HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+            }
+            pending_adj_zero = adj_epoch[f] < 0;                                  // A[f] is known to be all zero: write instead of +=
+            adj_epoch[f] = e;
+            D.An = An;
+            if (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0) {
+                // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing
+                D.any_contact = (D.collision_type == CONTACT_MIXED && any_contact()) ? 1 : 0;
+                prof_begin(K_CKPT);
+                hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f));
+                if (D.any_contact) hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                prof_end();
+            } else {
+                REQUIRE(phase < 0, "slab-decomposed substep_grad needs the forward-grid checkpoint of this frame "
+                                   "(recomputing it would need the forward halo exchanges again)");
+                if ((rc = forward_grid(f, false, true))) return rc;               // :347-359 (clears values + adjoints, recomputes)
+            }
+            if (D.nchunks > 0) {
+                prof_begin(K_G2P_GRAD);
+                if (pending_adj_zero) hipLaunchKernelGGL((k_g2p_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :361
+                else hipLaunchKernelGGL((k_g2p_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                prof_end();
+                prof_begin(K_REDUCE);
+                hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
             }
-            prof_begin(K_GRID_OP_GRAD);
-            hipLaunchKernelGGL(k_grid_op_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);   // :394 / :365
+        }
+        if ((phase < 0 || phase == 1) && D.nchunks > 0 && D.collision_type == CONTACT_MIXED && any_contact()) {   // :362-363, 389-393
+            prof_begin(K_CONTACT_GRAD);
+            hipLaunchKernelGGL(k_contact_grad<R>, dim3(256), dim3(BLOCK), 0, stream, D, f);
             prof_end();
         }
-        if (cfg.rigid_velocity_control)                                       // :367-369
-            for (int i = D.P - 1; i >= 0; --i)
-                if ((rc = prim_fk_grad(i, f))) return rc;
-        if (D.nchunks > 0) {
-            prof_begin(K_P2G_GRAD);
-            if (adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :371-374
-            else hipLaunchKernelGGL((k_p2g_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
-            prof_end();
+        if (phase < 0 || phase == 2) {
+            if (D.nchunks > 0) {
+                prof_begin(K_GRID_OP_GRAD);
+                hipLaunchKernelGGL(k_grid_op_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);   // :394 / :365
+                prof_end();
+            }
+            if (cfg.rigid_velocity_control)                                       // :367-369
+                for (int i = D.P - 1; i >= 0; --i)
+                    if ((rc = prim_fk_grad(i, f))) return rc;
+            if (D.nchunks > 0) {
+                prof_begin(K_P2G_GRAD);
+                if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :371-374
+                else hipLaunchKernelGGL((k_p2g_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                prof_end();
+            }
+            if ((rc = check_launch())) return rc;
+            if (action_grad_out && D.n_control > 0) {                             // :378
+                R tmp[3 * 64];
+                HIP_TRY(hipMemcpyAsync(tmp, D.action_grad, 3 * D.n_control * sizeof(R), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                for (int i = 0; i < 3 * D.n_control; ++i) action_grad_out[i] = (double)tmp[i];
+            }
         }
-        if ((rc = check_launch())) return rc;
-        if (action_grad_out && D.n_control > 0) {                             // :378
-            R tmp[3 * 64];
-            HIP_TRY(hipMemcpyAsync(tmp, D.action_grad, 3 * D.n_control * sizeof(R), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            for (int i = 0; i < 3 * D.n_control; ++i) action_grad_out[i] = (double)tmp[i];
-        }
+        return check_launch();
+    }
+    int substep_grad(int f, const double* action, const double* ext_f_grad, double* action_grad_out) override {
+        return substep_grad_phase(f, action, ext_f_grad, action_grad_out, -1);
+    }
+    int substep_phase_v(int f, int phase) override { return substep_phase(f, nullptr, phase); }
+    int substep_grad_phase_v(int f, const double* ext_f_grad, int phase) override { return substep_grad_phase(f, nullptr, ext_f_grad, nullptr, phase); }
+
+    // ---- halo planes (slab decomposition) -------------------------------------------------------
+    Vec4<R>* field_by_name(const char* name) {
+        struct { const char* n; Vec4<R>* p; } tab[] = {{"grid_in", D.vin}, {"grid_mixed", D.vmix}, {"grid_out", D.vout},
+                                                       {"grid_in.grad", D.ain}, {"grid_mixed.grad", D.amix}, {"grid_out.grad", D.aout}};
+        for (auto& t : tab)
+            if (!strcmp(t.n, name)) return t.p;
+        return nullptr;
+    }
+    int halo_pack(const char* field, int plane0, int np, void* dev_out, int minus_mixed) override {
+        Vec4<R>* fp = field ? field_by_name(field) : nullptr;
+        REQUIRE(fp && dev_out && plane0 >= 0 && np > 0 && plane0 + np <= D.n, "halo_pack: bad field / plane range");
+        REQUIRE(grid_epoch > 0, "halo_pack: no epoch bound");
+        const int total = np * D.n * D.n;
+        hipLaunchKernelGGL(k_halo_pack<R>, dim3(nblk(total)), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)fp,
+                           (const Vec4<R>*)(minus_mixed ? D.vmix : nullptr), plane0, np, (Vec4<R>*)dev_out);
+        return check_launch();
+    }
+    int halo_unpack_add(const char* field, int plane0, int np, const void* dev_in) override {
+        Vec4<R>* fp = field ? field_by_name(field) : nullptr;
+        REQUIRE(fp && dev_in && plane0 >= 0 && np > 0 && plane0 + np <= D.n, "halo_unpack_add: bad field / plane range");
+        REQUIRE(grid_epoch > 0, "halo_unpack_add: no epoch bound");
+        const int total = np * D.n * D.n;
+        hipLaunchKernelGGL(k_halo_unpack_add<R>, dim3(nblk(total)), dim3(BLOCK), 0, stream, D, fp, plane0, np, (const Vec4<R>*)dev_in);
+        return check_launch();
+    }
+    bool own_stream = true;
+    int set_stream(void* s) override {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (own_stream && stream) hipStreamDestroy(stream);
+        stream = (hipStream_t)s;
+        own_stream = false;
         return SMAC_OK;
     }
 
@@ -1125,5 +1202,14 @@ int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64
     return FWD(grid_ptr(field, dev_ptr, n_scalars, scalar_bytes));
 }
 int smac_stream_handle(smac_handle h, void** hip_stream) { return FWD(stream_handle(hip_stream)); }
+int smac_set_stream(smac_handle h, void* hip_stream) { return FWD(set_stream(hip_stream)); }
+int smac_substep_phase(smac_handle h, int f, int phase) { return FWD(substep_phase_v(f, phase)); }
+int smac_substep_grad_phase(smac_handle h, int f, const double* ext_f_grad, int phase) { return FWD(substep_grad_phase_v(f, ext_f_grad, phase)); }
+int smac_halo_pack(smac_handle h, const char* field, int plane0, int nplanes, void* dev_out, int minus_mixed) {
+    return FWD(halo_pack(field, plane0, nplanes, dev_out, minus_mixed));
+}
+int smac_halo_unpack_add(smac_handle h, const char* field, int plane0, int nplanes, const void* dev_in) {
+    return FWD(halo_unpack_add(field, plane0, nplanes, dev_in));
+}
 
 }  // extern "C"

@@ -102,3 +102,37 @@ def s_elastic(n_particles=1 << 18, n_grid=64, max_steps=128, precision="float32"
     cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=2e-4, ptype=1, max_steps=max_steps,
                         precision=precision, device=device, ground_friction=1.5)
     return cfg, 2e-3, state, [], []
+
+
+def s_grip_slab(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
+                substeps=10, lo=32, hi=96):
+    """Weak-scaling variant of S-grip for several GPUs: one continuous bar of plasticine along x, cut into
+    `world` slabs.  Rank r simulates in local coordinates on its own n_grid^3 grid and owns the particles whose
+    stencil base lies in x-planes [lo, hi); its planes [hi, hi+2) are the same physical planes as the right
+    neighbour's [lo, lo+2).  Same particle count, density and primitives per GPU as the single-GPU workload
+    (the two fingers close on the bar's z faces)."""
+    rng = np.random.default_rng(seed + 1000 * rank)
+    wx = hi - lo
+    side = (n_particles / 8 / wx) ** 0.5                     # y,z extent in cells at 8 particles per cell
+    dx = 1.0 / n_grid
+    x = np.empty((n_particles, 3))
+    x[:, 0] = (lo + 0.5 + wx * rng.random(n_particles)) * dx * (1 - 1e-9)
+    y0, z0 = 0.3 - side * dx / 2, 0.5 - side * dx / 2
+    x[:, 1] = y0 + side * dx * rng.random(n_particles)
+    x[:, 2] = z0 + side * dx * rng.random(n_particles)
+    v = 0.05 * rng.standard_normal((n_particles, 3))
+    F = np.eye(3).reshape(1, 9) + 5e-3 * rng.standard_normal((n_particles, 9))
+    C = 0.5 * rng.standard_normal((n_particles, 9))
+    state = np.hstack([x, v, F, C])
+    cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=dt, max_steps=max_steps, precision=precision, device=device)
+    cfg.slab_flags = (2 if rank > 0 else 0) | (4 if rank < world - 1 else 0)      # smac_config.flags bits 1,2
+    finger, palm = cylinder_sdf(), box_sdf()
+    specs = [dict(palm, friction=0.001, softness=666.0, contact=False),
+             dict(finger, friction=0.001, softness=666.0, contact=True),
+             dict(finger, friction=0.001, softness=666.0, contact=True)]
+    ident = [1.0, 0.0, 0.0, 0.0]
+    xc = (lo + wx / 2) * dx
+    s13 = [np.array([xc, y0 + side * dx + 0.2, 0.5] + ident + [0, 0, 0] + [0, 0, 0], dtype=np.float64),
+           np.array([xc, 0.3, z0 - 0.05 + 0.002] + ident + [0, 0, 0.3] + [0, 0, 0], dtype=np.float64),
+           np.array([xc, 0.3, z0 + side * dx + 0.05 - 0.002] + ident + [0, 0, -0.3] + [0, 0, 0], dtype=np.float64)]
+    return cfg, dt * substeps, state, specs, s13, (lo, hi)

@@ -1,0 +1,149 @@
+"""Engines for the slab-decomposition tests.
+
+OracleSlabEngine: a stand-in for the HIP engine built from the oracle's kernels on dense torch grids, with the
+same phase / halo interface as softmac_amd.parallel.HipSlabEngine.  It lets the world_size-2 gloo test exercise
+SlabRunner's exchange logic on the CPU (test infrastructure only)."""
+import numpy as np
+import torch
+
+import helpers as H
+from helpers import O
+
+
+class OracleSlabEngine:
+    def __init__(self, P, state24, prim_specs=(), prim_states=None):
+        self.P, self.n = P, P.n_grid
+        self.frames = [O.state24_split(state24)]
+        self.specs, self.pstates = list(prim_specs), prim_states
+        n = self.n
+        z = lambda: torch.zeros(n, n, n, 4, dtype=O.DT)
+        self.fields = {k: z() for k in ("grid_in", "grid_mixed", "grid_out", "grid_in.grad", "grid_mixed.grad", "grid_out.grad")}
+        self.ck = {}
+        self.adj = {}
+        self.ext = [torch.zeros(6, dtype=O.DT) for _ in self.specs]
+        self.pgrad = {}
+        self.newF = None
+
+    # ---- helpers
+    def prims_at(self, f, leaves=False):
+        out, lv = [], []
+        for i, s in enumerate(self.specs):
+            st = torch.as_tensor(np.asarray(self.pstates[f][i]), dtype=O.DT)
+            parts = [st[:3].clone(), st[3:7].clone(), st[7:10].clone(), st[10:13].clone()]
+            if leaves:
+                parts = [p.requires_grad_(True) for p in parts]
+            lv.append(parts)
+            out.append(O.RigidPrim(*parts, torch.as_tensor(s["sdf"], dtype=O.DT), torch.as_tensor(s["normal"], dtype=O.DT),
+                                   torch.as_tensor(s["lower"], dtype=O.DT), torch.as_tensor(s["upper"], dtype=O.DT), float(s["dx"]),
+                                   float(s.get("friction", 0.9)), float(s.get("softness", 666.0)), bool(s.get("contact", True))))
+        return out, lv
+
+    def get_adj(self, f):
+        if f not in self.adj:
+            N = self.frames[0][0].shape[0]
+            self.adj[f] = [torch.zeros(N, 3, dtype=O.DT), torch.zeros(N, 3, dtype=O.DT), torch.zeros(N, 3, 3, dtype=O.DT),
+                           torch.zeros(N, 3, 3, dtype=O.DT)]
+        return self.adj[f]
+
+    def new_buffer(self, nplanes):
+        return torch.zeros(nplanes, self.n, self.n, 4, dtype=O.DT)
+
+    def halo_pack(self, field, plane0, nplanes, buf, minus_mixed=0):
+        v = self.fields[field][plane0:plane0 + nplanes]
+        if minus_mixed:
+            v = v - self.fields["grid_mixed"][plane0:plane0 + nplanes]
+        buf.copy_(v)
+
+    def halo_unpack_add(self, field, plane0, nplanes, buf):
+        self.fields[field][plane0:plane0 + nplanes] += buf
+
+    def _contact(self, x, vmix, gm, prims, f):
+        """correction added to grid_v_out by mixed2-4, and the per-primitive wrench"""
+        v_tmp = O.grid_op_mixed2(x, vmix, self.P)
+        v_tgt, ext = O.grid_op_mixed3(x, v_tmp, prims, self.P, f)
+        corr = O.grid_op_mixed4(x, v_tmp, v_tgt, gm, torch.zeros_like(vmix), self.P)
+        return corr, ext
+
+    # ---- forward phases
+    def phase(self, f, k):
+        P = self.P
+        x, v, C, F = self.frames[f]
+        if k == 0:
+            Ft = O.compute_F_tmp(C, F, P.dt)
+            U, sig, V = O.svd3(Ft) if P.material_model == 0 else (None, None, None)
+            self.newF, gv, gm, _ = O.p2g(x, v, C, Ft, U, sig, V, P)
+            self.fields["grid_in"] = torch.cat([gm[..., None], gv], -1)
+        elif k == 1:
+            gin = self.fields["grid_in"]
+            vmix = O.grid_op_mixed1(gin[..., 0], gin[..., 1:], P)
+            vout = vmix
+            prims, _ = self.prims_at(f)
+            if any(p.contact for p in prims) and x.shape[0] > 0:
+                corr, ext = self._contact(x, vmix, gin[..., 0], prims, f)
+                vout = vmix + corr
+                self.ext = [a + b for a, b in zip(self.ext, ext)]
+            pad = torch.zeros(self.n, self.n, self.n, 1, dtype=O.DT)
+            self.fields["grid_mixed"] = torch.cat([vmix, pad], -1)
+            self.fields["grid_out"] = torch.cat([vout, pad], -1)
+        else:
+            self.ck[f] = {k_: self.fields[k_].clone() for k_ in ("grid_in", "grid_mixed", "grid_out")}
+            nx, nv, nC = O.g2p(x, self.fields["grid_out"][..., :3], P)
+            nxt = (nx, nv, nC, self.newF)
+            if len(self.frames) > f + 1:
+                self.frames[f + 1] = nxt
+            else:
+                self.frames.append(nxt)
+
+    # ---- backward phases (autograd per piece)
+    def grad_phase(self, f, k, ext_f_grad=None):
+        P = self.P
+        x, v, C, F = self.frames[f]
+        a1 = self.get_adj(f + 1)
+        a0 = self.get_adj(f)
+        if k == 0:
+            for k_, val in self.ck[f].items():
+                self.fields[k_] = val.clone()
+            for k_ in ("grid_in.grad", "grid_mixed.grad", "grid_out.grad"):
+                self.fields[k_] = torch.zeros(self.n, self.n, self.n, 4, dtype=O.DT)
+            self._eg = ext_f_grad
+            xl = x.clone().requires_grad_(True)
+            vo = self.fields["grid_out"][..., :3].clone().requires_grad_(True)
+            nx, nv, nC = O.g2p(xl, vo, P)
+            L = (nx * a1[0]).sum() + (nv * a1[1]).sum() + (nC * a1[2]).sum()
+            gx, gvo = torch.autograd.grad(L, [xl, vo])
+            a0[0] = a0[0] + gx
+            self.fields["grid_out.grad"][..., :3] = gvo
+        elif k == 1:
+            prims, leaves = self.prims_at(f, leaves=True)
+            if any(p.contact for p in prims) and x.shape[0] > 0:
+                xl = x.clone().requires_grad_(True)
+                vm = self.fields["grid_mixed"][..., :3].clone().requires_grad_(True)
+                corr, ext = self._contact(xl, vm, self.fields["grid_in"][..., 0], prims, f)
+                L = (corr * self.fields["grid_out.grad"][..., :3]).sum()
+                if self._eg is not None:
+                    for e, g in zip(ext, self._eg):
+                        L = L + (e * torch.as_tensor(g, dtype=O.DT)).sum()
+                inputs = [xl, vm] + [t for lv in leaves for t in lv]
+                gr = torch.autograd.grad(L, inputs, allow_unused=True)
+                gr = [torch.zeros_like(i) if g is None else g for g, i in zip(gr, inputs)]
+                a0[0] = a0[0] + gr[0]
+                self.fields["grid_mixed.grad"][..., :3] = gr[1]
+                for i in range(len(prims)):
+                    self.pgrad.setdefault(f, [np.zeros(13) for _ in prims])
+                    self.pgrad[f][i] += torch.cat(gr[2 + 4 * i: 6 + 4 * i]).numpy()
+        else:
+            gin = self.fields["grid_in"]
+            gm = gin[..., 0].clone().requires_grad_(True)
+            gv = gin[..., 1:].clone().requires_grad_(True)
+            vmix = O.grid_op_mixed1(gm, gv, P)
+            up = self.fields["grid_out.grad"][..., :3] + self.fields["grid_mixed.grad"][..., :3]
+            agm, agv = torch.autograd.grad((vmix * up).sum(), [gm, gv], allow_unused=True)
+            agm = torch.zeros_like(gm) if agm is None else agm
+            leaves = [t.clone().requires_grad_(True) for t in (x, v, C, F)]
+            Ft = O.compute_F_tmp(leaves[2], leaves[3], P.dt)
+            U, sig, V = O.svd3(Ft) if P.material_model == 0 else (None, None, None)
+            nF, pgv, pgm, _ = O.p2g(leaves[0], leaves[1], leaves[2], Ft, U, sig, V, P)
+            L = (nF * a1[3]).sum() + (pgv * agv).sum() + (pgm * agm).sum()
+            gr = torch.autograd.grad(L, leaves)
+            for i in range(4):
+                a0[i] = a0[i] + gr[i]

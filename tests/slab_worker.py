@@ -1,0 +1,73 @@
+"""One rank of the 2-slab test (spawned by tests/test_slabs.py): runs SlabRunner over either the oracle
+stand-in engine (CPU, gloo) or the real HIP engine (GPU box; gloo staging through the host because both ranks
+share the one GPU), and writes its particles' results to <out>/rank<r>.npz."""
+import argparse
+import os
+import pathlib
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE)); sys.path.insert(0, str(HERE.parent))
+import helpers as H  # noqa: E402
+import scenes_slab as S  # noqa: E402
+from softmac_amd.parallel import SlabRunner  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--engine", default="oracle"); ap.add_argument("--rank", type=int); ap.add_argument("--world", type=int)
+    ap.add_argument("--port", type=int); ap.add_argument("--out"); ap.add_argument("--precision", default="float64")
+    a = ap.parse_args()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port))
+    dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+    sc = S.build(a.precision)
+    idx = S.owned(sc, a.rank, a.world)
+    state = sc["state"][idx]
+    nsteps = sc["nsteps"]
+    seeds = S.seeds(sc)
+    if a.engine == "oracle":
+        import slab_engines as E
+        eng = E.OracleSlabEngine(H.oracle_params(sc["cfg"], sc["env_dt"]), state, sc["specs"], sc["pstates"])
+        run = SlabRunner(eng, a.rank, a.world, sc["split"], sc["split"], 2, has_contact=bool(sc["specs"]))
+        run.run_substeps(0, nsteps)
+        for f, s in seeds.items():
+            adj = eng.get_adj(f)
+            for k in range(4):
+                if s[k] is not None:
+                    adj[k] = adj[k] + torch.as_tensor(s[k][idx]).reshape(adj[k].shape)
+        run.run_substeps_grad(0, nsteps, sc["ext_f_grad"])
+        x, v, C, F = eng.frames[nsteps]
+        g = eng.get_adj(0)
+        out = dict(x=x.numpy(), v=v.numpy(), C=C.numpy(), F=F.numpy(), gx=g[0].numpy(), gv=g[1].numpy(), gC=g[2].numpy(), gF=g[3].numpy(),
+                   ext=np.array([e.numpy() for e in eng.ext]) if sc["specs"] else np.zeros((0, 6)),
+                   pgrad=np.array([eng.pgrad.get(f, [np.zeros(13)] * len(sc["specs"])) for f in range(nsteps)]))
+    else:
+        from softmac_amd.parallel import HipSlabEngine
+        cfg = sc["cfg"]
+        cfg.n_particles = len(state)
+        sim, prims = H.build_engine(cfg, sc["env_dt"], sc["specs"], sc["pstates"])
+        sim.reset(state)
+        eng = HipSlabEngine(sim, use_torch_stream=True)
+        run = SlabRunner(eng, a.rank, a.world, sc["split"], sc["split"], 2, has_contact=bool(sc["specs"]))
+        run.run_substeps(0, nsteps)
+        sim.clear_grads()
+        for f, s in seeds.items():
+            sim.add_grad(f, **{k: (None if s[i] is None else s[i][idx]) for i, k in enumerate(("gx", "gv", "gC", "gF"))})
+        run.run_substeps_grad(0, nsteps, sc["ext_f_grad"])
+        st = sim.get_state(nsteps)
+        N = len(state)
+        gx, gv, gF, gC = sim.get_grad_full(0)
+        out = dict(x=st[:, 0:3], v=st[:, 3:6], F=st[:, 6:15].reshape(N, 3, 3), C=st[:, 15:24].reshape(N, 3, 3), gx=gx, gv=gv, gC=gC, gF=gF,
+                   ext=np.array([m.ext_f.to_numpy() for m in prims]) if sc["specs"] else np.zeros((0, 6)),
+                   pgrad=np.array([[m.get_all_states_grad(f) for m in prims] for f in range(nsteps)]))
+    np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=idx, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,9 @@ def load_library(path=None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
+    import os
+    if path is None and os.environ.get("SMAC_LIB"):          # experiments: an alternative build of the same ABI
+        path = os.environ["SMAC_LIB"]
     p = pathlib.Path(path) if path else LIB_PATH
     if not p.exists():
         raise RuntimeError(

@@ -27,6 +27,15 @@
 
 namespace smac {
 
+#ifndef SMAC_OCC_HEAVY
+#define SMAC_OCC_HEAVY 2      // A/B on MI355X: 2 waves/SIMD without spills beats 3-4 with scratch traffic
+#endif
+#ifndef SMAC_OCC_G2P
+#define SMAC_OCC_G2P 4
+#endif
+#ifndef SMAC_OCC_P2G
+#define SMAC_OCC_P2G 4
+#endif
 constexpr int BLOCK = 256;
 enum { CX = 0, CV = 3, CC = 6, CF = 15, NCOMP = 24 };
 
@@ -67,6 +76,7 @@ template <class R> struct DevSim {
     int* ncand;
     int* pmask;                  // per particle slot: bit i = inside primitive i's band (valid for candidate chunks)
     int any_contact;
+    int cur_frame;               // frame of the substep being processed (kernels without an f argument)
     const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
     const int* block_chunks;
     int* drift_flag;
@@ -269,7 +279,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
         }
     }
     const int any = __syncthreads_or(cmask);
-    if (any) {
+    if (D.collision_type == CONTACT_PARTICLE) {
+        if (valid) D.pmask[p] = cmask;
+    } else if (any) {
         if (valid) D.pmask[p] = cmask;
         if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = blockIdx.x;
     }
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
 // forward
 // ------------------------------------------------------------------------------------------
 template <class R, bool STORE_F>
-__global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_p2g(DevSim<R> D, int f) {
     __shared__ tile_t tile[4 * TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
-        if (D.any_contact) {                               // contact band test (x is at hand): build the sparse contact lists
+        if (D.any_contact && D.collision_type != CONTACT_GRID) {   // contact band test (x is at hand): build the sparse contact lists
             cmask = contact_mask(D, f, x);
             if (cmask) {
                 Hit h = {p, cmask, ch.block, 0};
@@ -335,6 +347,19 @@ __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
         R pv[3] = {D.p_mass * v[0], D.p_mass * v[1], D.p_mass * v[2]};
+        if (D.collision_type == CONTACT_PARTICLE && cmask) {                              // :203-206 penalty contact impulse
+#pragma unroll 1
+            for (int i = 0; i < D.P; ++i) {
+                if (!((cmask >> i) & 1)) continue;
+                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                R s13[13], imp[3], ext[6];
+                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+                if (collide_particle(D.prim[i], s13, x, v, D.dt, imp, ext)) {
+                    for (int c = 0; c < 3; ++c) pv[c] += imp[c];
+                    for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + i * 6 + c, ext[c]);   // sparse: a few thousand particles
+                }
+            }
+        }
         if (D.n_control > 0) {                                                            // :209-213
             int ci = D.control_idx[D.orig_id[p]];
             if (ci >= 0)
@@ -383,13 +408,14 @@ __global__ __launch_bounds__(BLOCK) void k_p2g(DevSim<R> D, int f) {
             }
         }
     }
-    if (D.any_contact) {
+    if (D.any_contact && D.collision_type == CONTACT_MIXED) {
         const int any = __syncthreads_or(cmask);
         if (any) {
             if (valid) D.pmask[p] = cmask;
             if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = blockIdx.x;
         }
     } else {
+        if (D.any_contact && D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;   // read back by p2g.grad
         __syncthreads();
     }
     tile_store<R, 4>(D, tile);
@@ -441,6 +467,18 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     if (!(m > R(1e-10))) return;                                                       // :286 / :399
     const R inv = R(1) / m;
     R v[3] = {inv * acc.y + D.dt * D.g[0], inv * acc.z + D.dt * D.g[1], inv * acc.w + D.dt * D.g[2]};   // :287-288
+    if (D.collision_type == CONTACT_GRID && D.any_contact) {                           // :290-294 grid-node contact
+        const R pos[3] = {R(i) * D.dx, R(j) * D.dx, R(k) * D.dx};
+#pragma unroll 1
+        for (int q = 0; q < D.P; ++q) {
+            if (!D.prim[q].contact) continue;
+            const R* ps = D.prim_state + ((size_t)q * D.max_frames + D.cur_frame) * 13;
+            R s13[13], ext[6];
+            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            if (collide_grid(D.prim[q], s13, pos, v, m, D.dt, ext))
+                for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + q * 6 + c, ext[c]);
+        }
+    }
     boundary(D, i, j, k, v);
     const Vec4<R> o = {v[0], v[1], v[2], R(0)};
     if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = o;                            // :403
@@ -543,7 +581,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
 }
 
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_g2p(DevSim<R> D, int f) {
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_g2p(DevSim<R> D, int f) {
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     gather_tile_load(D, D.vout, ch.block, gt);
@@ -616,7 +654,7 @@ template <class R> struct WGrad {
 };
 
 template <class R, bool ACC_X>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? 3 : 2)) void k_g2p_grad(DevSim<R> D, int f) {
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_HEAVY : 2)) void k_g2p_grad(DevSim<R> D, int f) {
     __shared__ tile_t tile[3 * TILE_WORDS];
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
@@ -856,6 +894,69 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
     }
 }
 
+// Adjoint of the penalty contact impulse of p2g (collision_type 1) for the listed particles: the impulse's
+// adjoint is sum_nodes w * grid_v_in.grad (what p2g.grad calls gvp); 32 lanes per hit, lane n < 27 gathers node n,
+// lane d < 19 runs forward-mode direction d (p_pos3, p_v3, state13).
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, int f) {
+    const int nh = *D.nhits;
+    const int grp = threadIdx.x >> 5, d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
+    for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
+        const int hi = base + grp;
+        Hit h = {0, 0, 0, 0};
+        if (hi < nh) h = D.hits[hi];
+        const int mask = h.mask, p = h.p;
+        R x[3] = {R(0.5), R(0.5), R(0.5)}, v[3] = {R(0), R(0), R(0)};
+        if (mask) {
+            load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+            load_vec(frame(D.S, f, D.Npad), CV, 3, D.Npad, p, v);
+        }
+        Stencil<R> st;
+        Nodes nd;
+        stencil_at(D, x, st, nd, h.block);
+        const int n = d < 27 ? d : 0;
+        const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+        const R wn = (ni == 0 ? st.w[0][0] : (ni == 1 ? st.w[1][0] : st.w[2][0])) * (nj == 0 ? st.w[0][1] : (nj == 1 ? st.w[1][1] : st.w[2][1])) *
+                     (nk == 0 ? st.w[0][2] : (nk == 1 ? st.w[1][2] : st.w[2][2]));
+        const unsigned cell = (unsigned)((ni == 0 ? nd.cx[0] : (ni == 1 ? nd.cx[1] : nd.cx[2])) + (nj == 0 ? nd.cy[0] : (nj == 1 ? nd.cy[1] : nd.cy[2])) +
+                                         (nk == 0 ? nd.cz[0] : (nk == 1 ? nd.cz[1] : nd.cz[2])));
+        R gi[3] = {R(0), R(0), R(0)};
+        if (mask && d < 27) {
+            const Vec4<R> a = gld(D.ain, cell);
+            gi[0] = wn * a.y; gi[1] = wn * a.z; gi[2] = wn * a.w;
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gi[c] += __shfl_xor(gi[c], o, 64);
+#pragma unroll 1
+        for (int i = 0; i < D.P; ++i) {
+            const bool act = (mask >> i) & 1;
+            if (!__ballot(act)) continue;
+            R out = R(0);
+            if (act && d < 19) {
+                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                Dual<R> xs[3], vs[3], ss[13], im[3], es[6];
+                for (int c = 0; c < 3; ++c) { xs[c] = Dual<R>(x[c], d == c ? R(1) : R(0)); vs[c] = Dual<R>(v[c], d == 3 + c ? R(1) : R(0)); }
+                for (int c = 0; c < 13; ++c) ss[c] = Dual<R>(ps[c], d == 6 + c ? R(1) : R(0));
+                if (collide_particle(D.prim[i], ss, xs, vs, D.dt, im, es)) {
+                    for (int c = 0; c < 3; ++c) out += gi[c] * im[c].d;
+                    for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * es[c].d;
+                }
+            }
+            if (act && d < 6 && !((D.debug & 16) && d < 3)) {
+                R* Af = frame(D.A, f, D.Npad);
+                Af[(size_t)((d < 3 ? CX : CV - 3) + d) * D.Npad + p] += out;
+            }
+            R sg = (act && d >= 6 && d < 19) ? out : R(0);
+            sg += __shfl_xor(sg, 32, 64);
+            if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != R(0))
+                atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + (d - 6), sg);
+            (void)lane0;
+        }
+    }
+}
+
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     int b, l, i, j, k;
@@ -875,14 +976,61 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     R v[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) v[d] = inv * vin[d] + D.dt * D.g[d];
+    R gm_extra = R(0);
+    const bool gridc = D.collision_type == CONTACT_GRID && D.any_contact;
+    R v0[3] = {v[0], v[1], v[2]};
+    if (gridc) {                                    // forward chain again: the boundary acts on the post-contact velocity
+        const R pos[3] = {R(i) * D.dx, R(j) * D.dx, R(k) * D.dx};
+        R dummy[6];
+        for (int q = 0; q < D.P; ++q) {
+            if (!D.prim[q].contact) continue;
+            const R* ps = D.prim_state + ((size_t)q * D.max_frames + D.cur_frame) * 13;
+            R s13[13];
+            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            collide_grid(D.prim[q], s13, pos, v, m, D.dt, dummy);
+        }
+    }
     const int mask = boundary(D, i, j, k, v);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (mask & (1 << d)) g[d] = R(0);
+    if (gridc) {                                    // adjoint of the chain, last primitive first (17 forward-mode directions)
+        const R pos[3] = {R(i) * D.dx, R(j) * D.dx, R(k) * D.dx};
+#pragma unroll 1
+        for (int q = D.P - 1; q >= 0; --q) {
+            if (!D.prim[q].contact) continue;
+            const R* ps = D.prim_state + ((size_t)q * D.max_frames + D.cur_frame) * 13;
+            R s13[13], vq[3] = {v0[0], v0[1], v0[2]}, dummy[6];
+            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            for (int r = 0; r < q; ++r) {           // velocity entering primitive q
+                if (!D.prim[r].contact) continue;
+                const R* pr = D.prim_state + ((size_t)r * D.max_frames + D.cur_frame) * 13;
+                R sr[13];
+                for (int c = 0; c < 13; ++c) sr[c] = pr[c];
+                collide_grid(D.prim[r], sr, pos, vq, m, D.dt, dummy);
+            }
+            R probe[3] = {vq[0], vq[1], vq[2]};
+            if (!collide_grid(D.prim[q], s13, pos, probe, m, D.dt, dummy)) continue;       // identity for this node
+            R out[17];
+            for (int dir = 0; dir < 17; ++dir) {
+                Dual<R> vs[3], ss[13], es[6];
+                for (int c = 0; c < 3; ++c) vs[c] = Dual<R>(vq[c], dir == c ? R(1) : R(0));
+                for (int c = 0; c < 13; ++c) ss[c] = Dual<R>(s13[c], dir == 4 + c ? R(1) : R(0));
+                collide_grid(D.prim[q], ss, pos, vs, Dual<R>(m, dir == 3 ? R(1) : R(0)), D.dt, es);
+                R acc = R(0);
+                for (int c = 0; c < 3; ++c) acc += g[c] * vs[c].d;
+                for (int c = 0; c < 6; ++c) acc += D.ext_f_grad[q * 6 + c] * es[c].d;
+                out[dir] = acc;
+            }
+            g[0] = out[0]; g[1] = out[1]; g[2] = out[2];
+            gm_extra += out[3];
+            for (int c = 0; c < 13; ++c) atomic_add(D.prim_grad + ((size_t)q * D.max_frames + D.cur_frame) * 13 + c, out[4 + c]);
+        }
+    }
     R gm = R(0);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (mask & (1 << d)) g[d] = R(0);
-        gm -= vin[d] * g[d];
-    }
-    const Vec4<R> o = {gm * inv * inv, g[0] * inv, g[1] * inv, g[2] * inv};
+    for (int d = 0; d < 3; ++d) gm -= vin[d] * g[d];
+    const Vec4<R> o = {gm * inv * inv + gm_extra, g[0] * inv, g[1] * inv, g[2] * inv};
     D.ain[cell] = o;
 }
 
@@ -890,11 +1038,12 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
 // 128 VGPRs together, and at 1 wave/SIMD the kernel is latency-bound.  The SVD factors (kept for the
 // constitutive adjoint) are parked in LDS across the gather loop, and the loop is fenced per x-plane so
 // that at most 9 nodes of loads are in flight: 4 waves/SIMD instead of 1.
-constexpr int STASH = 34;   // U9 V9 e3 ep3 Et9 Jm1
-template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? 3 : 2; };   // waves/SIMD asked of the register allocator
+constexpr int STASH = 34;   // U9 V9 e3 ep3 Et9 Jm1 (+ C9 E9 in f32 mode; f64 reloads them to keep two workgroups per CU)
+template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SMAC_OCC_HEAVY : 2; };   // waves/SIMD asked of the register allocator
 template <class R, bool ACC_VCF>
 __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
-    __shared__ R stash[STASH * BLOCK];
+    constexpr bool STASH_CE = sizeof(R) == 4;
+    __shared__ R stash[(STASH + (STASH_CE ? 18 : 0)) * BLOCK];
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     gather_tile_load(D, D.ain, ch.block, gt);
@@ -903,11 +1052,16 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     const R* Sf = frame(D.S, f, D.Npad);
     const R* An = D.An;
     R* Af = frame(D.A, f, D.Npad);
-    R x[3], v[3], aff[9];
+    // every global load of the kernel is issued here, in one batch (one memory round trip instead of four);
+    // C, E and the SVD factors wait in LDS until the constitutive adjoint needs them
+    R x[3], v[3], aff[9], gFn[9];
     {
         R C[9], E[9], Et[9], En[9], stress[9];
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
+        load_vec(Sf, CX, 3, D.Npad, p, x);
+        load_vec(Sf, CV, 3, D.Npad, p, v);
+        load_vec(An, CF, 9, D.Npad, p, gFn);
         f_tmp(C, E, D.dt, Et);
         ConstState<R> cs;
         constitutive_fwd(D.mat, Et, En, stress, cs);
@@ -918,19 +1072,32 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
             stash[i * BLOCK + t] = cs.U[i];
             stash[(9 + i) * BLOCK + t] = cs.V[i];
             stash[(24 + i) * BLOCK + t] = Et[i];
+            if (STASH_CE) { stash[(34 + i) * BLOCK + t] = C[i]; stash[(43 + i) * BLOCK + t] = E[i]; }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) { stash[(18 + i) * BLOCK + t] = cs.e[i]; stash[(21 + i) * BLOCK + t] = cs.ep[i]; }
         stash[33 * BLOCK + t] = cs.Jm1;
     }
-    load_vec(Sf, CX, 3, D.Npad, p, x);
-    load_vec(Sf, CV, 3, D.Npad, p, v);
     R imp[3] = {R(0), R(0), R(0)};
     int ci = -1;
     if (D.n_control > 0) {
         ci = D.control_idx[D.orig_id[p]];
         if (ci >= 0)
             for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
+    }
+    if (D.collision_type == CONTACT_PARTICLE && D.any_contact) {      // the contact impulse is part of the scattered momentum
+        const int cm = (D.debug & 8) ? 0 : D.pmask[p];
+        if (cm) {
+#pragma unroll 1
+            for (int i = 0; i < D.P; ++i) {
+                if (!((cm >> i) & 1)) continue;
+                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                R s13[13], im[3], ex[6];
+                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+                if (collide_particle(D.prim[i], s13, x, v, D.dt, im, ex))
+                    for (int c = 0; c < 3; ++c) imp[c] += im[c];
+            }
+        }
     }
     R pv[3] = {D.p_mass * v[0] + imp[0], D.p_mass * v[1] + imp[1], D.p_mass * v[2] + imp[2]};
     Stencil<R> st;
@@ -1008,18 +1175,22 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         for (int i = 0; i < 3; ++i) { cs.e[i] = stash[(18 + i) * BLOCK + t]; cs.ep[i] = stash[(21 + i) * BLOCK + t]; }
         cs.Jm1 = stash[33 * BLOCK + t];
         cs.has_svd = true;
-        R G[9], gFn[9];
+        R G[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) G[i] = D.stress_scale * gaff[i];
-        load_vec(An, CF, 9, D.Npad, p, gFn);
         constitutive_bwd(D.mat, Et, cs, G, gFn, gEt);
     }
     // compute_F_tmp.grad: F_tmp = (I + dt C)(I + E)
     R gC[9], gE[9], Ft[9], A1[9];
-    load_vec(Sf, CF, 9, D.Npad, p, Ft);
-    load_vec(Sf, CC, 9, D.Npad, p, A1);
+    if (STASH_CE) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) A1[i] *= D.dt;
+        for (int i = 0; i < 9; ++i) { Ft[i] = stash[(43 + i) * BLOCK + t]; A1[i] = D.dt * stash[(34 + i) * BLOCK + t]; }
+    } else {
+        load_vec(Sf, CF, 9, D.Npad, p, Ft);
+        load_vec(Sf, CC, 9, D.Npad, p, A1);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A1[i] *= D.dt;
+    }
     Ft[0] += R(1); Ft[4] += R(1); Ft[8] += R(1);
     A1[0] += R(1); A1[4] += R(1); A1[8] += R(1);
     mmt(gEt, Ft, gC);          // gEt (I+E)^T

@@ -306,6 +306,72 @@ SMAC_HD bool collide_mixed_adjoint(const PrimTable<R>& T, const R* st13, const R
     return true;
 }
 
+// abs with the derivative of the taken branch
+template <class R> SMAC_HD R abs_(R a) { return a < R(0) ? -a : a; }
+template <class R> SMAC_HD Dual<R> abs_(Dual<R> a) { return a.v < R(0) ? -a : a; }
+
+// collide_particle, primitive_base.py:105-137 (collision_type 1, called from p2g :203-206).
+// Returns true when c = dist - 5e-3 < 0; imp3 = p_f * dt is the impulse added to the particle's momentum,
+// ext6 this particle's wrench contribution.
+template <class S, class R>
+SMAC_HD bool collide_particle(const PrimTable<R>& T, const S* st13, const S* p_pos, const S* p_v, R dt, S* imp3, S* ext6) {
+    S dist = prim_sdf(T, st13, p_pos);
+    S c = dist - R(5e-3);                                                   // :108-109
+    if (!(val(c) < R(0))) return false;
+    S D[3], r[3], cv[3], in[3];
+    prim_normal(T, st13, p_pos, D);
+    for (int i = 0; i < 3; ++i) r[i] = p_pos[i] - st13[i];
+    collider_v(st13, r, cv);
+    for (int i = 0; i < 3; ++i) in[i] = p_v[i] - cv[i];
+    S nc = dot3(in, D);
+    S t[3] = {in[0] - nc * D[0], in[1] - nc * D[1], in[2] - nc * D[2]};     // :118
+    S tn = sqrt_(dot3(t, t) + R(1e-8));                                     // :124
+    S an = abs_(nc);
+    S bf[3], bt[3];
+    for (int i = 0; i < 3; ++i) {
+        S f1 = -D[i] * c * R(50);                                           // :120-121
+        S f2 = -(t[i] / tn) * an * T.friction;                              // :126
+        imp3[i] = (f1 + f2) * dt;                                           // :128, 137
+        bf[i] = -(f1 + f2);                                                 // :129
+    }
+    cross3(r, bf, bt);
+    for (int i = 0; i < 3; ++i) { ext6[i] = bf[i]; ext6[3 + i] = bt[i]; }
+    return true;
+}
+
+// collide (grid contact), primitive_base.py:72-103 (collision_type 0, called from grid_op :290-294).
+// grid_pos is a node position (integer index * dx: carries no derivative), v_io the node velocity, grid_m its mass.
+template <class S, class R>
+SMAC_HD bool collide_grid(const PrimTable<R>& T, const S* st13, const R* grid_pos, S* v_io, S grid_m, R dt, S* ext6) {
+    S pos[3] = {S(grid_pos[0]), S(grid_pos[1]), S(grid_pos[2])};
+    S dist = prim_sdf(T, st13, pos);
+    S infl = minc(exp_(-dist * T.softness), R(1));                         // :75
+    if (!((T.softness > R(0) && val(infl) > R(0.1)) || val(dist) <= R(0))) return false;   // :76
+    S v_in[3] = {v_io[0], v_io[1], v_io[2]};
+    S D[3], r[3], cv[3], in[3];
+    prim_normal(T, st13, pos, D);
+    for (int i = 0; i < 3; ++i) r[i] = pos[i] - st13[i];
+    collider_v(st13, r, cv);
+    for (int i = 0; i < 3; ++i) in[i] = v_io[i] - cv[i];
+    S nc = dot3(in, D);
+    S ncm = minc(nc, R(0));                                                 // :86 ti.min(normal_component, 0)
+    S t[3] = {in[0] - ncm * D[0], in[1] - ncm * D[1], in[2] - ncm * D[2]};
+    S tt = dot3(t, t);
+    S tn = sqrt_(tt + R(1e-8));
+    S scale = maxc(tn + nc * T.friction, R(0)) / tn;                        // :89
+    R flag = (val(nc) < R(0) && std::sqrt(val(tt)) > R(1e-30)) ? R(1) : R(0);   // :90
+    S bf[3], bt[3];
+    for (int i = 0; i < 3; ++i) {
+        S t2 = (t[i] * scale) * flag + t[i] * (R(1) - flag);               // :91
+        S vo = cv[i] + in[i] * (R(1) - infl) + t2 * infl;                   // :92
+        bf[i] = grid_m * (v_in[i] - vo) * (R(1) / dt);                      // :95
+        v_io[i] = vo;
+    }
+    cross3(r, bf, bt);
+    for (int i = 0; i < 3; ++i) { ext6[i] = bf[i]; ext6[3 + i] = bt[i]; }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------
 // quadratic B-spline stencil, mpm_simulator.py:215-217
 // ------------------------------------------------------------------------------------------

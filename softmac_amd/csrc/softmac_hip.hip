@@ -241,7 +241,7 @@ template <class R> struct Sim final : ISim {
         D.open_x = (c.flags >> 1) & 3;                               // flags bits 1,2: neighbour slab at the low / high x end
         D.nb = c.n_grid / 4;
         nblocks = D.nb * D.nb * D.nb;
-        sort_interval = c.sort_interval > 0 ? c.sort_interval : 8;
+        sort_interval = c.sort_interval > 0 ? c.sort_interval : 16;
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_bin, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_bin_start, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
@@ -674,8 +674,6 @@ template <class R> struct Sim final : ISim {
     }
     int check_contact_supported() {
         if (D.P > 0 && any_contact()) {
-            REQUIRE(D.collision_type == CONTACT_MIXED,
-                    "rigid contact is implemented for collision_type 2 (forecast/mixed) only");
             for (int i = 0; i < D.P; ++i)
                 if (D.prim[i].contact) REQUIRE(D.prim[i].sdf != nullptr, "contact primitive without an uploaded SDF");
         }
@@ -695,14 +693,17 @@ template <class R> struct Sim final : ISim {
     int forward_grid(int f, bool store_F, bool is_recompute, int stage = 0) {
         int rc;
         if (D.nchunks == 0 || D.nactive == 0) return SMAC_OK;
-        D.any_contact = (D.collision_type == CONTACT_MIXED && any_contact()) ? 1 : 0;
+        D.any_contact = any_contact() ? 1 : 0;
+        D.cur_frame = f;
+        DevSim<R> Dc = D;                                       // the recompute pass must not double-count ext_f
+        if (is_recompute) Dc.ext_f = scratch_ext();
         if (stage != 2) {
             prof_begin(K_CLEAR);
             hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 3);
             prof_end();
             prof_begin(K_P2G);
-            if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
-            else hipLaunchKernelGGL((k_p2g<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+            if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, Dc, f);
+            else hipLaunchKernelGGL((k_p2g<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
             if (!is_recompute && cfg.rigid_velocity_control) {                    // :329-331
                 for (int i = 0; i < D.P; ++i)
@@ -710,12 +711,10 @@ template <class R> struct Sim final : ISim {
             }
         }
         prof_begin(K_GRID_OP);
-        hipLaunchKernelGGL(k_grid_op<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, stage);
+        hipLaunchKernelGGL(k_grid_op<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dc, stage);
         prof_end();
-        if (stage != 1 && D.any_contact) {
+        if (stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED) {
             prof_begin(K_CONTACT);
-            DevSim<R> Dc = D;
-            if (is_recompute) Dc.ext_f = scratch_ext();
             hipLaunchKernelGGL(k_contact<R>, dim3(contact_grid()), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
         }
@@ -814,10 +813,12 @@ template <class R> struct Sim final : ISim {
             D.An = An;
             if (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0) {
                 // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing
-                D.any_contact = (D.collision_type == CONTACT_MIXED && any_contact()) ? 1 : 0;
+                D.any_contact = any_contact() ? 1 : 0;
+                D.cur_frame = f;
                 prof_begin(K_CKPT);
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f));
-                if (D.any_contact) hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                if (D.any_contact && D.collision_type != CONTACT_GRID)
+                    hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
             } else {
                 REQUIRE(phase < 0, "slab-decomposed substep_grad needs the forward-grid checkpoint of this frame "
@@ -853,6 +854,11 @@ template <class R> struct Sim final : ISim {
                 if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :371-374
                 else hipLaunchKernelGGL((k_p2g_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
+                if (D.collision_type == CONTACT_PARTICLE && any_contact()) {      // adjoint of p2g's contact impulse (:203-206)
+                    prof_begin(K_CONTACT_GRAD);
+                    hipLaunchKernelGGL(k_particle_contact_grad<R>, dim3(256), dim3(BLOCK), 0, stream, D, f);
+                    prof_end();
+                }
             }
             if ((rc = check_launch())) return rc;
             if (action_grad_out && D.n_control > 0) {                             // :378

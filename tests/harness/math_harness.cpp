@@ -1,5 +1,6 @@
 // Test-only host build of softmac_amd/csrc/smac_math.hpp (g++).  Lets pytest compare the
 // per-particle device arithmetic with the torch oracle on the CPU.  Never linked into the product.
+#include <vector>
 #include "../../softmac_amd/csrc/smac_math.hpp"
 
 using namespace smac;
@@ -65,6 +66,47 @@ static void collide_run(int n, const double* sdf, const double* normal, const in
     delete[] tn;
 }
 
+// collide_particle / collide (grid) forward + forward-mode adjoints, one particle / node per entry
+template <class R>
+static void collide_other_run(int kind, int n, const double* sdf, const double* normal, const int* res, const double* lower,
+                              const double* upper, double sdf_dx, double friction, double softness, const double* st13,
+                              const double* pos, const double* vel, const double* mass, double dt, const double* g_out,
+                              const double* g_ext, double* out3, double* out_ext, int* active, double* g_in /* n x 20 */) {
+    long cells = (long)res[0] * res[1] * res[2];
+    std::vector<R> ts(cells), tn(cells * 3);
+    for (long i = 0; i < cells; ++i) ts[i] = (R)sdf[i];
+    for (long i = 0; i < cells * 3; ++i) tn[i] = (R)normal[i];
+    PrimTable<R> T;
+    T.sdf = ts.data(); T.normal = tn.data();
+    for (int i = 0; i < 3; ++i) { T.res[i] = res[i]; T.lower[i] = (R)lower[i]; T.upper[i] = (R)upper[i]; }
+    T.inv_dx = (R)(1.0 / sdf_dx); T.friction = (R)friction; T.softness = (R)softness; T.contact = 1;
+    for (int p = 0; p < n; ++p) {
+        R st[13], x[3], v[3], o[3] = {0, 0, 0}, ext[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 13; ++i) st[i] = (R)st13[i];
+        for (int i = 0; i < 3; ++i) { x[i] = (R)pos[3 * p + i]; v[i] = (R)vel[3 * p + i]; }
+        bool act;
+        if (kind == 1) act = collide_particle(T, st, x, v, (R)dt, o, ext);
+        else { for (int i = 0; i < 3; ++i) o[i] = v[i]; act = collide_grid(T, st, x, o, (R)mass[p], (R)dt, ext); }
+        active[p] = act;
+        for (int i = 0; i < 3; ++i) out3[3 * p + i] = o[i];
+        for (int i = 0; i < 6; ++i) out_ext[6 * p + i] = ext[i];
+        // directions: 0-2 pos (particle contact only), 3-5 v, 6 mass (grid contact only), 7-19 state
+        for (int dir = 0; dir < 20; ++dir) {
+            double acc = 0;
+            if (act) {
+                Dual<R> xs[3], vs[3], ss[13], os[3], es[6];
+                for (int i = 0; i < 3; ++i) { xs[i] = Dual<R>(x[i], (kind == 1 && dir == i) ? R(1) : R(0)); vs[i] = Dual<R>(v[i], dir == 3 + i ? R(1) : R(0)); }
+                for (int i = 0; i < 13; ++i) ss[i] = Dual<R>(st[i], dir == 7 + i ? R(1) : R(0));
+                if (kind == 1) collide_particle(T, ss, xs, vs, (R)dt, os, es);
+                else { for (int i = 0; i < 3; ++i) os[i] = vs[i]; collide_grid(T, ss, x, os, Dual<R>((R)mass[p], dir == 6 ? R(1) : R(0)), (R)dt, es); }
+                for (int i = 0; i < 3; ++i) acc += g_out[3 * p + i] * os[i].d;
+                for (int i = 0; i < 6; ++i) acc += g_ext[i] * es[i].d;
+            } else if (kind == 0 && dir >= 3 && dir < 6) acc = g_out[3 * p + dir - 3];
+            g_in[20 * p + dir] = acc;
+        }
+    }
+}
+
 template <class R> static void fk_run(const double* s13, double dt, double* out7) {
     R s[13], o[7];
     for (int i = 0; i < 13; ++i) s[i] = (R)s13[i];
@@ -92,6 +134,13 @@ void h_collide_mixed(int prec, int n, const double* sdf, const double* normal, c
     else
         collide_run<float>(n, sdf, normal, res, lower, upper, sdf_dx, friction, softness, st13, pos, vel, p_mass, dt,
                            life, g_v, g_ext, out_v, out_ext, active, g_pos, g_vin, g_state);
+}
+void h_collide_other(int prec, int kind, int n, const double* sdf, const double* normal, const int* res, const double* lower,
+                     const double* upper, double sdf_dx, double friction, double softness, const double* st13, const double* pos,
+                     const double* vel, const double* mass, double dt, const double* g_out, const double* g_ext, double* out3,
+                     double* out_ext, int* active, double* g_in) {
+    if (prec == 64) collide_other_run<double>(kind, n, sdf, normal, res, lower, upper, sdf_dx, friction, softness, st13, pos, vel, mass, dt, g_out, g_ext, out3, out_ext, active, g_in);
+    else collide_other_run<float>(kind, n, sdf, normal, res, lower, upper, sdf_dx, friction, softness, st13, pos, vel, mass, dt, g_out, g_ext, out3, out_ext, active, g_in);
 }
 void h_forward_kinematics(int prec, const double* s13, double dt, double* out7) {
     if (prec == 64) fk_run<double>(s13, dt, out7); else fk_run<float>(s13, dt, out7);

@@ -114,3 +114,50 @@ def test_forward_kinematics(lib, prec, tol):
     t = lambda a: torch.tensor(a, dtype=O.DT)
     p, r = O.forward_kinematics(t(s13[:3]), t(s13[3:7]), t(s13[7:10]), t(s13[10:]), 2e-4)
     assert np.abs(out7[:3] - p.numpy()).max() < tol and np.abs(out7[3:] - r.numpy()).max() < tol
+
+
+@pytest.mark.parametrize("prec,tol", [(64, 1e-10), (32, 2e-3)])
+@pytest.mark.parametrize("kind", [1, 0])
+def test_collide_particle_and_grid(lib, prec, tol, kind):
+    """collision_type 1 (penalty impulse in p2g) and 0 (grid-node projection in grid_op) vs the oracle, with adjoints."""
+    d = H.load_palm()
+    rng = np.random.default_rng(4 + kind)
+    n = 1200
+    he = np.array([0.3, 0.15, 0.075])
+    loc = rng.uniform(-1, 1, (n, 3)) * he
+    ax = rng.integers(0, 3, n); sgn = rng.choice([-1, 1], n)
+    loc[np.arange(n), ax] = sgn * (he[ax] + rng.uniform(-0.004, 0.008, n))
+    q = np.array([0.9, 0.1, -0.3, 0.2]); q /= np.linalg.norm(q)
+    pos0 = np.array([0.5, 0.4, 0.5])
+    st13 = np.concatenate([pos0, q, [0.1, -0.2, 0.05], [0.3, 0.2, -0.4]])
+    world = O.qrot(torch.tensor(q), torch.tensor(loc)).numpy() + pos0
+    vel = 0.5 * rng.standard_normal((n, 3)); mass = rng.uniform(1e-5, 1e-4, n)
+    g_out = rng.standard_normal((n, 3)); g_ext = rng.standard_normal(6)
+    dt = 2e-4
+    prim = O.make_prim(st13[:3], st13[3:7], st13[7:10], st13[10:], d["sdf"], d["normal"], d["lower"], d["upper"], d["dx"], friction=0.3)
+    x = torch.tensor(world, requires_grad=True); v = torch.tensor(vel, requires_grad=True); m = torch.tensor(mass, requires_grad=True)
+    leaves = [t.requires_grad_(True) for t in (prim.position, prim.rotation, prim.v, prim.w)]
+    if kind == 1:
+        out, ext = O.collide_particle(prim, x, v, dt)
+    else:
+        out, ext = O.collide_grid(prim, x.detach(), v, dt, m)
+    L = (out * torch.tensor(g_out)).sum() + (ext * torch.tensor(g_ext)).sum()
+    ins = ([x] if kind == 1 else []) + [v] + ([m] if kind == 0 else []) + leaves
+    gr = torch.autograd.grad(L, ins, allow_unused=True)
+    gr = [torch.zeros_like(i) if g is None else g for g, i in zip(gr, ins)]
+    out3, out_ext = np.zeros((n, 3)), np.zeros((n, 6))
+    act = np.zeros(n, dtype=np.int32); g_in = np.zeros((n, 20))
+    res = np.asarray(d["res"], dtype=np.int32)
+    lib.h_collide_other(prec, kind, n, P(np.ascontiguousarray(d["sdf"])), P(np.ascontiguousarray(d["normal"])), res.ctypes.data_as(ip),
+                        P(d["lower"]), P(d["upper"]), ctypes.c_double(d["dx"]), ctypes.c_double(0.3), ctypes.c_double(666.0), P(st13),
+                        P(world), P(vel), P(mass), ctypes.c_double(dt), P(g_out), P(g_ext), P(out3), P(out_ext), act.ctypes.data_as(ip), P(g_in))
+    assert act.sum() > 300
+    assert H.rel_err(out3, out.detach().numpy()) < tol
+    assert H.rel_err(out_ext.sum(0), ext.detach().numpy()) < tol
+    k = 0
+    if kind == 1:
+        assert H.rel_err(g_in[:, 0:3], gr[k].numpy()) < tol; k += 1
+    assert H.rel_err(g_in[:, 3:6], gr[k].numpy()) < tol; k += 1
+    if kind == 0:
+        assert H.rel_err(g_in[:, 6], gr[k].numpy()) < tol; k += 1
+    assert H.rel_err(g_in[:, 7:20].sum(0), torch.cat(gr[k:]).numpy()) < tol

@@ -242,3 +242,22 @@ def test_against_committed_golden_vectors(name, precision):
         for f in range(n):
             for i, m in enumerate(prims):
                 assert H.rel_err(m.get_all_states_grad(f), ref["prim_grad"][f, i]) < tg * 10
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+@pytest.mark.parametrize("collision_type", [1, 0])
+def test_particle_and_grid_contact_models(precision, collision_type):
+    """collide_particle (penalty impulse inside p2g, type 1) and collide (grid-node projection inside
+    grid_op, type 0) with their adjoints, on the grip fixture pressed by the palm."""
+    d = np.load(H.GOLDEN / "grip_state_2k.npz")
+    state = d["state"]
+    specs, pstates = _palm_scene(state, 4)
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, material_model=0, ground_friction=20.0, precision=precision,
+                    collision_type=collision_type)
+    rng = np.random.default_rng(6)
+    eg = [rng.standard_normal(6) * 1e-2]
+    tol = None if precision == "float64" else dict(state=5e-4, grad=5e-3)
+    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg, tol=tol)
+    # the recompute path (no grid checkpoint) must give the same adjoints
+    cfg2 = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, precision=precision, collision_type=collision_type, recompute_backward=True)
+    _compare_rollout(cfg2, 1e-3, state, 2, specs, pstates, ext_f_grad=eg, tol=tol)

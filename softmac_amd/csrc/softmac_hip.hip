@@ -711,7 +711,10 @@ template <class R> struct Sim final : ISim {
             }
         }
         prof_begin(K_GRID_OP);
-        hipLaunchKernelGGL(k_grid_op<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dc, stage);
+        if (D.collision_type == CONTACT_GRID && D.any_contact)
+            hipLaunchKernelGGL((k_grid_op<R, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dc, stage);
+        else
+            hipLaunchKernelGGL((k_grid_op<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dc, stage);
         prof_end();
         if (stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED) {
             prof_begin(K_CONTACT);
@@ -843,7 +846,10 @@ template <class R> struct Sim final : ISim {
         if (phase < 0 || phase == 2) {
             if (D.nchunks > 0) {
                 prof_begin(K_GRID_OP_GRAD);
-                hipLaunchKernelGGL(k_grid_op_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);   // :394 / :365
+                if (D.collision_type == CONTACT_GRID && any_contact())
+                    hipLaunchKernelGGL((k_grid_op_grad<R, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);   // :394 / :365
+                else
+                    hipLaunchKernelGGL((k_grid_op_grad<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
             }
             if (cfg.rigid_velocity_control)                                       // :367-369

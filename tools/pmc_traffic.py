@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes as
+MI355X_MICROARCH.md prescribes) -> profiles/traffic_latest.json (read by bench.py for roofline.traffic).
+
+gfx950 correction (same guide): FETCH_SIZE tallies 128-B read requests at 64 B, i.e. reports 1/2 of the bytes of a
+coalesced stream.  Calibrated on this code: k_grid_save moves the same bytes in and out (16 B/lane): WRITE_SIZE =
+13.87 MB, FETCH_SIZE = 7.02 MB = 0.506x; the SoA particle kernels (4 B/lane, 256 B per wave instruction) read
+0.56-0.58x of their known byte counts.  So bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+import collections
+import csv
+import json
+import sys
+
+NAMES = {"k_p2g<float, true>": "p2g", "k_p2g_grad<float, false>": "p2g_grad", "k_g2p<float>": "g2p", "k_g2p_grad<float, false>": "g2p_grad",
+         "k_grid_op<float, false>": "grid_op", "k_grid_op_grad<float, false>": "grid_op_grad", "k_clear_active<float>": "clear_grid",
+         "k_contact<float>": "contact", "k_contact_grad<float>": "contact_grad", "k_reduce_aout<float>": "reduce_agvout",
+         "k_grid_save<float>": "grid_checkpoint"}
+
+
+def mean_by_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].split("(")[0].replace("void smac::", "")].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch = mean_by_kernel(sys.argv[1], "FETCH_SIZE")
+write = mean_by_kernel(sys.argv[2], "WRITE_SIZE")
+out, rows = {}, []
+for k, short in NAMES.items():
+    if k in fetch and k in write:
+        b = (2 * fetch[k] + write[k]) * 1024
+        out[short] = b
+        rows.append((short, fetch[k], write[k], b))
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print("kernel,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_per_launch(2F+W)")
+for r in rows:
+    print("%s,%.1f,%.1f,%.0f" % r)

@@ -27,8 +27,13 @@
 
 namespace smac {
 
+// A/B on MI355X (tools/ab.sh): k_g2p_grad is fastest at 2 waves/SIMD without spills; k_p2g_grad at 3 with the small
+// LDS stash (3 workgroups per CU); forcing more occupancy only buys scratch traffic.
 #ifndef SMAC_OCC_HEAVY
-#define SMAC_OCC_HEAVY 2      // A/B on MI355X: 2 waves/SIMD without spills beats 3-4 with scratch traffic
+#define SMAC_OCC_HEAVY 2
+#endif
+#ifndef SMAC_OCC_P2GG
+#define SMAC_OCC_P2GG 3
 #endif
 #ifndef SMAC_OCC_G2P
 #define SMAC_OCC_G2P 4
@@ -184,11 +189,22 @@ template <class R> __device__ __forceinline__ void f_tmp(const R* C, const R* E,
     const int t = threadIdx.x;                                \
     const bool valid = t < ch.count;                          \
     const int p = ch.start + (valid ? t : 0);
-#define SMAC_CHUNK_PROLOGUE SMAC_CHUNK_PROLOGUE_AT(blockIdx.x)
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the XCD group).  Chunks are listed in block
+// order, so giving XCD g the contiguous range [g*n/8, (g+1)*n/8) keeps spatially adjacent chunks - which re-read the
+// same grid records and slabs - behind ONE L2 instead of spreading every grid line over all eight.  Speed only.
+__device__ __forceinline__ int xcd_chunk(int nchunks) {
+    const int per = (nchunks + 7) >> 3;
+    const int c = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    return c;
+}
+#define SMAC_CHUNK_PROLOGUE                                   \
+    const int cid = xcd_chunk(D.nchunks);                     \
+    if (cid >= D.nchunks) return;                             \
+    SMAC_CHUNK_PROLOGUE_AT(cid)
 
 // store this chunk's f64 LDS tile (NS scalars, tile[s][word]) to its slab as 16-byte records, coalesced
 template <class R, int NS> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const tile_t* tile) {
-    Vec4<R>* dst = D.slab + (size_t)blockIdx.x * TILE_WORDS;
+    Vec4<R>* dst = D.slab + (size_t)xcd_chunk(D.nchunks) * TILE_WORDS;
     for (int i = threadIdx.x; i < TILE_WORDS; i += BLOCK) {
         Vec4<R> v;
         v.x = (R)tile[i]; v.y = (R)tile[TILE_WORDS + i]; v.z = (R)tile[2 * TILE_WORDS + i];
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
         if (valid) D.pmask[p] = cmask;
     } else if (any) {
         if (valid) D.pmask[p] = cmask;
-        if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = blockIdx.x;
+        if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = cid;
     }
 }
 
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         const int any = __syncthreads_or(cmask);
         if (any) {
             if (valid) D.pmask[p] = cmask;
-            if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = blockIdx.x;
+            if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = cid;
         }
     } else {
         if (D.any_contact && D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;   // read back by p2g.grad
@@ -1084,10 +1100,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
 // constitutive adjoint) are parked in LDS across the gather loop, and the loop is fenced per x-plane so
 // that at most 9 nodes of loads are in flight: 4 waves/SIMD instead of 1.
 constexpr int STASH = 34;   // U9 V9 e3 ep3 Et9 Jm1 (+ C9 E9 in f32 mode; f64 reloads them to keep two workgroups per CU)
-template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SMAC_OCC_HEAVY : 2; };   // waves/SIMD asked of the register allocator
+template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SMAC_OCC_P2GG : 2; };   // waves/SIMD asked of the register allocator
 template <class R, bool ACC_VCF>
 __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
-    constexpr bool STASH_CE = sizeof(R) == 4;
+    constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
     __shared__ R stash[(STASH + (STASH_CE ? 18 : 0)) * BLOCK];
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE

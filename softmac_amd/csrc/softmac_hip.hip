@@ -686,6 +686,7 @@ template <class R> struct Sim final : ISim {
         return scratch;
     }
     int ngrid_blocks() const { return (D.nactive + 3) / 4; }
+    int nchunk_blocks() const { return ((D.nchunks + 7) / 8) * 8; }   // XCD-aware chunk mapping (xcd_chunk) needs a multiple of 8
     int contact_grid() const { return D.nchunks < 512 ? D.nchunks : 512; }    // fixed grid walking the candidate-chunk list
     // Forward grid passes.  stage 0: everything; stage 1: clear_grid :93-114 on the active blocks, p2g, (forward
     // kinematics), slab reduction; stage 2: grid_op + contact.  Stages 1/2 exist for the slab decomposition, which
@@ -702,8 +703,8 @@ template <class R> struct Sim final : ISim {
             hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 3);
             prof_end();
             prof_begin(K_P2G);
-            if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, Dc, f);
-            else hipLaunchKernelGGL((k_p2g<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, Dc, f);
+            if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+            else hipLaunchKernelGGL((k_p2g<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
             if (!is_recompute && cfg.rigid_velocity_control) {                    // :329-331
                 for (int i = 0; i < D.P; ++i)
@@ -773,7 +774,7 @@ template <class R> struct Sim final : ISim {
             }
             if (D.nchunks > 0) {
                 prof_begin(K_G2P);
-                hipLaunchKernelGGL(k_g2p<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                hipLaunchKernelGGL(k_g2p<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
             }
             frame_epoch[f + 1] = e;
@@ -821,7 +822,7 @@ template <class R> struct Sim final : ISim {
                 prof_begin(K_CKPT);
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f));
                 if (D.any_contact && D.collision_type != CONTACT_GRID)
-                    hipLaunchKernelGGL(k_contact_mask<R>, dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                    hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
             } else {
                 REQUIRE(phase < 0, "slab-decomposed substep_grad needs the forward-grid checkpoint of this frame "
@@ -830,8 +831,8 @@ template <class R> struct Sim final : ISim {
             }
             if (D.nchunks > 0) {
                 prof_begin(K_G2P_GRAD);
-                if (pending_adj_zero) hipLaunchKernelGGL((k_g2p_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :361
-                else hipLaunchKernelGGL((k_g2p_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                if (pending_adj_zero) hipLaunchKernelGGL((k_g2p_grad<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);   // :361
+                else hipLaunchKernelGGL((k_g2p_grad<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
                 prof_begin(K_REDUCE);
                 hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
@@ -857,8 +858,8 @@ template <class R> struct Sim final : ISim {
                     if ((rc = prim_fk_grad(i, f))) return rc;
             if (D.nchunks > 0) {
                 prof_begin(K_P2G_GRAD);
-                if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);   // :371-374
-                else hipLaunchKernelGGL((k_p2g_grad<R, true>), dim3(D.nchunks), dim3(BLOCK), 0, stream, D, f);
+                if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);   // :371-374
+                else hipLaunchKernelGGL((k_p2g_grad<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
                 if (D.collision_type == CONTACT_PARTICLE && any_contact()) {      // adjoint of p2g's contact impulse (:203-206)
                     prof_begin(K_CONTACT_GRAD);

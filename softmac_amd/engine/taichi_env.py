@@ -1,0 +1,122 @@
+"""TaichiEnv - scene assembly and env-step orchestration with the reference's surface
+(/root/reference/softmac/engine/taichi_env.py:15-162), over the HIP engine.  No Taichi is involved; the name is
+kept so the demos' `from ...taichi_env import TaichiEnv` keeps working.
+
+Built this round: velocity-controlled rigid bodies (`cfg.rigid_velocity_control = True`, reference
+rigid_simulator_vel.py) - a complete Jade-free differentiable rollout.  The force-controlled path needs
+nimblephysics ("Jade", closed third-party, absent) and raises.  The renderer is a stub."""
+import numpy as np
+import torch
+
+from .mpm_simulator import MPMSimulator
+from .primitive import Primitives
+from .shapes import Shapes
+
+
+class _NullRenderer:
+    def initialize(self): pass
+    def reset(self): pass
+    def set_particles(self, x, colors): pass
+    def set_primitives(self, f): pass
+    def render(self): return None
+
+
+class TaichiEnv:
+    def __init__(self, cfg, primitives=None, loss=None):
+        """cfg: CfgNode as produced by softmac_amd.config.load.  `primitives` lets tests / synthetic scenes pass a
+        ready Primitives container instead of URDF-driven construction."""
+        self.cfg = cfg.ENV
+        cfg.defrost()
+        self.env_dt = cfg.env_dt
+        self.control_mode = cfg.control_mode
+        assert self.control_mode in ("mpm", "rigid")
+        self.rigid_velocity_control = cfg.rigid_velocity_control
+
+        self.primitives = primitives if primitives is not None else Primitives(
+            cfg.PRIMITIVES, max_timesteps=cfg.SIMULATOR.max_steps, rigid_velocity_control=self.rigid_velocity_control)
+        self.shapes = Shapes(cfg.SHAPES)
+        self.init_particles, self.particle_colors = self.shapes.get()
+        self.n_particles = cfg.SIMULATOR.n_particles = len(self.init_particles)
+
+        self.simulator = MPMSimulator(cfg.SIMULATOR, self.primitives, self.env_dt,
+                                      rigid_velocity_control=self.rigid_velocity_control)
+        self.substeps = self.simulator.substeps
+        if self.rigid_velocity_control:
+            from .rigid_simulator_vel import RigidSimulatorVelocityControl
+            self.rigid_simulator = RigidSimulatorVelocityControl(cfg.RIGID, self.primitives, self.substeps, self.env_dt)
+        else:
+            raise NotImplementedError("force-controlled rigid bodies need nimblephysics (Jade), which is not available; "
+                                      "use cfg.rigid_velocity_control = True")
+        self.renderer = _NullRenderer()
+        self.use_loss = loss is not None
+        self.loss = loss
+        self._is_copy = False
+        self.initialize()
+
+    def set_copy(self, is_copy: bool):
+        self._is_copy = is_copy
+
+    def initialize(self):                                        # :64-73
+        self.primitives.initialize()
+        self.simulator.initialize()
+        self.rigid_simulator.initialize()
+        self.renderer.initialize()
+        if self.loss:
+            self.loss.initialize()
+        self.reset()
+
+    def reset(self):                                             # :75-82
+        self.primitives.reset()
+        self.simulator.reset(self.init_particles)
+        self.rigid_simulator.reset()
+        self.renderer.reset()
+        if self.loss:
+            self.loss.reset()
+        self.action_list = []
+
+    def render(self, f=None):
+        return self.renderer.render()
+
+    def step(self, action=None):                                 # :93-115
+        start = 0 if self._is_copy else self.simulator.cur
+        self.simulator.cur = start + self.substeps
+        mpm_action = action if self.control_mode == "mpm" else None
+        rigid_action = action if self.control_mode == "rigid" else None
+        self.action_list.append(action)
+        if mpm_action is None:
+            self.simulator.run_substeps(start, self.substeps)    # one FFI call for the env step's substeps
+        else:
+            for s in range(start, self.simulator.cur):
+                self.simulator.substep(s, mpm_action)
+        self.rigid_simulator.step(start // self.substeps, rigid_action)
+        if self._is_copy:
+            self.simulator.copyframe(self.simulator.cur, 0)
+            self.simulator.cur = 0
+
+    def step_grad(self, action=None):                            # :117-137
+        start = self.simulator.cur
+        self.simulator.cur = start - self.substeps
+        mpm_action = action if self.control_mode == "mpm" else None
+        rigid_action = action if self.control_mode == "rigid" else None
+        rigid_action_grad, ext_f_grad_list = self.rigid_simulator.step_grad(self.simulator.cur // self.substeps, rigid_action)
+        mpm_action_grad = np.zeros(np.asarray(action).shape)
+        for s in range(start - 1, self.simulator.cur - 1, -1):
+            tmp = self.simulator.substep_grad(s, action=mpm_action, ext_f_grad=ext_f_grad_list)
+            if tmp is not None:
+                mpm_action_grad += tmp
+        if action is None:
+            return None
+        return torch.tensor(mpm_action_grad) if self.control_mode == "mpm" else rigid_action_grad
+
+    def backward(self):                                          # :139-151
+        total_steps = self.simulator.cur // self.substeps
+        action_grad = []
+        for s in range(total_steps - 1, -1, -1):
+            action_grad = [self.step_grad(self.action_list[s])] + action_grad
+        return torch.vstack(action_grad)
+
+    def compute_loss(self, f=None, **kwargs):
+        assert self.loss is not None
+        if f is None:
+            f = 0 if self._is_copy else self.simulator.cur
+        return self.loss.compute_loss(f, **kwargs)

@@ -32,6 +32,9 @@ namespace smac {
 #ifndef SMAC_OCC_HEAVY
 #define SMAC_OCC_HEAVY 2
 #endif
+#ifndef SMAC_OCC_G2PG
+#define SMAC_OCC_G2PG 4
+#endif
 #ifndef SMAC_OCC_P2GG
 #define SMAC_OCC_P2GG 3
 #endif
@@ -699,7 +702,7 @@ template <class R> struct WGrad {
 };
 
 template <class R, bool ACC_X>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_HEAVY : 2)) void k_g2p_grad(DevSim<R> D, int f) {
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k_g2p_grad(DevSim<R> D, int f) {
     __shared__ tile_t tile[3 * TILE_WORDS];
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
@@ -736,20 +739,26 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_HEAVY : 2)) void 
 #pragma unroll
             for (int c = 0; c < 3; ++c) T0[c] = gnv[c] - (gC1[3 * c] * st.fx[0] + gC1[3 * c + 1] * st.fx[1] + gC1[3 * c + 2] * st.fx[2]);
             R M0[3] = {R(0), R(0), R(0)};
-#pragma unroll
+            R gwx[3] = {R(0), R(0), R(0)};
+            const int tbase = nd.tx[0] + nd.ty[0] + nd.tz[0];
+            // one x-plane (9 nodes) per trip: rolled, so only 9 gathered records are live at a time
+#pragma unroll 1
             for (int i = 0; i < 3; ++i) {
-                R ti[3] = {T0[0] + R(i) * gC1[0], T0[1] + R(i) * gC1[3], T0[2] + R(i) * gC1[6]};
+                const R fi = (R)i;
+                const R wxi = i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0]);
+                const int ti0 = tbase + i * TSX;
+                R ti[3] = {T0[0] + fi * gC1[0], T0[1] + fi * gC1[3], T0[2] + fi * gC1[6]};
                 R s0[3] = {R(0), R(0), R(0)};
                 R gxi = R(0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const R wij = st.w[i][0] * st.w[j][1];
+                    const R wij = wxi * st.w[j][1];
                     R tj[3] = {ti[0] + R(j) * gC1[1], ti[1] + R(j) * gC1[4], ti[2] + R(j) * gC1[7]};
                     R aq = R(0);                    // sum_k Q wz_k
                     R r0[3] = {R(0), R(0), R(0)};   // sum_k wz_k g
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const int tw = nd.tile(i, j, k);
+                        const int tw = ti0 + j * TSY + k;
                         const Vec4<R> g = gt[tw];
                         const R tk[3] = {tj[0] + R(k) * gC1[2], tj[1] + R(k) * gC1[5], tj[2] + R(k) * gC1[8]};
                         const R w = wij * st.w[k][2];
@@ -761,14 +770,16 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_HEAVY : 2)) void 
                         r0[0] += st.w[k][2] * g.x; r0[1] += st.w[k][2] * g.y; r0[2] += st.w[k][2] * g.z;
                     }
                     gxi += aq * st.w[j][1];
-                    wg.g[j][1] += aq * st.w[i][0];
+                    wg.g[j][1] += aq * wxi;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) s0[c] += st.w[j][1] * r0[c];
                 }
-                wg.g[i][0] += gxi;
+                gwx[0] += i == 0 ? gxi : R(0); gwx[1] += i == 1 ? gxi : R(0); gwx[2] += i == 2 ? gxi : R(0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) M0[c] += st.w[i][0] * s0[c];
+                for (int c = 0; c < 3; ++c) M0[c] += wxi * s0[c];
             }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) wg.g[a][0] += gwx[a];
 #pragma unroll
             for (int d = 0; d < 3; ++d) gfx[d] -= gC1[d] * M0[0] + gC1[3 + d] * M0[1] + gC1[6 + d] * M0[2];   // dpos = offset - fx
         } else {

@@ -5,7 +5,9 @@
 //            -> one block = 64 consecutive scalars = one 256-B wave access per field
 //   sort   : counting sort with key = block*KMAX + min(rank_in_cell, KMAX-1).  All particles of one
 //            bin live in DIFFERENT cells, so the 64 lanes of a wave scatter to (mostly) distinct
-//            nodes: LDS / global float atomics do not serialise on one address.
+//            nodes: LDS / global float atomics do not serialise on one address.  Inside a bin the
+//            particles are ordered by cell, so neighbouring lanes hit neighbouring tile words
+//            (measured: 17 instead of 23.5 LDS cycles per 64-lane f64 atomic, tools/microbench/lds_tile.hip).
 //   chunks : each non-empty block is cut into work items of <= 4 waves (256 particles);
 //            one workgroup per chunk, one LDS tile per workgroup.
 //   active : blocks within [-1,+2]^3 of a block that holds particle bases - every cell a particle can
@@ -28,10 +30,10 @@ __host__ __device__ __forceinline__ size_t cell_of(int nb, int i, int j, int k) 
     return (size_t)block_of(nb, i, j, k) * 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
 }
 
-// pass 1: rank of each particle inside its cell, key, slot inside its (block, rank) bin
+// pass 1: rank of each particle inside its cell; key; (rank, local cell) packed for pass 2
 template <class R>
 __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, int N, int n, int nb, R inv_dx, int* cell_count,
-                            int* bin_count, int* key_out, int* slot_out) {
+                            int* key_out, int* slot_out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     const R x[3] = {x0[p], x1[p], x2[p]};
@@ -42,17 +44,46 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, int N, int n,
     }
     const size_t cell = cell_of(nb, b[0], b[1], b[2]);
     const int r = atomicAdd(cell_count + cell, 1);
-    const int key = (int)(cell >> 6) * KMAX + (r < KMAX - 1 ? r : KMAX - 1);
-    key_out[p] = key;
-    slot_out[p] = atomicAdd(bin_count + key, 1);
+    key_out[p] = (int)(cell >> 6) * KMAX + (r < KMAX - 1 ? r : KMAX - 1);
+    slot_out[p] = (r << 6) | (int)(cell & 63);
+}
+
+// pass 1b, one wave per block: bin sizes and, per bin, the set of cells that own a particle of that rank
+// (bit c of mask[block*KMAX + r] <=> cell c holds more than r particles).  A particle's slot inside its bin is
+// the number of lower cells in the mask; the overflow bin (rank >= KMAX-1) uses a prefix sum of the excess counts.
+__global__ void k_bin_masks(int nblocks, const int* cell_count, int* bin_count, unsigned long long* mask, int* over_prefix) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= nblocks) return;
+    const int lane = threadIdx.x & 63;
+    const int c = cell_count[(size_t)b * 64 + lane];
+    if (__ballot(c > 0) == 0ull) {
+        if (lane < KMAX) bin_count[b * KMAX + lane] = 0;
+        return;
+    }
+    for (int r = 0; r < KMAX - 1; ++r) {
+        const unsigned long long m = __ballot(c > r);
+        if (lane == 0) { mask[b * KMAX + r] = m; bin_count[b * KMAX + r] = __popcll(m); }
+    }
+    const int over = c > KMAX - 1 ? c - (KMAX - 1) : 0;
+    int incl = over;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    over_prefix[(size_t)b * 64 + lane] = incl - over;
+    if (lane == 63) bin_count[b * KMAX + KMAX - 1] = incl;
 }
 
 // pass 2 (after an exclusive scan of bin_count): destination index + composed original id
-__global__ void k_sort_dest(int N, const int* key, const int* slot, const int* bin_start, const int* orig_old, int* dest,
-                            int* orig_new) {
+__global__ void k_sort_dest(int N, const int* key, const int* slot, const int* bin_start, const unsigned long long* mask,
+                            const int* over_prefix, const int* orig_old, int* dest, int* orig_new) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
-    const int q = bin_start[key[p]] + slot[p];
+    const int k = key[p], r = slot[p] >> 6, cl = slot[p] & 63;
+    int pos;
+    if (r < KMAX - 1) pos = __popcll(mask[k] & ((1ull << cl) - 1ull));
+    else pos = over_prefix[(size_t)(k / KMAX) * 64 + cl] + (r - (KMAX - 1));
+    const int q = bin_start[k] + pos;
     dest[p] = q;
     orig_new[q] = orig_old ? orig_old[p] : p;
 }

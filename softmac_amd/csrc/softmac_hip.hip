@@ -120,10 +120,13 @@ template <class R> struct Sim final : ISim {
     std::vector<Epoch> epochs;      // [0] = identity
     std::vector<int> frame_epoch;   // order tag of S[f]   (-1: never written)
     std::vector<int> adj_epoch;     // order tag of A[f]   (-1: all zero, any order)
+    std::vector<char> adj_stale;    // A[f] is logically zero (adj_epoch -1) but its memory has not been cleared yet
     int grid_epoch = 0;             // epoch whose active blocks may hold non-zero grid data
     int sort_interval = 8;
     int nblocks = 0;
     // sort scratch
+    unsigned long long* d_bin_mask = nullptr;
+    int* d_over_prefix = nullptr;
     int *d_cell_count = nullptr, *d_bin = nullptr, *d_bin_start = nullptr, *d_key = nullptr, *d_slot = nullptr, *d_dest = nullptr;
     int *d_block_start = nullptr, *d_block_chunks = nullptr, *d_chunk_start = nullptr, *d_active_flag = nullptr, *d_active_start = nullptr;
     int* d_map = nullptr;
@@ -152,6 +155,7 @@ template <class R> struct Sim final : ISim {
         hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);
         hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
         for (auto& e : epochs) free_epoch(e);
+        hipFree(d_bin_mask); hipFree(d_over_prefix);
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
@@ -243,6 +247,8 @@ template <class R> struct Sim final : ISim {
         nblocks = D.nb * D.nb * D.nb;
         sort_interval = c.sort_interval > 0 ? c.sort_interval : 16;
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_over_prefix, D.G * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_bin_mask, (size_t)nblocks * KMAX * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void**)&d_bin, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_bin_start, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_key, D.Npad * sizeof(int)));
@@ -263,6 +269,7 @@ template <class R> struct Sim final : ISim {
         epochs[0].live = true;
         frame_epoch.assign(c.max_frames, -1);
         adj_epoch.assign(c.max_frames, -1);
+        adj_stale.assign(c.max_frames, 0);
         ck_epoch.assign(c.max_frames, -1);
         ck_gen.assign(c.max_frames, -1);
         ck_enabled = c.grad_enabled && !(getenv("SMAC_NO_CHECKPOINT") && atoi(getenv("SMAC_NO_CHECKPOINT")));
@@ -423,9 +430,18 @@ template <class R> struct Sim final : ISim {
         REQUIRE(D.A != nullptr, "handle created with grad_enabled = 0");
         return SMAC_OK;
     }
+    // clear_grads() is lazy: an adjoint frame is only physically zeroed if somebody is about to read it
+    // or add to it.  A backward sweep overwrites A[f] (write mode of g2p_grad / p2g_grad), so it never is.
+    int adj_make_zero(int f) {
+        if (!adj_stale[f]) return SMAC_OK;
+        HIP_TRY(hipMemsetAsync(D.A + (size_t)f * frame_scalars(), 0, frame_scalars() * sizeof(R), stream));
+        adj_stale[f] = 0;
+        return SMAC_OK;
+    }
     int get_grad(int f, double* gx, double* gv, double* gF, double* gC) override {
         int rc;
         if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
+        if (adj_epoch[f] < 0 && (rc = adj_make_zero(f))) return rc;
         const int e = adj_epoch[f] < 0 ? 0 : adj_epoch[f];
         if (gx && (rc = download_comp(D.A, f, CX, 3, gx, false, e))) return rc;
         if (gv && (rc = download_comp(D.A, f, CV, 3, gv, false, e))) return rc;
@@ -436,6 +452,7 @@ template <class R> struct Sim final : ISim {
     int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) override {
         int rc;
         if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
+        if (adj_epoch[f] < 0 && (rc = adj_make_zero(f))) return rc;
         if (adj_epoch[f] < 0) adj_epoch[f] = frame_epoch[f] < 0 ? 0 : frame_epoch[f];   // empty adjoint frame: adopt the state's order
         const int e = adj_epoch[f];
         const double* src[4] = {gx, gv, gC, gF};
@@ -451,7 +468,7 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     int clear_grads() override {
-        if (D.A) HIP_TRY(hipMemsetAsync(D.A, 0, frame_scalars() * sizeof(R) * cfg.max_frames, stream));
+        if (D.A) adj_stale.assign(cfg.max_frames, 1);                              // zeroed on demand (adj_make_zero)
         adj_epoch.assign(cfg.max_frames, -1);
         const int Pn = D.P > 0 ? D.P : 1;
         HIP_TRY(hipMemsetAsync(D.prim_grad, 0, (size_t)Pn * cfg.max_frames * 13 * sizeof(R), stream));
@@ -546,15 +563,18 @@ template <class R> struct Sim final : ISim {
         const int nbins = nblocks * KMAX;
         R* Sf = D.S + (size_t)f * frame_scalars();
         HIP_TRY(hipMemsetAsync(d_cell_count, 0, D.G * sizeof(int), stream));
-        HIP_TRY(hipMemsetAsync(d_bin, 0, ((size_t)nbins + 1) * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(d_bin + nbins, 0, sizeof(int), stream));
         hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + D.Npad),
-                           (const R*)(Sf + 2 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_bin, d_key, d_slot);
+                           (const R*)(Sf + 2 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot);
+        hipLaunchKernelGGL(k_bin_masks, dim3((nblocks + 3) / 4), dim3(BLOCK), 0, stream, nblocks, (const int*)d_cell_count, d_bin,
+                           d_bin_mask, d_over_prefix);
         int rc = scan(d_bin, d_bin_start, nbins + 1);
         if (rc) return rc;
         Epoch ep;
         HIP_TRY(hipMalloc((void**)&ep.orig, D.Npad * sizeof(int)));
         hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot,
-                           (const int*)d_bin_start, (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig);
+                           (const int*)d_bin_start, (const unsigned long long*)d_bin_mask, (const int*)d_over_prefix,
+                           (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig);
         hipLaunchKernelGGL(k_sort_move<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_dest, (const R*)Sf, tmp_frame,
                            D.Npad, (int)NCOMP);
         HIP_TRY(hipMemcpyAsync(Sf, tmp_frame, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
@@ -805,6 +825,7 @@ template <class R> struct Sim final : ISim {
             if ((rc = bind_epoch(e))) return rc;
             // adjoint of frame f+1 in this epoch's particle order; adjoint of frame f must be in it too
             const R* An = nullptr;
+            if (adj_epoch[f + 1] < 0 && (rc = adj_make_zero(f + 1))) return rc;  // no seed and no later substep: zero adjoint
             if ((rc = adjoint_in_order(f + 1, e, &An))) return rc;
             if (adj_epoch[f] >= 0 && adj_epoch[f] != e) {                         // seeds stored in another order: convert in place
                 const R* tmp = nullptr;
@@ -814,6 +835,7 @@ template <class R> struct Sim final : ISim {
             }
             pending_adj_zero = adj_epoch[f] < 0;                                  // A[f] is known to be all zero: write instead of +=
             adj_epoch[f] = e;
+            adj_stale[f] = 0;                                                     // write mode overwrites every row
             D.An = An;
             if (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0) {
                 // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void k(T* out, int stride, int iters) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             int a = (idx + u * 67) % WORDS;
-            if (MODE == 0) __hip_atomic_fetch_add(&buf[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == 3) { if ((lane & 7) == 0) __hip_atomic_fetch_add(&buf[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            else if (MODE == 4) { if ((lane & 1) == 0) __hip_atomic_fetch_add(&buf[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            else if (MODE == 0) __hip_atomic_fetch_add(&buf[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else if (MODE == 1) buf[a] = v;                      // plain store
             else if (MODE == 2) v += buf[a];                     // plain load
         }
@@ -57,6 +59,9 @@ int main() {
         run<unsigned, 0>("ds_add_u32", stride);
         run<unsigned long long, 0>("ds_add_u64", stride);
         run<int, 0>("ds_add_i32", stride);
+        run<double, 3>("ds_add_f64 1/8 lanes", stride);
+        run<double, 4>("ds_add_f64 1/2 lanes", stride);
+        run<float, 3>("ds_add_f32 1/8 lanes", stride);
         run<float, 1>("ds_write_b32", stride);
         run<float, 2>("ds_read_b32", stride);
     }

@@ -78,6 +78,12 @@ const char* smac_last_error(smac_handle h);
 int smac_abi_version(void);
 int smac_device_count(void);   /* 0 when no GPU is visible (does not initialise a context) */
 
+/* Asset pipeline (mesh.py:178-241, trimesh2sdf): signed distance and closest-face normal of a triangle mesh
+ * sampled at lower + (i,j,k) dx, i < res[0] etc. (C order, z fastest; normal_out has a trailing 3).  Negative
+ * inside.  Needs no simulation handle; errors are reported through smac_last_error(NULL). */
+int smac_mesh_to_sdf(int device, const double* vertices, int nv, const int32_t* faces, int nf, const double lower[3],
+                     const int32_t res[3], double dx, double* sdf_out, double* normal_out);
+
 int smac_create(const smac_config* cfg, smac_handle* out);
 int smac_destroy(smac_handle h);
 int smac_sync(smac_handle h);

@@ -40,6 +40,8 @@ SIGNATURES = {
     "smac_last_error": (C.c_char_p, [H]),
     "smac_abi_version": (C.c_int, []),
     "smac_device_count": (C.c_int, []),
+    "smac_mesh_to_sdf": (C.c_int, [C.c_int, c_double_p, C.c_int, c_int32_p, C.c_int, c_double_p, c_int32_p, C.c_double,
+                                   c_double_p, c_double_p]),
     "smac_create": (C.c_int, [C.POINTER(SmacConfig), C.POINTER(H)]),
     "smac_destroy": (C.c_int, [H]),
     "smac_sync": (C.c_int, [H]),

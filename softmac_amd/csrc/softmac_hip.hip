@@ -10,6 +10,7 @@
 
 #include "../../include/softmac_hip.h"
 #include "smac_kernels.hpp"
+#include "smac_voxel.hpp"
 
 using namespace smac;
 
@@ -1154,6 +1155,42 @@ int smac_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
+}
+
+int smac_mesh_to_sdf(int device, const double* vertices, int nv, const int32_t* faces, int nf, const double lower[3],
+                     const int32_t res[3], double dx, double* sdf_out, double* normal_out) {
+    if (!vertices || !faces || !lower || !res || !sdf_out || !normal_out) { g_create_error = "null argument"; return SMAC_ERR_INVALID; }
+    if (nv <= 0 || nf <= 0 || res[0] <= 0 || res[1] <= 0 || res[2] <= 0 || !(dx > 0)) { g_create_error = "empty mesh or grid"; return SMAC_ERR_INVALID; }
+    const int ndev = smac_device_count();
+    if (ndev <= 0) { g_create_error = "no HIP device visible: libsoftmac_hip has no CPU fallback"; return SMAC_ERR_NOGPU; }
+    if (device < 0 || device >= ndev) { g_create_error = "device ordinal out of range"; return SMAC_ERR_INVALID; }
+    std::vector<double> tri((size_t)nf * 9);
+    for (int t = 0; t < nf; ++t)
+        for (int c = 0; c < 3; ++c) {
+            const int v = faces[3 * t + c];
+            if (v < 0 || v >= nv) { g_create_error = "face index out of range"; return SMAC_ERR_INVALID; }
+            for (int d = 0; d < 3; ++d) tri[(size_t)t * 9 + 3 * c + d] = vertices[3 * (size_t)v + d];
+        }
+    const size_t total = (size_t)res[0] * res[1] * res[2];
+    double *d_tri = nullptr, *d_sdf = nullptr, *d_nrm = nullptr;
+    auto fail = [&](hipError_t e, const char* what) {
+        g_create_error = std::string(what) + " failed: " + hipGetErrorString(e);
+        hipFree(d_tri); hipFree(d_sdf); hipFree(d_nrm);
+        return SMAC_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    if ((e = hipMalloc((void**)&d_tri, tri.size() * sizeof(double))) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&d_sdf, total * sizeof(double))) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&d_nrm, total * 3 * sizeof(double))) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMemcpy(d_tri, tri.data(), tri.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    hipLaunchKernelGGL(smac::k_mesh_to_sdf, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, (const double*)d_tri, nf, lower[0],
+                       lower[1], lower[2], res[0], res[1], res[2], dx, d_sdf, d_nrm);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_mesh_to_sdf launch");
+    if ((e = hipMemcpy(sdf_out, d_sdf, total * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(normal_out, d_nrm, total * 3 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+    hipFree(d_tri); hipFree(d_sdf); hipFree(d_nrm);
+    return SMAC_OK;
 }
 
 int smac_create(const smac_config* cfg, smac_handle* out) {

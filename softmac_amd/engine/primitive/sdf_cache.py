@@ -2,9 +2,10 @@
 
 The reference stores `{signature, sdf, meshes}` pickles next to the OBJ, named by
 sha256("v2" + vertices.tobytes() + faces.tobytes()).  This module parses the OBJ without trimesh, recomputes the
-signature and loads a matching cache with a numpy-only restricted unpickler (never plain pickle.load on foreign
-blobs).  Building a missing cache (mesh -> SDF voxelisation, mesh.py:167-241) is the asset-pipeline row f3 of
-SURVEY section 8 and is not implemented yet: a missing cache raises."""
+signature (after the vertex merge trimesh applies on load) and loads a matching cache with a numpy-only restricted
+unpickler (never plain pickle.load on foreign blobs).  A missing cache is built on the GPU (voxelize.py ->
+smac_mesh_to_sdf, the MI355X replacement of mesh.py:167-241) and written next to the mesh in the reference's format
+when the directory is writable."""
 from __future__ import annotations
 
 import hashlib
@@ -50,15 +51,21 @@ def signature(vertices, faces):
     return h.hexdigest()
 
 
-def load_or_build_sdf(mesh_path):
+def load_or_build_sdf(mesh_path, device=0, write_cache=True):
+    from .voxelize import merge_vertices, mesh_to_sdf
     mesh_path = pathlib.Path(mesh_path)
-    vertices, faces = load_obj(mesh_path)
+    vertices, faces = merge_vertices(*load_obj(mesh_path))
     sig = signature(vertices, faces)
     cache = mesh_path.parent.absolute() / sig
     if cache.exists():
         with open(cache, "rb") as fh:
             blob = _NumpyOnlyUnpickler(fh).load()
         return blob["sdf"], (vertices, faces)
-    raise NotImplementedError(
-        f"no SDF cache {cache.name[:12]}... next to {mesh_path.name}: the mesh->SDF voxeliser (reference mesh.py:167-241) "
-        "is not implemented yet; pass `sdf=` tables to Mesh (e.g. softmac_amd.scenes.box_sdf / cylinder_sdf)")
+    sdf = mesh_to_sdf(vertices, faces, device=device)                # mesh.py:155-157
+    if write_cache:
+        try:
+            with open(cache, "wb") as fh:                            # mesh.py:159-161, same layout
+                pickle.dump({"signature": sig, "sdf": sdf, "meshes": [(vertices, faces)]}, fh)
+        except OSError:
+            pass                                                     # read-only asset directory: rebuild next time
+    return sdf, (vertices, faces)

@@ -8,6 +8,7 @@ cache is a pickle, so it is opened with a numpy-only restricted unpickler (SURVE
   grip_state_2k.npz   2000-particle subsample of softmac/envs/grip/grip_mpm_init_state.npy
   pour_state_1k.npz   1000-particle subsample of softmac/envs/pour/pour_mpm_init_state_corotated.npy
   palm_sdf.npz        sdf/normal tables of softmac/assets/gripper/palm.obj (the cached 6895...c4d5 blob)
+  door_sdf.npz        sdf/normal tables of softmac/assets/door/door.obj (the cached e7ab...561a blob; four touching boxes)
 """
 import importlib
 import pathlib
@@ -44,6 +45,13 @@ def main():
         blob = NumpyOnlyUnpickler(f).load()
     sdf = blob["sdf"]
     np.savez_compressed(OUT / "palm_sdf.npz", sdf=sdf["sdf"], normal=sdf["normal"],
+                        lower=np.asarray(sdf["position"][0]), upper=np.asarray(sdf["position"][1]),
+                        dx=float(sdf["dx"][0]), res=np.asarray(sdf["res"]),
+                        vertices=blob["meshes"][0][0], faces=blob["meshes"][0][1])
+    with open(REF / "assets/door/e7ab3378b317f8d1d4de18fa5bfa4d98e79629e714104b720ebcf0470dfc561a", "rb") as f:
+        blob = NumpyOnlyUnpickler(f).load()
+    sdf = blob["sdf"]
+    np.savez_compressed(OUT / "door_sdf.npz", sdf=sdf["sdf"], normal=sdf["normal"].astype(np.float32),
                         lower=np.asarray(sdf["position"][0]), upper=np.asarray(sdf["position"][1]),
                         dx=float(sdf["dx"][0]), res=np.asarray(sdf["res"]),
                         vertices=blob["meshes"][0][0], faces=blob["meshes"][0][1])

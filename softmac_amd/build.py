@@ -42,6 +42,7 @@ def build(force: bool = False, report: bool = False, verbose: bool = True) -> pa
         return LIB
     LIBDIR.mkdir(exist_ok=True)
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=fast",
+           "-fno-slp-vectorize",      # the SLP packer's v_pk_* f32 ops cost more v_mov shuffles than they save (measured +12%)
            "-Wno-unused-value", "-shared", "-fPIC", "-o", str(LIB)] + [str(s) for s in SOURCES]
     if report:
         cmd.append("-Rpass-analysis=kernel-resource-usage")

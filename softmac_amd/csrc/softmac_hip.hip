@@ -184,6 +184,13 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipEventCreate(&t1));
         D.N = c.n_particles;
         D.Npad = (c.n_particles + 255) / 256 * 256;
+        // component rows are Npad scalars apart: keep that stride off large powers of two (1M particles would put all
+        // 24 rows of a particle on the same HBM channel phase).  SMAC_ROW_SKEW scalars, a multiple of 64 (256 B).
+        {
+            const char* sk = getenv("SMAC_ROW_SKEW");
+            const int skew = sk ? atoi(sk) : 4160;
+            if (D.Npad >= 65536) D.Npad += (skew / 64) * 64;
+        }
         D.n = c.n_grid;
         D.G = (size_t)c.n_grid * c.n_grid * c.n_grid;
         D.P = c.n_primitives;

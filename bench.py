@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--precision", default="float32", choices=["float32", "float64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
     ap.add_argument("--sort-interval", type=int, default=0)
     args = ap.parse_args()

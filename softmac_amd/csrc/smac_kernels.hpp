@@ -48,7 +48,7 @@ constexpr int BLOCK = 256;
 enum { CX = 0, CV = 3, CC = 6, CF = 15, NCOMP = 24 };
 
 template <class R> struct alignas(4 * sizeof(R)) Vec4 { R x, y, z, w; };
-struct Hit;
+struct Hit { int p, mask, block, pad; };
 
 template <class R> struct DevSim {
     int N, Npad, n, P, n_control, substeps, collision_type, sticky, max_frames;
@@ -282,7 +282,6 @@ template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& 
 // (for the others v_tgt == v_tmp and the mixed4 correction is exactly zero).  k_p2g evaluates the band
 // test while it has x in registers and builds (a) a compact hit list {particle, mask, block} walked by
 // the contact adjoint and (b) the list of chunks holding hits + a per-particle mask, walked by k_contact.
-struct Hit { int p, mask, block, pad; };
 // stand-alone form of the same test (used when the forward grid is restored from a checkpoint)
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
@@ -309,8 +308,15 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
 // Grid checkpoint: the three value fields of the active blocks, packed [active slot][field][64 cells].
 // Saved after the forward substep's contact pass, restored (with the adjoint fields zeroed) at the start
 // of substep_grad instead of recomputing compute_F_tmp/svd/p2g/grid_op (mpm_simulator.py:352-359).
+// hit_ck / nhit_ck (optional): the frame's contact hit list travels with the checkpoint, so the backward pass
+// does not have to repeat the band test over all particles (k_contact_mask)
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck) {
+__global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck) {
+    if (hit_ck) {
+        const int nh = *D.nhits;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *nhit_ck = nh;
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += gridDim.x * BLOCK) hit_ck[i] = D.hits[i];
+    }
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= D.nactive) return;
     const int l = threadIdx.x & 63;
@@ -319,8 +325,12 @@ __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck) {
     dst[0] = D.vin[cell]; dst[64] = D.vmix[cell]; dst[128] = D.vout[cell];
 }
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<R>* ck) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }
+__global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<R>* ck, const Hit* hit_ck, const int* nhit_ck) {
+    if (hit_ck) {
+        const int nh = *nhit_ck;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = nh; *D.ncand = 0; }
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += gridDim.x * BLOCK) D.hits[i] = hit_ck[i];
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= D.nactive) return;
     const int l = threadIdx.x & 63;
@@ -547,11 +557,17 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
         R v_tmp[3] = {R(0), R(0), R(0)}, v_tgt[3] = {R(0), R(0), R(0)};
         Stencil<R> st;
         Nodes nd;
+        int mmask = 0;
         if (mask) {
             load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
             stencil_at(D, x, st, nd, ch.block);
             gather_vec(D, D.vmix, st, nd, v_tmp);                                           // mixed2
             v_tgt[0] = v_tmp[0]; v_tgt[1] = v_tmp[1]; v_tgt[2] = v_tmp[2];
+            // which of the 27 nodes carry mass (mixed4's test): fetched here, all loads in flight together,
+            // instead of one dependent load per trip of the rolled scatter loop below
+#pragma unroll
+            for (int n = 0; n < 27; ++n)
+                mmask |= (gld(D.vin, nd.cell(n / 9, (n / 3) % 3, n % 3)).x > R(1e-10) ? 1 : 0) << n;
         }
         const R life = R(1) / R(D.substeps - f % D.substeps);                               // :425
 #pragma unroll 1
@@ -584,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
                 const int tw = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
                                (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
                 const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
-                if (gld(D.vin, cell).x > R(1e-10)) {
+                if ((mmask >> n) & 1) {
                     for (int c = 0; c < 3; ++c) {
                         if (in) lds_add(tile + tw + c * TILE_WORDS, -w * diff[c]);
                         else gatomic(D.vout, cell, c, -w * diff[c]);

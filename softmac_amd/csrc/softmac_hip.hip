@@ -144,6 +144,8 @@ template <class R> struct Sim final : ISim {
     R* dense_tmp = nullptr;
     // grid checkpoints (one slot per frame in one arena); see k_grid_save
     Vec4<R>* ck_arena = nullptr;
+    Hit* ck_hits = nullptr;          // per frame: the contact hit list of that substep (capacity Npad), with its length
+    int* ck_nhits = nullptr;
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
     std::vector<int> ck_epoch;       // epoch the slot of frame f was saved in (-1: invalid)
@@ -160,7 +162,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
-        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena);
+        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
         for (auto e : pool) hipEventDestroy(e);
         for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -715,7 +717,10 @@ template <class R> struct Sim final : ISim {
     }
     int ngrid_blocks() const { return (D.nactive + 3) / 4; }
     int nchunk_blocks() const { return ((D.nchunks + 7) / 8) * 8; }   // XCD-aware chunk mapping (xcd_chunk) needs a multiple of 8
-    int contact_grid() const { return D.nchunks < 512 ? D.nchunks : 512; }    // fixed grid walking the candidate-chunk list
+    int contact_grid() const { return D.nchunks < 1024 ? D.nchunks : 1024; }  // fixed grid walking the candidate-chunk list
+    // hit list: 8 hits per workgroup and pass; the count lives on the device, so size the grid for the chip (a group
+    // that finds no hit left exits at once) - a short grid turns the list into a serial chain of SDF-lookup latencies
+    int contact_grad_grid() const { const int need = (D.N + 7) / 8; return need < 2048 ? (need > 0 ? need : 1) : 2048; }
     // Forward grid passes.  stage 0: everything; stage 1: clear_grid :93-114 on the active blocks, p2g, (forward
     // kinematics), slab reduction; stage 2: grid_op + contact.  Stages 1/2 exist for the slab decomposition, which
     // sums the {m,p} halo planes across neighbouring GPUs between them.
@@ -766,6 +771,15 @@ template <class R> struct Sim final : ISim {
                 ck_arena = nullptr;
                 ck_enabled = false;                        // not enough memory: substep_grad recomputes the forward grid
             }
+            // the hit lists ride along when they fit too (otherwise substep_grad repeats the band test)
+            const size_t hbytes = (size_t)cfg.max_frames * D.Npad * sizeof(Hit);
+            if (ck_arena && D.collision_type == CONTACT_MIXED && hipMemGetInfo(&free_b, &total_b) == hipSuccess && hbytes <= free_b / 4) {
+                if (hipMalloc((void**)&ck_hits, hbytes) != hipSuccess || hipMalloc((void**)&ck_nhits, cfg.max_frames * sizeof(int)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    hipFree(ck_hits);
+                    ck_hits = nullptr;
+                }
+            }
         }
         return ck_arena != nullptr && (size_t)D.nactive <= ck_slot_blocks;
     }
@@ -795,7 +809,9 @@ template <class R> struct Sim final : ISim {
             const int e = frame_epoch[f];
             if (D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {              // keep the forward grid for substep_grad
                 prof_begin(K_CKPT);
-                hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f));
+                const bool keep_hits = ck_hits && any_contact();
+                hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f),
+                                   keep_hits ? ck_hits + (size_t)f * D.Npad : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr);
                 prof_end();
                 ck_epoch[f] = e;
                 ck_gen[f] = config_gen;
@@ -850,8 +866,11 @@ template <class R> struct Sim final : ISim {
                 D.any_contact = any_contact() ? 1 : 0;
                 D.cur_frame = f;
                 prof_begin(K_CKPT);
-                hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f));
-                if (D.any_contact && D.collision_type != CONTACT_GRID)
+                const bool have_hits = ck_hits && D.any_contact && D.collision_type == CONTACT_MIXED;
+                hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f),
+                                   have_hits ? (const Hit*)(ck_hits + (size_t)f * D.Npad) : (const Hit*)nullptr,
+                                   have_hits ? (const int*)(ck_nhits + f) : (const int*)nullptr);
+                if (D.any_contact && D.collision_type != CONTACT_GRID && !have_hits)
                     hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
             } else {
@@ -871,7 +890,7 @@ template <class R> struct Sim final : ISim {
         }
         if ((phase < 0 || phase == 1) && D.nchunks > 0 && D.collision_type == CONTACT_MIXED && any_contact()) {   // :362-363, 389-393
             prof_begin(K_CONTACT_GRAD);
-            hipLaunchKernelGGL(k_contact_grad<R>, dim3(256), dim3(BLOCK), 0, stream, D, f);
+            hipLaunchKernelGGL(k_contact_grad<R>, dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
             prof_end();
         }
         if (phase < 0 || phase == 2) {

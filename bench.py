@@ -179,6 +179,7 @@ def main():
     prof = sim.profile_report()
     sim.profile(False)
     G_t = sim.count_active_cells(W)
+    n_hits, n_hit_chunks = sim.contact_counts()
 
     if rank == 0:
         kern = {k: v for k, v in prof.items() if v[1] > 0}
@@ -203,7 +204,7 @@ def main():
             "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
                                    f"3 gripper SDF primitives (2 in forecast contact), fwd+bwd",
-                       "particles_per_gpu": N, "n_grid": args.grid, "touched_cells": G_t,
+                       "particles_per_gpu": N, "n_grid": args.grid, "touched_cells": G_t, "contact_particles": n_hits,
                        "backward": "forward grid recomputed in substep_grad (reference style)" if args.recompute_backward
                        else "forward grid restored from the per-frame checkpoint saved by substep",
                        "parallelism": "1 gpu" if world == 1 else

@@ -133,6 +133,7 @@ int smac_profile_reset(smac_handle h);
 int smac_profile_count(smac_handle h);                           /* number of kernel classes */
 int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* total_ms, int64_t* launches); /* blocks */
 int smac_count_active_cells(smac_handle h, int f, int64_t* cells); /* cells with grid_m > 0 after P2G of frame f (G_t of SURVEY 8d) */
+int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /* particles inside a contact band / work items holding one, last forward substep */
 
 /* ---- raw device views for the multi-GPU halo exchange (softmac_amd/parallel.py wraps them as
  * torch tensors for torch.distributed/RCCL; no reference counterpart - SURVEY 8e). */

@@ -902,15 +902,19 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         // forward chain (every lane), then its adjoint primitive by primitive in reverse
         R v_tgt[3] = {v_tmp[0], v_tmp[1], v_tmp[2]};
         R dummy[6];
+        // One primitive in range (the usual case): the value part of the dual pass below IS the forward result,
+        // so the separate forward evaluation - a second chain of dependent SDF lookups - is skipped.
+        const bool single = mask != 0 && (mask & (mask - 1)) == 0;
+        if (!single) {
 #pragma unroll 1
-        for (int i = 0; i < D.P; ++i)
-            if ((mask >> i) & 1) {
-                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-                R s13[13];
-                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, dummy);
-            }
-        const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
+            for (int i = 0; i < D.P; ++i)
+                if ((mask >> i) & 1) {
+                    const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                    R s13[13];
+                    for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+                    collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, dummy);
+                }
+        }
         R g[3] = {-gd[0], -gd[1], -gd[2]};             // adjoint of v_tgt
         R gpos[3] = {R(0), R(0), R(0)};
 #pragma unroll 1
@@ -918,6 +922,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             const bool act = (mask >> i) & 1;
             if (!__ballot(act)) continue;
             R out = R(0);
+            R vfwd[3] = {R(0), R(0), R(0)};
             if (act) {
                 const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                 // velocity entering primitive i: replay the chain up to i
@@ -937,7 +942,12 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                     collide_mixed(D.prim[i], stt, pos, v, D.p_mass, D.dt, life, ext);
                     for (int c = 0; c < 3; ++c) out += g[c] * v[c].d;
                     for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * ext[c].d;
+                    for (int c = 0; c < 3; ++c) vfwd[c] = v[c].v;
                 }
+            }
+            {   // forward velocity after this primitive, from the group's first lane
+                const R f0 = __shfl(vfwd[0], lane0, 64), f1 = __shfl(vfwd[1], lane0, 64), f2 = __shfl(vfwd[2], lane0, 64);
+                if (act && single) { v_tgt[0] = f0; v_tgt[1] = f1; v_tgt[2] = f2; }
             }
             // direction d of this group's hit sits in lane lane0 + d
             const R o0 = __shfl(out, lane0 + 0, 64), o1 = __shfl(out, lane0 + 1, 64), o2 = __shfl(out, lane0 + 2, 64);
@@ -952,6 +962,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != R(0))
                 atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + (d - 6), sg);
         }
+        const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
         if (mask) {
             // adjoint of v_tmp = direct (mixed4) + through the chain (mixed3); mixed2.grad scatter by node
             const R gvt[3] = {gd[0] + g[0], gd[1] + g[1], gd[2] + g[2]};

@@ -75,6 +75,7 @@ struct ISim {
     virtual int profile_reset() = 0;
     virtual int profile_get(int i, char* name, int cap, double* ms, int64_t* launches) = 0;
     virtual int count_active_cells(int f, int64_t* cells) = 0;
+    virtual int contact_counts(int32_t* nhits, int32_t* nchunks_hit) = 0;
     virtual int grid_ptr(const char* field, void** p, int64_t* n, int32_t* bytes) = 0;
     virtual int substep_phase_v(int f, int phase) = 0;
     virtual int substep_grad_phase_v(int f, const double* ext_f_grad, int phase) = 0;
@@ -514,6 +515,15 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipStreamSynchronize(stream));
             for (size_t i = 0; i < D.G; ++i) out[i] = (double)tmp[i];
         }
+        return SMAC_OK;
+    }
+    // particles inside a contact band / chunks holding one, as left by the most recent forward substep
+    int contact_counts(int32_t* nhits, int32_t* nchunks_hit) override {
+        int h[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(h, d_nhits, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (nhits) *nhits = h[0];
+        if (nchunks_hit) *nchunks_hit = h[1];
         return SMAC_OK;
     }
     int count_active_cells(int f, int64_t* cells) override {
@@ -1296,6 +1306,7 @@ int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* tot
     return FWD(profile_get(i, name, name_cap, total_ms, launches));
 }
 int smac_count_active_cells(smac_handle h, int f, int64_t* cells) { return FWD(count_active_cells(f, cells)); }
+int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit) { return FWD(contact_counts(nhits, nchunks_hit)); }
 int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64_t* n_scalars, int32_t* scalar_bytes) {
     return FWD(grid_ptr(field, dev_ptr, n_scalars, scalar_bytes));
 }

@@ -256,6 +256,12 @@ class MPMSimulator:
         self._h.call("smac_count_active_cells", int(f), C.byref(n))
         return int(n.value)
 
+    def contact_counts(self):
+        """(particles inside a contact band, work items holding one) after the most recent forward substep."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._h.call("smac_contact_counts", C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def timer_start(self):
         self._h.call("smac_timer_start")
 

@@ -133,6 +133,12 @@ int smac_profile_reset(smac_handle h);
 int smac_profile_count(smac_handle h);                           /* number of kernel classes */
 int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* total_ms, int64_t* launches); /* blocks */
 int smac_count_active_cells(smac_handle h, int f, int64_t* cells); /* cells with grid_m > 0 after P2G of frame f (G_t of SURVEY 8d) */
+/* ---- losses on the device (losses/loss_pour.py:44-70, loss_grip.py:45-68: chamfer_closest + compute_chamfer_loss_kernel
+ * and the tape's adjoint of the latter).  set_target uploads the (m,3) target cloud once; chamfer returns
+ *   sum_i min_j |x_i - t_j|^2 + sum_j min_i |x_i - t_j|^2   over frame f (unweighted), and with add_grad != 0 also does
+ *   x.grad[f] += weight * d(chamfer)/dx  - what `with ti.ad.Tape(loss)` leaves in x.grad[f] for a loss weight `weight`. */
+int smac_loss_set_target(smac_handle h, const double* target, int m);
+int smac_loss_chamfer(smac_handle h, int f, double weight, int add_grad, double* loss_out);
 int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /* particles inside a contact band / work items holding one, last forward substep */
 
 /* ---- raw device views for the multi-GPU halo exchange (softmac_amd/parallel.py wraps them as

@@ -11,6 +11,7 @@
 #include "../../include/softmac_hip.h"
 #include "smac_kernels.hpp"
 #include "smac_voxel.hpp"
+#include "smac_loss.hpp"
 
 using namespace smac;
 
@@ -76,6 +77,8 @@ struct ISim {
     virtual int profile_get(int i, char* name, int cap, double* ms, int64_t* launches) = 0;
     virtual int count_active_cells(int f, int64_t* cells) = 0;
     virtual int contact_counts(int32_t* nhits, int32_t* nchunks_hit) = 0;
+    virtual int loss_set_target(const double* target, int m) = 0;
+    virtual int loss_chamfer(int f, double weight, int add_grad, double* loss_out) = 0;
     virtual int grid_ptr(const char* field, void** p, int64_t* n, int32_t* bytes) = 0;
     virtual int substep_phase_v(int f, int phase) = 0;
     virtual int substep_grad_phase_v(int f, const double* ext_f_grad, int phase) = 0;
@@ -163,6 +166,8 @@ template <class R> struct Sim final : ISim {
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
+        for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
+        hipFree(d_target); hipFree(d_loss);
         hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
         for (auto e : pool) hipEventDestroy(e);
@@ -516,6 +521,88 @@ template <class R> struct Sim final : ISim {
             for (size_t i = 0; i < D.G; ++i) out[i] = (double)tmp[i];
         }
         return SMAC_OK;
+    }
+    // ---- chamfer loss (smac_loss.hpp) -------------------------------------------------------
+    struct PIdx { int *cell_start = nullptr, *count = nullptr, *key = nullptr, *ids = nullptr, *slots = nullptr; double* pts = nullptr; int cap = 0, npts = 0; };
+    PIdx pi_target, pi_cur;
+    double *d_target = nullptr, *d_loss = nullptr;
+    int n_target = 0;
+    int pi_res() const { return (D.n + 7) / 8 * 8; }
+    int pi_alloc(PIdx& I, int m) {
+        const size_t cells = (size_t)pi_res() * pi_res() * pi_res();
+        if (!I.cell_start) {
+            HIP_TRY(hipMalloc((void**)&I.cell_start, (cells + 1) * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&I.count, (cells + 1) * sizeof(int)));
+        }
+        if (m > I.cap) {
+            hipFree(I.key); hipFree(I.ids); hipFree(I.slots); hipFree(I.pts);
+            HIP_TRY(hipMalloc((void**)&I.key, (size_t)m * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&I.ids, (size_t)m * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&I.slots, (size_t)m * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&I.pts, (size_t)m * 3 * sizeof(double)));
+            I.cap = m;
+        }
+        return SMAC_OK;
+    }
+    // counting sort of m points (rows x0..x2 of a frame, or an (m,3) f64 array) into the two-level cell order
+    int pi_build(PIdx& I, int m, const R* x0, const R* x1, const R* x2, const double* aos, const int* orig) {
+        int rc;
+        if ((rc = pi_alloc(I, m))) return rc;
+        const int n = pi_res();
+        const size_t cells = (size_t)n * n * n;
+        HIP_TRY(hipMemsetAsync(I.count, 0, (cells + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_pi_count<R>, dim3(nblk(m)), dim3(BLOCK), 0, stream, m, x0, x1, x2, aos, n, I.count, I.key);
+        if ((rc = scan(I.count, I.cell_start, (int)cells + 1))) return rc;
+        HIP_TRY(hipMemsetAsync(I.count, 0, (cells + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_pi_fill<R>, dim3(nblk(m)), dim3(BLOCK), 0, stream, m, x0, x1, x2, aos, (const int*)I.key,
+                           (const int*)I.cell_start, I.count, orig, I.ids, I.slots, I.pts);
+        I.npts = m;
+        return check_launch();
+    }
+    PointIndex pi_view(const PIdx& I) const { PointIndex v = {pi_res(), I.npts, I.cell_start, I.ids, I.slots, I.pts}; return v; }
+    int loss_set_target(const double* target, int m) override {                  // loss_pour.py:29-31 load_target_position
+        REQUIRE(target && m > 0, "loss_set_target: empty target");
+        hipFree(d_target);
+        d_target = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_target, (size_t)m * 3 * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(d_target, target, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        n_target = m;
+        return pi_build(pi_target, m, nullptr, nullptr, nullptr, d_target, nullptr);
+    }
+    int loss_chamfer(int f, double weight, int add_grad, double* loss_out) override {   // loss_pour.py:44-70 (+ its adjoint)
+        int rc;
+        if ((rc = check_frame(f))) return rc;
+        REQUIRE(n_target > 0, "loss_chamfer: no target set (smac_loss_set_target)");
+        REQUIRE(frame_epoch[f] >= 0, "loss_chamfer: frame holds no state");
+        const int e = frame_epoch[f];
+        const R* Sf = D.S + (size_t)f * frame_scalars();
+        if ((rc = pi_build(pi_cur, D.N, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad, nullptr, e > 0 ? (const int*)epochs[e].orig : nullptr))) return rc;
+        R* Af = nullptr;
+        if (add_grad) {
+            if ((rc = need_grad())) return rc;
+            if (adj_epoch[f] < 0) {
+                if ((rc = adj_make_zero(f))) return rc;
+            } else if (adj_epoch[f] != e) {                                   // seeds stored in another particle order
+                const R* tmp = nullptr;
+                if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
+                HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+            }
+            adj_epoch[f] = e;
+            Af = D.A + (size_t)f * frame_scalars();
+        }
+        if (!d_loss) HIP_TRY(hipMalloc((void**)&d_loss, sizeof(double)));
+        HIP_TRY(hipMemsetAsync(d_loss, 0, sizeof(double), stream));
+        R* g0 = Af; R* g1 = Af ? Af + D.Npad : nullptr; R* g2 = Af ? Af + 2 * (size_t)D.Npad : nullptr;
+        hipLaunchKernelGGL(k_chamfer_cur_to_target<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, Sf, Sf + D.Npad,
+                           Sf + 2 * (size_t)D.Npad, pi_view(pi_target), weight, add_grad ? 1 : 0, g0, g1, g2, d_loss);
+        hipLaunchKernelGGL(k_chamfer_target_to_cur<R>, dim3(nblk(n_target)), dim3(BLOCK), 0, stream, n_target, (const double*)d_target,
+                           pi_view(pi_cur), weight, add_grad ? 1 : 0, g0, g1, g2, d_loss);
+        double h = 0;
+        HIP_TRY(hipMemcpyAsync(&h, d_loss, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (loss_out) *loss_out = h;
+        return check_launch();
     }
     // particles inside a contact band / chunks holding one, as left by the most recent forward substep
     int contact_counts(int32_t* nhits, int32_t* nchunks_hit) override {
@@ -1307,6 +1394,8 @@ int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* tot
 }
 int smac_count_active_cells(smac_handle h, int f, int64_t* cells) { return FWD(count_active_cells(f, cells)); }
 int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit) { return FWD(contact_counts(nhits, nchunks_hit)); }
+int smac_loss_set_target(smac_handle h, const double* target, int m) { return FWD(loss_set_target(target, m)); }
+int smac_loss_chamfer(smac_handle h, int f, double weight, int add_grad, double* loss_out) { return FWD(loss_chamfer(f, weight, add_grad, loss_out)); }
 int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64_t* n_scalars, int32_t* scalar_bytes) {
     return FWD(grid_ptr(field, dev_ptr, n_scalars, scalar_bytes));
 }

@@ -256,6 +256,19 @@ class MPMSimulator:
         self._h.call("smac_count_active_cells", int(f), C.byref(n))
         return int(n.value)
 
+    # ------------------------------------------------------------------ losses on the device (losses/loss_*.py)
+    def loss_set_target(self, target):
+        t = _ffi.as_f64(target)
+        assert t.ndim == 2 and t.shape[1] == 3
+        self._h.call("smac_loss_set_target", _ffi.dptr(t), int(t.shape[0]))
+
+    def loss_chamfer(self, f, weight=1.0, add_grad=False):
+        """Unweighted bidirectional chamfer distance between x[f] and the target; with add_grad,
+        x.grad[f] += weight * d(chamfer)/dx (what the reference's tape leaves there)."""
+        out = C.c_double(0.0)
+        self._h.call("smac_loss_chamfer", int(f), C.c_double(float(weight)), 1 if add_grad else 0, C.byref(out))
+        return float(out.value)
+
     def contact_counts(self):
         """(particles inside a contact band, work items holding one) after the most recent forward substep."""
         a, b = C.c_int32(0), C.c_int32(0)

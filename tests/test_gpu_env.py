@@ -79,3 +79,54 @@ def test_velocity_control_rollout_and_action_gradients(precision, ts, tg):
     # pose reached through device forward kinematics
     st = mesh.get_state(T)
     assert np.abs(st[:3] - pos.detach().numpy()).max() < ts * 10 and np.abs(st[3:7] - rot.detach().numpy()).max() < max(ts * 10, 1e-6)
+
+
+def test_loss_to_action_gradient_by_finite_differences():
+    """The whole loop of demo_pour_vel.py (:76-111) - reset, K env steps, chamfer + pose + velocity loss at every env
+    step inside the tape, env.backward() - against central differences of the total loss in the actions (f64,
+    neo-Hookean so that no SVD-clamp convention enters, see tests/test_gpu_fullsize.py)."""
+    import types
+    from softmac_amd.config import CfgNode
+    from softmac_amd.engine.losses import PourLoss
+    from softmac_amd.engine.primitive import Mesh, Primitives
+    from softmac_amd.engine.taichi_env import TaichiEnv
+    cfg, state, pose, vel = _scene("float64")
+    cfg.SIMULATOR.ptype = 1
+    cfg.SIMULATOR.material_model = 1
+    palm = H.load_palm()
+    pc = CfgNode(); pc.friction = 0.4; pc.enable_external_force = True; pc.urdf_path = ""
+    mesh = Mesh(sdf=palm, cfg=pc, max_timesteps=cfg.SIMULATOR.max_steps, rigid_velocity_control=True)
+    env = TaichiEnv(cfg, primitives=Primitives(primitives=[mesh]))
+    mesh.friction[None] = 0.4
+    rng = np.random.default_rng(12)
+    target = state[:, :3] + np.array([0.02, -0.03, 0.01]) + 0.002 * rng.standard_normal((len(state), 3))
+    loss = PourLoss(types.SimpleNamespace(weight=(1.0, 0.5, 0.25), target_path=None), env.simulator)
+    loss.set_target(target)
+    loss.initialize()
+    env.loss = loss
+    K = 3
+    actions = 0.3 * rng.standard_normal((K, 6))
+
+    def rollout(acts, record):
+        env.reset()
+        env.simulator.clear_grads()
+        total = 0.0
+        ctx = loss.tape() if record else contextlib.nullcontext()
+        with ctx:
+            for k in range(K):
+                env.step(torch.tensor(acts[k]))
+                loss.clear()
+                total += env.compute_loss()["loss"]
+        return total
+
+    import contextlib
+    base = rollout(actions, True)
+    grad = env.backward().numpy()
+    assert np.abs(grad[:-1]).max() > 0
+    for (k, c) in ((0, 4), (0, 1), (1, 3), (1, 2)):            # components of (w, v) of the first two actions
+        eps = 1e-6
+        ap, am = actions.copy(), actions.copy()
+        ap[k, c] += eps; am[k, c] -= eps
+        fd = (rollout(ap, False) - rollout(am, False)) / (2 * eps)
+        assert abs(fd - grad[k, c]) < 2e-5 * max(abs(fd), 1e-3), (k, c, fd, grad[k, c])
+    assert abs(rollout(actions, False) - base) < 1e-12 * abs(base)

@@ -265,6 +265,10 @@ __global__ __launch_bounds__(BLOCK) void k_clear_active(DevSim<R> D, Vec4<R>* ba
     for (int f = 0; f < nfields; ++f) base[(size_t)f * D.G + cell] = z;
 }
 
+template <class R> __global__ void k_reset_contact_lists(DevSim<R> D) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }
+}
+
 // band test shared by k_contact and k_contact_grad: which primitives see this particle
 template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const R* x) {
     int mask = 0;
@@ -323,6 +327,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, H
     const size_t cell = (size_t)D.active[a] * 64 + l;
     Vec4<R>* dst = ck + (size_t)a * 192 + l;
     dst[0] = D.vin[cell]; dst[64] = D.vmix[cell]; dst[128] = D.vout[cell];
+    // {m, p} is not read again this substep: leave it zeroed for the next P2G (drifted particles add to it with
+    // global atomics), which saves that substep's clear pass
+    const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+    D.vin[cell] = z;
 }
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<R>* ck, const Hit* hit_ck, const int* nhit_ck) {
@@ -504,7 +512,12 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     }
     if (phase == 1) return;
     const R m = acc.x;
-    if (!(m > R(1e-10))) return;                                                       // :286 / :399
+    if (!(m > R(1e-10))) {                                                             // :286 / :399: no velocity on this node
+        const Vec4<R> z = {R(0), R(0), R(0), R(0)};                                    // (written, so the fields need no clear)
+        if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = z;
+        D.vout[cell] = z;
+        return;
+    }
     const R inv = R(1) / m;
     R v[3] = {inv * acc.y + D.dt * D.g[0], inv * acc.z + D.dt * D.g[1], inv * acc.w + D.dt * D.g[2]};   // :287-288
     if (GRIDC) {                                                                       // :290-294 grid-node contact (collision_type 0)

@@ -152,6 +152,7 @@ template <class R> struct Sim final : ISim {
     int* ck_nhits = nullptr;
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
+    bool vin_clean = false;          // {m,p} of every active block is zero (saves the clear pass before P2G)
     std::vector<int> ck_epoch;       // epoch the slot of frame f was saved in (-1: invalid)
     std::vector<long long> ck_gen;   // configuration generation at save time
     long long config_gen = 0;        // bumped whenever something the forward grid depends on may have changed
@@ -731,6 +732,7 @@ template <class R> struct Sim final : ISim {
             Do.nactive = epochs[grid_epoch].nactive;
             hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 6);
         }
+        if (e != grid_epoch) vin_clean = false;
         grid_epoch = e;
         const Epoch& ep = epochs[e];
         D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
@@ -830,7 +832,12 @@ template <class R> struct Sim final : ISim {
         if (is_recompute) Dc.ext_f = scratch_ext();
         if (stage != 2) {
             prof_begin(K_CLEAR);
-            hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 3);
+            // grid_op rewrites v_mixed / v_out of every active cell; {m,p} must start from zero (drifted particles add to
+            // it atomically) and is left zeroed by the checkpoint save of the previous substep
+            if (is_recompute) hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 6);
+            else if (!vin_clean) hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 1);
+            else hipLaunchKernelGGL(k_reset_contact_lists<R>, dim3(1), dim3(64), 0, stream, D);
+            vin_clean = false;
             prof_end();
             prof_begin(K_P2G);
             if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
@@ -912,6 +919,7 @@ template <class R> struct Sim final : ISim {
                 prof_end();
                 ck_epoch[f] = e;
                 ck_gen[f] = config_gen;
+                vin_clean = true;
             }
             if (D.nchunks > 0) {
                 prof_begin(K_G2P);
@@ -964,6 +972,7 @@ template <class R> struct Sim final : ISim {
                 D.cur_frame = f;
                 prof_begin(K_CKPT);
                 const bool have_hits = ck_hits && D.any_contact && D.collision_type == CONTACT_MIXED;
+                vin_clean = false;
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f),
                                    have_hits ? (const Hit*)(ck_hits + (size_t)f * D.Npad) : (const Hit*)nullptr,
                                    have_hits ? (const int*)(ck_nhits + f) : (const int*)nullptr);

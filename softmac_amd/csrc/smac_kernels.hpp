@@ -88,7 +88,6 @@ template <class R> struct DevSim {
     const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
     const int* block_chunks;
     int* drift_flag;
-    int debug;                   // SMAC_DEBUG env: timing experiments only
     int open_x;                  // slab decomposition: bit 0 / bit 1 = no wall at the low / high x end (neighbour slab there)
     const int* block_active;     // dense per-block flag of the current epoch (halo packing)
 };
@@ -1056,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
                     for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * es[c].d;
                 }
             }
-            if (act && d < 6 && !((D.debug & 16) && d < 3)) {
+            if (act && d < 6) {
                 R* Af = frame(D.A, f, D.Npad);
                 Af[(size_t)((d < 3 ? CX : CV - 3) + d) * D.Npad + p] += out;
             }
@@ -1198,7 +1197,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
             for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
     }
     if (D.collision_type == CONTACT_PARTICLE && D.any_contact) {      // the contact impulse is part of the scattered momentum
-        const int cm = (D.debug & 8) ? 0 : D.pmask[p];
+        const int cm = D.pmask[p];
         if (cm) {
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i) {

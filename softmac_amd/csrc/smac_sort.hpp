@@ -31,10 +31,19 @@ __host__ __device__ __forceinline__ size_t cell_of(int nb, int i, int j, int k) 
 }
 
 // pass 1: rank of each particle inside its cell; key; (rank, local cell) packed for pass 2
+// Also records the largest velocity component (float bits of a non-negative value order like unsigned ints): the
+// host turns it into the number of substeps the binning stays valid for.
 template <class R>
-__global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, int N, int n, int nb, R inv_dx, int* cell_count,
-                            int* key_out, int* slot_out) {
+__global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, const R* v1, const R* v2, int N, int n, int nb,
+                            R inv_dx, int* cell_count, int* key_out, int* slot_out, unsigned* vmax_bits) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float vm = 0.f;
+    if (p < N) {
+        const float a = fabsf((float)v0[p]), b = fabsf((float)v1[p]), c = fabsf((float)v2[p]);
+        vm = fmaxf(a, fmaxf(b, c));
+    }
+    for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o, 64));
+    if ((threadIdx.x & 63) == 0 && vm > 0.f) atomicMax(vmax_bits, __float_as_uint(vm));
     if (p >= N) return;
     const R x[3] = {x0[p], x1[p], x2[p]};
     int b[3];

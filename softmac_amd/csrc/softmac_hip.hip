@@ -119,6 +119,7 @@ template <class R> struct Sim final : ISim {
         int* block_chunks = nullptr;
         int* block_active = nullptr;
         int frame = 0;              // frame at which the sort happened
+        int interval = 1;           // substeps this binning is used for (<= sort_interval, shortened for fast particles)
         std::vector<int> h_orig;    // host copy (lazy) for IO
         bool live = false;
     };
@@ -132,6 +133,7 @@ template <class R> struct Sim final : ISim {
     // sort scratch
     unsigned long long* d_bin_mask = nullptr;
     int* d_over_prefix = nullptr;
+    unsigned* d_vmax = nullptr;
     int *d_cell_count = nullptr, *d_bin = nullptr, *d_bin_start = nullptr, *d_key = nullptr, *d_slot = nullptr, *d_dest = nullptr;
     int *d_block_start = nullptr, *d_block_chunks = nullptr, *d_chunk_start = nullptr, *d_active_flag = nullptr, *d_active_start = nullptr;
     int* d_map = nullptr;
@@ -163,7 +165,7 @@ template <class R> struct Sim final : ISim {
         hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);
         hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
         for (auto& e : epochs) free_epoch(e);
-        hipFree(d_bin_mask); hipFree(d_over_prefix);
+        hipFree(d_bin_mask); hipFree(d_over_prefix); hipFree(d_vmax);
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
@@ -258,12 +260,12 @@ template <class R> struct Sim final : ISim {
         D.control_idx = d_control_idx;
         HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
         // block-sparse grid + sort scratch
-        D.debug = getenv("SMAC_DEBUG") ? atoi(getenv("SMAC_DEBUG")) : 0;
         D.open_x = (c.flags >> 1) & 3;                               // flags bits 1,2: neighbour slab at the low / high x end
         D.nb = c.n_grid / 4;
         nblocks = D.nb * D.nb * D.nb;
         sort_interval = c.sort_interval > 0 ? c.sort_interval : 16;
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_vmax, sizeof(unsigned)));
         HIP_TRY(hipMalloc((void**)&d_over_prefix, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_bin_mask, (size_t)nblocks * KMAX * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void**)&d_bin, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
@@ -672,8 +674,10 @@ template <class R> struct Sim final : ISim {
         R* Sf = D.S + (size_t)f * frame_scalars();
         HIP_TRY(hipMemsetAsync(d_cell_count, 0, D.G * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_bin + nbins, 0, sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), stream));
         hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + D.Npad),
-                           (const R*)(Sf + 2 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot);
+                           (const R*)(Sf + 2 * (size_t)D.Npad), (const R*)(Sf + 3 * (size_t)D.Npad), (const R*)(Sf + 4 * (size_t)D.Npad),
+                           (const R*)(Sf + 5 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax);
         hipLaunchKernelGGL(k_bin_masks, dim3((nblocks + 3) / 4), dim3(BLOCK), 0, stream, nblocks, (const int*)d_cell_count, d_bin,
                            d_bin_mask, d_over_prefix);
         int rc = scan(d_bin, d_bin_start, nbins + 1);
@@ -694,9 +698,21 @@ template <class R> struct Sim final : ISim {
         if ((rc = scan(d_block_chunks, d_chunk_start, nblocks + 1))) return rc;
         if ((rc = scan(d_active_flag, d_active_start, nblocks + 1))) return rc;
         int totals[2];
+        unsigned vbits = 0;
         HIP_TRY(hipMemcpyAsync(&totals[0], d_chunk_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&totals[1], d_active_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&vbits, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        {
+            // A particle may move 4 cells (its block's halo) before the binning breaks; budget 2 cells for the fastest
+            // particle at its current speed, which leaves a factor two for acceleration inside the interval.
+            float vmax;
+            memcpy(&vmax, &vbits, sizeof vmax);
+            const double travel = (double)vmax * cfg.dt * D.n;                   // cells per substep
+            int iv = sort_interval;
+            if (travel > 0 && 2.0 / travel < (double)iv) iv = (int)(2.0 / travel);
+            ep.interval = iv < 1 ? 1 : iv;
+        }
         ep.nchunks = totals[0];
         ep.nactive = totals[1];
         HIP_TRY(hipMalloc((void**)&ep.chunks, (size_t)(ep.nchunks > 0 ? ep.nchunks : 1) * sizeof(Chunk)));
@@ -779,7 +795,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h) {
             HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
-            err = "a particle moved more than one grid block between two re-sorts: lower sort_interval (or dt)";
+            err = "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort interval): lower sort_interval or dt";
             return SMAC_ERR_INVALID;
         }
         return SMAC_OK;
@@ -899,7 +915,7 @@ template <class R> struct Sim final : ISim {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
             int e = frame_epoch[f];
-            if (e == 0 || f - epochs[e].frame >= sort_interval || f < epochs[e].frame) {
+            if (e == 0 || f - epochs[e].frame >= epochs[e].interval || f < epochs[e].frame) {
                 if (e > 0 && (rc = check_drift())) return rc;
                 if ((rc = sort_frame(f))) return rc;
                 e = frame_epoch[f];
@@ -1263,7 +1279,9 @@ template <class R> struct Sim final : ISim {
         struct { const char* name; R* ptr; int64_t n; } tab[] = {
             {"grid_in", (R*)D.vin, (int64_t)(4 * D.G)}, {"grid_mixed", (R*)D.vmix, (int64_t)(4 * D.G)}, {"grid_out", (R*)D.vout, (int64_t)(4 * D.G)},
             {"grid_in.grad", (R*)D.ain, (int64_t)(4 * D.G)}, {"grid_mixed.grad", (R*)D.amix, (int64_t)(4 * D.G)},
-            {"grid_out.grad", (R*)D.aout, (int64_t)(4 * D.G)}};
+            {"grid_out.grad", (R*)D.aout, (int64_t)(4 * D.G)},
+            {"state", D.S, (int64_t)frame_scalars() * cfg.max_frames}, {"state.grad", D.A, (int64_t)frame_scalars() * cfg.max_frames},
+            {"slab", (R*)slab, (int64_t)(slab_chunks * TILE_WORDS * 4)}};
         for (auto& t : tab)
             if (!strcmp(t.name, field)) {
                 *p = t.ptr;

@@ -156,6 +156,16 @@ def test_resort_every_substep_and_long_window():
         _compare_rollout(cfg, 1e-3, state, steps)
 
 
+def test_fast_particles_shorten_the_resort_interval():
+    """A cloud crossing 5.4 cells in 14 substeps with sort_interval 16: more than the 4-cell halo a binning is good
+    for, so the library has to re-bin on its own schedule (0.38 cells per substep -> every 5 substeps)."""
+    n_grid, N = 64, 2500
+    state = H.make_cloud(N, n_grid, seed=14, lo=(0.2, 0.4, 0.4), hi=(0.35, 0.55, 0.55), v_std=0.2)
+    state[:, 3] += 30.0
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, gravity=(0., 0., 0.), precision="float64", sort_interval=16, max_steps=16)
+    _compare_rollout(cfg, 2e-3, state, 14)
+
+
 @pytest.mark.parametrize("precision", ["float64"])
 def test_two_primitives_one_disabled(precision):
     d = np.load(H.GOLDEN / "grip_state_2k.npz")

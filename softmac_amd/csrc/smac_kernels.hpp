@@ -103,6 +103,39 @@ __device__ __forceinline__ int tile_index(int li, int lj, int lk) { return li * 
 // ds_add_f64 retires a conflict-free wave instruction in ~10 cycles while ds_add_f32 is lane-serial
 // (~193 cycles) - and the f64 sum is the more accurate one anyway.
 typedef double tile_t;
+
+// Scatter tiles of the two hot scatter kernels (k_p2g, k_g2p_grad).
+//   R = double : f64 words, ds_add_f64.
+//   R = float  : 32-bit FIXED-POINT words, ds_add_u32 - 5.5 instead of 17 LDS cycles per 64-lane atomic
+//                (tools/microbench/lds_tile.hip; ds_add_f32 is lane-serial on gfx950 and not an option).  The scale is
+//                chosen per chunk from a bound B on any single contribution (quadratic B-spline: w <= 0.75^3 and
+//                w |offset - fx| <= 0.25 * 0.75^2 per axis): a contribution is rounded to B * 2^-23 - f32-grade
+//                accumulation, as the reference's own f32 atomics would be -, a node sum of the <= 256 contributions
+//                of a chunk cannot overflow, and integer adds make the tile independent of the order of arrival.
+template <class R> struct ScatterTile { typedef double word; };
+template <> struct ScatterTile<float> { typedef int word; };
+constexpr float FIX_RANGE = 8388000.0f;      // < 2^31 / 256: |q| <= FIX_RANGE per contribution, 256 of them per node at most
+constexpr float W_MAX = 0.421875f;           // 0.75^3
+constexpr float WD_MAX = 0.140625f;          // 0.25 * 0.75^2
+__device__ __forceinline__ void tile_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void tile_add(int* p, float v) {
+    __hip_atomic_fetch_add(p, __float2int_rn(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// largest `bound` over the workgroup (every thread calls it; 0 for idle lanes) -> scale to / from tile units
+template <class R> __device__ __forceinline__ void tile_scale(R bound, R* scratch4, R& to_tile, R& from_tile);
+template <> __device__ __forceinline__ void tile_scale<double>(double, double*, double& to_tile, double& from_tile) {
+    to_tile = from_tile = 1.0;
+    __syncthreads();
+}
+template <> __device__ __forceinline__ void tile_scale<float>(float bound, float* scratch4, float& to_tile, float& from_tile) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+    if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = bound;
+    __syncthreads();
+    const float B = fmaxf(fmaxf(scratch4[0], scratch4[1]), fmaxf(scratch4[2], scratch4[3]));
+    to_tile = B > 0.f ? FIX_RANGE / B : 0.f;
+    from_tile = B * (1.0f / FIX_RANGE);
+}
 template <class R> __device__ __forceinline__ void lds_add(tile_t* p, R v) {
     __hip_atomic_fetch_add(p, (tile_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -205,12 +238,12 @@ __device__ __forceinline__ int xcd_chunk(int nchunks) {
     SMAC_CHUNK_PROLOGUE_AT(cid)
 
 // store this chunk's f64 LDS tile (NS scalars, tile[s][word]) to its slab as 16-byte records, coalesced
-template <class R, int NS> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const tile_t* tile) {
+template <class R, int NS, class W> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const W* tile, R s0 = R(1), R s123 = R(1)) {
     Vec4<R>* dst = D.slab + (size_t)xcd_chunk(D.nchunks) * TILE_WORDS;
     for (int i = threadIdx.x; i < TILE_WORDS; i += BLOCK) {
         Vec4<R> v;
-        v.x = (R)tile[i]; v.y = (R)tile[TILE_WORDS + i]; v.z = (R)tile[2 * TILE_WORDS + i];
-        v.w = NS > 3 ? (R)tile[3 * TILE_WORDS + i] : R(0);
+        v.x = (R)tile[i] * s0; v.y = (R)tile[TILE_WORDS + i] * s123; v.z = (R)tile[2 * TILE_WORDS + i] * s123;
+        v.w = NS > 3 ? (R)tile[3 * TILE_WORDS + i] * s123 : R(0);
         dst[i] = v;
     }
 }
@@ -353,14 +386,20 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
 // ------------------------------------------------------------------------------------------
 template <class R, bool STORE_F>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_p2g(DevSim<R> D, int f) {
-    __shared__ tile_t tile[4 * TILE_WORDS];
+    typedef typename ScatterTile<R>::word W;
+    __shared__ W tile[4 * TILE_WORDS];
+    __shared__ R smax[4];
     SMAC_CHUNK_PROLOGUE
-    for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
+    for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = W(0);
     __syncthreads();
     int cmask = 0;
+    R x[3] = {R(0.5), R(0.5), R(0.5)}, pv[3] = {R(0), R(0), R(0)}, aff[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) aff[i] = R(0);
+    R bound = R(0);                       // no single scattered momentum component of this particle exceeds it
     if (valid) {
         const R* Sf = frame(D.S, f, D.Npad);
-        R x[3], v[3], C[9], E[9], Et[9], En[9], stress[9], aff[9];
+        R v[3], C[9], E[9], Et[9], En[9], stress[9];
         load_vec(Sf, CX, 3, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(Sf, CC, 9, D.Npad, p, C);
@@ -382,7 +421,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
-        R pv[3] = {D.p_mass * v[0], D.p_mass * v[1], D.p_mass * v[2]};
+        pv[0] = D.p_mass * v[0]; pv[1] = D.p_mass * v[1]; pv[2] = D.p_mass * v[2];
         if (D.collision_type == CONTACT_PARTICLE && cmask) {                              // :203-206 penalty contact impulse
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i) {
@@ -401,6 +440,15 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
             if (ci >= 0)
                 for (int d = 0; d < 3; ++d) pv[d] += R(6e-4) * D.action[3 * ci + d] * D.dt;
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)      // |w (pv + aff dpos)|
+            bound = maxc(bound, R(W_MAX) * abs_(pv[c]) + R(WD_MAX) * D.dx * (abs_(aff[3 * c]) + abs_(aff[3 * c + 1]) + abs_(aff[3 * c + 2])));
+    }
+    // tile units: momentum by the chunk's bound, mass by p_mass (w <= 1); one barrier (all threads)
+    R to_tile, from_tile;
+    tile_scale<R>(bound, smax, to_tile, from_tile);
+    const R mass_unit = sizeof(R) == 4 ? R(FIX_RANGE / W_MAX) : D.p_mass;    // w <= W_MAX
+    if (valid) {
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, ch.block);
@@ -423,10 +471,11 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const R w = wij * st.w[k][2];
-                        tile_t* tp = tile + nd.tile(i, j, k);
-                        lds_add(tp, w * D.p_mass);                                         // :262
+                        const R ws = w * to_tile;
+                        W* tp = tile + nd.tile(i, j, k);
+                        tile_add(tp, w * mass_unit);                                       // :262
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) lds_add(tp + (1 + c) * TILE_WORDS, w * (mj[c] + R(k) * a2[c]));   // :261
+                        for (int c = 0; c < 3; ++c) tile_add(tp + (1 + c) * TILE_WORDS, ws * (mj[c] + R(k) * a2[c]));   // :261
                     }
                 }
             }
@@ -445,11 +494,11 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
                 const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
                 const R d0 = (R(i) - st.fx[0]) * D.dx, d1 = (R(j) - st.fx[1]) * D.dx, d2 = (R(k) - st.fx[2]) * D.dx;
                 const unsigned cell = (unsigned)(cxi + cyj + czk);
-                if (in) lds_add(tile + tw, w * D.p_mass);
+                if (in) tile_add(tile + tw, w * mass_unit);
                 else gatomic(D.vin, cell, 0, w * D.p_mass);
                 for (int c = 0; c < 3; ++c) {
                     const R val = w * (pv[c] + aff[3 * c] * d0 + aff[3 * c + 1] * d1 + aff[3 * c + 2] * d2);
-                    if (in) lds_add(tile + tw + (1 + c) * TILE_WORDS, val);
+                    if (in) tile_add(tile + tw + (1 + c) * TILE_WORDS, val * to_tile);
                     else gatomic(D.vin, cell, 1 + c, val);
                 }
             }
@@ -465,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         if (D.any_contact && D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;   // read back by p2g.grad
         __syncthreads();
     }
-    tile_store<R, 4>(D, tile);
+    tile_store<R, 4>(D, tile, sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1), from_tile);
 }
 
 // boundary_condition :268-281 on a velocity; returns mask bits of the components that were zeroed
@@ -731,30 +780,42 @@ template <class R> struct WGrad {
 
 template <class R, bool ACC_X>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k_g2p_grad(DevSim<R> D, int f) {
-    __shared__ tile_t tile[3 * TILE_WORDS];
+    typedef typename ScatterTile<R>::word W;
+    __shared__ W tile[3 * TILE_WORDS];
     __shared__ Vec4<R> gt[TILE_WORDS];
+    __shared__ R smax[4];
     SMAC_CHUNK_PROLOGUE
-    for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
+    for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0);
     gather_tile_load(D, D.vout, ch.block, gt);
     __syncthreads();
+    R x[3] = {R(0.5), R(0.5), R(0.5)}, gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gC1[c] = R(0);
+    R bound = R(0);                       // no single scattered component of this particle exceeds it
     if (valid) {
         const R* Sf = frame(D.S, f, D.Npad);
         const R* An = D.An;
-        R* Af = frame(D.A, f, D.Npad);
-        R x[3], gx1[3], gv1[3], gC1[9];
+        R gv1[3];
         load_vec(Sf, CX, 3, D.Npad, p, x);
         load_vec(An, CX, 3, D.Npad, p, gx1);
         load_vec(An, CV, 3, D.Npad, p, gv1);
         load_vec(An, CC, 9, D.Npad, p, gC1);
-        Stencil<R> st;
-        Nodes nd;
-        stencil_at(D, x, st, nd, ch.block);
         const R four_inv_dx = R(4) * D.inv_dx;
-        R gnv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gnv[c] = gv1[c] + D.dt * gx1[c];                        // x' = x + dt v'
 #pragma unroll
         for (int c = 0; c < 9; ++c) gC1[c] *= four_inv_dx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)      // |w (gnv + gC (offset - fx))|
+            bound = maxc(bound, R(W_MAX) * abs_(gnv[c]) + R(WD_MAX) * (abs_(gC1[3 * c]) + abs_(gC1[3 * c + 1]) + abs_(gC1[3 * c + 2])));
+    }
+    R to_tile, from_tile;
+    tile_scale<R>(bound, smax, to_tile, from_tile);                                        // one barrier (all threads)
+    if (valid) {
+        R* Af = frame(D.A, f, D.Npad);
+        Stencil<R> st;
+        Nodes nd;
+        stencil_at(D, x, st, nd, ch.block);
         WGrad<R> wg;
         wg.zero();
         R gfx[3] = {R(0), R(0), R(0)};
@@ -791,7 +852,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
                         const R tk[3] = {tj[0] + R(k) * gC1[2], tj[1] + R(k) * gC1[5], tj[2] + R(k) * gC1[8]};
                         const R w = wij * st.w[k][2];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) lds_add(tile + tw + c * TILE_WORDS, w * tk[c]);
+                        for (int c = 0; c < 3; ++c) tile_add(tile + tw + c * TILE_WORDS, (w * to_tile) * tk[c]);
                         const R Q = g.x * tk[0] + g.y * tk[1] + g.z * tk[2];
                         aq += Q * st.w[k][2];
                         wg.g[k][2] += Q * wij;
@@ -832,7 +893,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
                 R gdp[3] = {R(0), R(0), R(0)};
                 for (int c = 0; c < 3; ++c) {
                     const R tt = gnv[c] + gC1[3 * c] * dp[0] + gC1[3 * c + 1] * dp[1] + gC1[3 * c + 2] * dp[2];
-                    if (in) lds_add(tile + tw + c * TILE_WORDS, w * tt);
+                    if (in) tile_add(tile + tw + c * TILE_WORDS, (w * to_tile) * tt);
                     else gatomic(D.aout, cell, c, w * tt);
                     gw += gvn[c] * tt;
                     for (int d = 0; d < 3; ++d) gdp[d] += gvn[c] * gC1[3 * c + d];
@@ -855,7 +916,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
         }
     }
     __syncthreads();
-    tile_store<R, 3>(D, tile);
+    tile_store<R, 3>(D, tile, from_tile, from_tile);
 }
 
 // completes the G2P-adjoint scatter: grid_v_out.grad += sum of overlapping slabs

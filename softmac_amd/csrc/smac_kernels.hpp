@@ -301,6 +301,17 @@ template <class R> __global__ void k_reset_contact_lists(DevSim<R> D) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }
 }
 
+// next free slot of a device-side list: the active lanes of the wave share ONE atomic on the counter
+__device__ __forceinline__ int hit_slot(int* counter) {
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)act) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(act));
+    base = __shfl(base, leader, 64);
+    return base + __popcll(act & ((1ull << lane) - 1ull));
+}
+
 // band test shared by k_contact and k_contact_grad: which primitives see this particle
 template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const R* x) {
     int mask = 0;
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
         cmask = contact_mask(D, f, x);
         if (cmask) {
             Hit h = {p, cmask, ch.block, 0};
-            D.hits[atomicAdd(D.nhits, 1)] = h;
+            D.hits[hit_slot(D.nhits)] = h;
         }
     }
     const int any = __syncthreads_or(cmask);
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
             cmask = contact_mask(D, f, x);
             if (cmask) {
                 Hit h = {p, cmask, ch.block, 0};
-                D.hits[atomicAdd(D.nhits, 1)] = h;
+                D.hits[hit_slot(D.nhits)] = h;
             }
         }
         f_tmp(C, E, D.dt, Et);
@@ -608,6 +619,10 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
     __shared__ tile_t tile[3 * TILE_WORDS];
+    // reaction wrenches are summed per workgroup in LDS and leave it once: every wave adding to the 6 P words of ext_f
+    // itself serialises in L2 (same cache line, ~35 ns per wave) and used to dominate this kernel
+    __shared__ double ext_acc[MAX_PRIMS * 6];
+    if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
     const int nc = *D.ncand;
     for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
         SMAC_CHUNK_PROLOGUE_AT(D.cand[ci])
@@ -645,7 +660,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const R sum = wave_sum(ext[c]);
-                if ((threadIdx.x & 63) == 0) atomic_add(D.ext_f + i * 6 + c, sum);
+                if ((threadIdx.x & 63) == 0 && sum != R(0))
+                    __hip_atomic_fetch_add(ext_acc + i * 6 + c, (double)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         if (mask) {
@@ -685,6 +701,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
         }
         __syncthreads();
     }
+    __syncthreads();
+    if (threadIdx.x < D.P * 6 && ext_acc[threadIdx.x] != 0.0) atomic_add(D.ext_f + threadIdx.x, (R)ext_acc[threadIdx.x]);
 }
 
 template <class R>
@@ -936,6 +954,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_aout(DevSim<R> D) {
 // times in one lane.  Lane n < 27 then owns stencil node n for the mixed2 scatter and the weight adjoints.
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
+    __shared__ double pg_acc[MAX_PRIMS * 13];         // primitive-state adjoints of this workgroup's hits (see k_contact)
+    if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
+    __syncthreads();
     const int nh = *D.nhits;
     const int grp = threadIdx.x >> 5, d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
     for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
@@ -1033,7 +1054,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             R sg = (act && d >= 6 && d < 19) ? out : R(0);
             sg += __shfl_xor(sg, 32, 64);
             if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != R(0))
-                atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + (d - 6), sg);
+                __hip_atomic_fetch_add(pg_acc + i * 13 + (d - 6), (double)sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
         if (mask) {
@@ -1064,6 +1085,11 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < D.P * 13 && pg_acc[threadIdx.x] != 0.0) {
+        const int i = threadIdx.x / 13, c = threadIdx.x % 13;
+        atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + c, (R)pg_acc[threadIdx.x]);
+    }
 }
 
 // Adjoint of the penalty contact impulse of p2g (collision_type 1) for the listed particles: the impulse's
@@ -1071,6 +1097,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
 // lane d < 19 runs forward-mode direction d (p_pos3, p_v3, state13).
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, int f) {
+    __shared__ double pg_acc[MAX_PRIMS * 13];         // primitive-state adjoints of this workgroup's hits (see k_contact)
+    if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
+    __syncthreads();
     const int nh = *D.nhits;
     const int grp = threadIdx.x >> 5, d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
     for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
@@ -1123,9 +1152,14 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
             R sg = (act && d >= 6 && d < 19) ? out : R(0);
             sg += __shfl_xor(sg, 32, 64);
             if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != R(0))
-                atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + (d - 6), sg);
+                __hip_atomic_fetch_add(pg_acc + i * 13 + (d - 6), (double)sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             (void)lane0;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < D.P * 13 && pg_acc[threadIdx.x] != 0.0) {
+        const int i = threadIdx.x / 13, c = threadIdx.x % 13;
+        atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + c, (R)pg_acc[threadIdx.x]);
     }
 }
 

@@ -35,7 +35,7 @@ __host__ __device__ __forceinline__ size_t cell_of(int nb, int i, int j, int k) 
 // host turns it into the number of substeps the binning stays valid for.
 template <class R>
 __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, const R* v1, const R* v2, int N, int n, int nb,
-                            R inv_dx, int* cell_count, int* key_out, int* slot_out, unsigned* vmax_bits) {
+                            R inv_dx, int* cell_count, int* key_out, int* slot_out, float* vmax_part) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     float vm = 0.f;
     if (p < N) {
@@ -43,7 +43,15 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, 
         vm = fmaxf(a, fmaxf(b, c));
     }
     for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o, 64));
-    if ((threadIdx.x & 63) == 0 && vm > 0.f) atomicMax(vmax_bits, __float_as_uint(vm));
+    // per-workgroup maxima go to an array (k_bin_masks folds it): thousands of atomics on one address would cost ~35 ns each
+    __shared__ float wg_max[16];
+    if ((threadIdx.x & 63) == 0) wg_max[threadIdx.x >> 6] = vm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = wg_max[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wg_max[w]);
+        vmax_part[blockIdx.x] = m;
+    }
     if (p >= N) return;
     const R x[3] = {x0[p], x1[p], x2[p]};
     int b[3];
@@ -60,7 +68,20 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, 
 // pass 1b, one wave per block: bin sizes and, per bin, the set of cells that own a particle of that rank
 // (bit c of mask[block*KMAX + r] <=> cell c holds more than r particles).  A particle's slot inside its bin is
 // the number of lower cells in the mask; the overflow bin (rank >= KMAX-1) uses a prefix sum of the excess counts.
-__global__ void k_bin_masks(int nblocks, const int* cell_count, int* bin_count, unsigned long long* mask, int* over_prefix) {
+__global__ void k_bin_masks(int nblocks, const int* cell_count, int* bin_count, unsigned long long* mask, int* over_prefix,
+                            const float* vmax_part, int nparts, float* vmax_out) {
+    if (blockIdx.x == gridDim.x - 1) {                           // fold the per-workgroup speed maxima of k_sort_rank
+        __shared__ float fold[16];
+        float m = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = fmaxf(m, vmax_part[i]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) fold[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, fold[w]);
+            *vmax_out = m;
+        }
+    }
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= nblocks) return;
     const int lane = threadIdx.x & 63;

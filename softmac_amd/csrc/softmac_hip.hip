@@ -137,6 +137,7 @@ template <class R> struct Sim final : ISim {
     unsigned long long* d_bin_mask = nullptr;
     int* d_over_prefix = nullptr;
     unsigned* d_vmax = nullptr;
+    float* d_vmax_part = nullptr;
     int *d_cell_count = nullptr, *d_bin = nullptr, *d_bin_start = nullptr, *d_key = nullptr, *d_slot = nullptr, *d_dest = nullptr;
     int *d_block_start = nullptr, *d_block_chunks = nullptr, *d_chunk_start = nullptr, *d_active_flag = nullptr, *d_active_start = nullptr;
     int* d_map = nullptr;
@@ -169,7 +170,7 @@ template <class R> struct Sim final : ISim {
         hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
         for (auto& e : epochs) free_epoch(e);
         for (auto& e : epoch_pool) free_epoch(e);
-        hipFree(d_bin_mask); hipFree(d_over_prefix); hipFree(d_vmax);
+        hipFree(d_bin_mask); hipFree(d_over_prefix); hipFree(d_vmax); hipFree(d_vmax_part);
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
@@ -270,6 +271,7 @@ template <class R> struct Sim final : ISim {
         sort_interval = c.sort_interval > 0 ? c.sort_interval : 16;
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_vmax, sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void**)&d_vmax_part, ((size_t)D.Npad / 64 + 8) * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&d_over_prefix, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_bin_mask, (size_t)nblocks * KMAX * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void**)&d_bin, ((size_t)nblocks * KMAX + 1) * sizeof(int)));
@@ -708,12 +710,11 @@ template <class R> struct Sim final : ISim {
         R* Sf = D.S + (size_t)f * frame_scalars();
         HIP_TRY(hipMemsetAsync(d_cell_count, 0, D.G * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_bin + nbins, 0, sizeof(int), stream));
-        HIP_TRY(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), stream));
         hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + D.Npad),
                            (const R*)(Sf + 2 * (size_t)D.Npad), (const R*)(Sf + 3 * (size_t)D.Npad), (const R*)(Sf + 4 * (size_t)D.Npad),
-                           (const R*)(Sf + 5 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax);
+                           (const R*)(Sf + 5 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax_part);
         hipLaunchKernelGGL(k_bin_masks, dim3((nblocks + 3) / 4), dim3(BLOCK), 0, stream, nblocks, (const int*)d_cell_count, d_bin,
-                           d_bin_mask, d_over_prefix);
+                           d_bin_mask, d_over_prefix, (const float*)d_vmax_part, nblk(D.N), (float*)d_vmax);
         int rc = scan(d_bin, d_bin_start, nbins + 1);
         if (rc) return rc;
         Epoch ep;

@@ -957,9 +957,16 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
     __shared__ double pg_acc[MAX_PRIMS * 13];         // primitive-state adjoints of this workgroup's hits (see k_contact)
     if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
     __syncthreads();
+    // grid_v_mixed.grad corrections of this workgroup's 8 hits are pre-reduced in an LDS tile over the block of its first
+    // hit (k_p2g appends a wave's hits contiguously, so the 8 nearly always share the block): neighbouring contact
+    // particles hit the same few nodes and their global atomics would serialise on those cache lines
+    __shared__ tile_t atile[3 * TILE_WORDS];
     const int nh = *D.nhits;
     const int grp = threadIdx.x >> 5, d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
     for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
+        for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) atile[i] = 0.0;
+        const int wg_block = D.hits[base].block;
+        __syncthreads();
         const int hi = base + grp;
         Hit h = {0, 0, 0, 0};
         if (hi < nh) h = D.hits[hi];
@@ -1062,8 +1069,14 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             const R gvt[3] = {gd[0] + g[0], gd[1] + g[1], gd[2] + g[2]};
             R gw = R(0);
             if (d < 27) {
+                const bool in_tile = h.block == wg_block && ((nd.okx >> ni) & (nd.oky >> nj) & (nd.okz >> nk) & 1) != 0;
+                const int tw = (ni == 0 ? nd.tx[0] : (ni == 1 ? nd.tx[1] : nd.tx[2])) + (nj == 0 ? nd.ty[0] : (nj == 1 ? nd.ty[1] : nd.ty[2])) +
+                               (nk == 0 ? nd.tz[0] : (nk == 1 ? nd.tz[1] : nd.tz[2]));
 #pragma unroll
-                for (int c = 0; c < 3; ++c) gatomic(D.amix, cell, c, wn * gvt[c]);
+                for (int c = 0; c < 3; ++c) {
+                    if (in_tile) lds_add(atile + tw + c * TILE_WORDS, wn * gvt[c]);
+                    else gatomic(D.amix, cell, c, wn * gvt[c]);
+                }
                 gw = vm.x * gvt[0] + vm.y * gvt[1] + vm.z * gvt[2]                           // mixed2: d/dw
                      - R(2) * has * (diff[0] * G.x + diff[1] * G.y + diff[2] * G.z);        // mixed4: d/dw
             }
@@ -1084,6 +1097,20 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                 Af[(size_t)(CX + d) * D.Npad + p] += gp + D.inv_dx * gf;
             }
         }
+        __syncthreads();
+        {
+            const int nb = D.nb;
+            const int bz = wg_block % nb, by = (wg_block / nb) % nb, bx = wg_block / (nb * nb);
+            for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
+                const R a0 = (R)atile[idx], a1 = (R)atile[TILE_WORDS + idx], a2 = (R)atile[2 * TILE_WORDS + idx];
+                if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
+                    const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
+                    const unsigned cell = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
+                    gatomic(D.amix, cell, 0, a0); gatomic(D.amix, cell, 1, a1); gatomic(D.amix, cell, 2, a2);
+                }
+            }
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x < D.P * 13 && pg_acc[threadIdx.x] != 0.0) {

@@ -82,6 +82,7 @@ template <class R> struct DevSim {
     int* nhits;
     int* cand;                   // chunks holding at least one such particle
     int* ncand;
+    int* last_counts;            // {nhits, ncand} of the last forward substep (k_g2p empties the lists)
     int* pmask;                  // per particle slot: bit i = inside primitive i's band (valid for candidate chunks)
     int any_contact;
     int cur_frame;               // frame of the substep being processed (kernels without an f argument)
@@ -295,10 +296,6 @@ __global__ __launch_bounds__(BLOCK) void k_clear_active(DevSim<R> D, Vec4<R>* ba
     const size_t cell = (size_t)D.active[a] * 64 + (threadIdx.x & 63);
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
     for (int f = 0; f < nfields; ++f) base[(size_t)f * D.G + cell] = z;
-}
-
-template <class R> __global__ void k_reset_contact_lists(DevSim<R> D) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }
 }
 
 // next free slot of a device-side list: the active lanes of the wave share ONE atomic on the counter
@@ -708,6 +705,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
 template <class R>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_g2p(DevSim<R> D, int f) {
     __shared__ Vec4<R> gt[TILE_WORDS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // last kernel of the substep: hand the contact lists back empty
+        D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
+        *D.nhits = 0; *D.ncand = 0;
+    }
     SMAC_CHUNK_PROLOGUE
     gather_tile_load(D, D.vout, ch.block, gt);
     __syncthreads();

@@ -233,11 +233,12 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(grid_block, 0, 6 * D.G * sizeof(Vec4<R>), stream));
         D.vin = grid_block; D.vmix = grid_block + D.G; D.vout = grid_block + 2 * D.G;
         D.ain = grid_block + 3 * D.G; D.amix = grid_block + 4 * D.G; D.aout = grid_block + 5 * D.G;
-        HIP_TRY(hipMalloc((void**)&d_nhits, 2 * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
+        HIP_TRY(hipMalloc((void**)&d_nhits, 4 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_nhits, 0, 4 * sizeof(int), stream));
         HIP_TRY(hipMalloc((void**)&d_hits, (size_t)D.Npad * sizeof(Hit)));
         HIP_TRY(hipMalloc((void**)&d_pmask, (size_t)D.Npad * sizeof(int)));
         D.nhits = d_nhits;
+        D.last_counts = d_nhits + 2;
         D.ncand = d_nhits + 1;
         D.hits = d_hits;
         D.pmask = d_pmask;
@@ -616,7 +617,7 @@ template <class R> struct Sim final : ISim {
     // particles inside a contact band / chunks holding one, as left by the most recent forward substep
     int contact_counts(int32_t* nhits, int32_t* nchunks_hit) override {
         int h[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(h, d_nhits, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h, d_nhits + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (nhits) *nhits = h[0];
         if (nchunks_hit) *nchunks_hit = h[1];
@@ -892,7 +893,6 @@ template <class R> struct Sim final : ISim {
             // it atomically) and is left zeroed by the checkpoint save of the previous substep
             if (is_recompute) hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 6);
             else if (!vin_clean) hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 1);
-            else hipLaunchKernelGGL(k_reset_contact_lists<R>, dim3(1), dim3(64), 0, stream, D);
             vin_clean = false;
             prof_end();
             prof_begin(K_P2G);

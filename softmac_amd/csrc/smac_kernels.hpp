@@ -22,6 +22,7 @@
 //   k_p2g_grad       p2g.grad + svd_grad :135-157 + compute_F_tmp.grad
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "smac_math.hpp"
 #include "smac_sort.hpp"
 
@@ -33,7 +34,7 @@ namespace smac {
 #define SMAC_OCC_HEAVY 2
 #endif
 #ifndef SMAC_OCC_G2PG
-#define SMAC_OCC_G2PG 4
+#define SMAC_OCC_G2PG 3
 #endif
 #ifndef SMAC_OCC_P2GG
 #define SMAC_OCC_P2GG 3
@@ -460,15 +461,19 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, ch.block);
-        if ((nd.okx & nd.oky & nd.okz) == 7) {             // whole stencil inside the tile: straight-line LDS atomics
-            // the scattered momentum is affine in the node offset: mom(i,j,k) = m0 + i a0 + j a1 + k a2 with
-            // a_d = dx * affine[:, d] and m0 = pv - affine (fx dx): three adds per node instead of nine FMAs
-            R m0[3], a0[3], a1[3], a2[3];
+        // the scattered momentum is affine in the node offset: mom(i,j,k) = m0 + i a0 + j a1 + k a2 with
+        // a_d = dx * affine[:, d] and m0 = pv - affine (fx dx): three adds per node instead of nine FMAs
+        R m0[3], a0[3], a1[3], a2[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                a0[c] = D.dx * aff[3 * c]; a1[c] = D.dx * aff[3 * c + 1]; a2[c] = D.dx * aff[3 * c + 2];
-                m0[c] = pv[c] - (a0[c] * st.fx[0] + a1[c] * st.fx[1] + a2[c] * st.fx[2]);
-            }
+        for (int c = 0; c < 3; ++c) {
+            a0[c] = D.dx * aff[3 * c]; a1[c] = D.dx * aff[3 * c + 1]; a2[c] = D.dx * aff[3 * c + 2];
+            m0[c] = pv[c] - (a0[c] * st.fx[0] + a1[c] * st.fx[1] + a2[c] * st.fx[2]);
+        }
+        // Every stencil of the wave inside the tile: straight-line LDS atomics.  Otherwise (a lane drifted out of its
+        // block since the last sort) the same unrolled code with a per-node choice LDS tile / global atomic - ONE pass
+        // for all lanes, where a separate slow loop would make the whole wave run both paths.
+        const bool wave_in = __all((nd.okx & nd.oky & nd.okz) == 7);
+        if (wave_in) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 R mi[3] = {m0[0] + R(i) * a0[0], m0[1] + R(i) * a0[1], m0[2] + R(i) * a0[2]};
@@ -487,27 +492,30 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
                     }
                 }
             }
-        } else {                                            // drifted out of the block since the last sort
-#pragma unroll 1
-            for (int n = 0; n < 27; ++n) {
-                const int i = n / 9, j = (n / 3) % 3, k = n % 3;
-                const R w = (i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0])) *
-                            (j == 0 ? st.w[0][1] : (j == 1 ? st.w[1][1] : st.w[2][1])) *
-                            (k == 0 ? st.w[0][2] : (k == 1 ? st.w[1][2] : st.w[2][2]));
-                const int cxi = i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2]);
-                const int cyj = j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2]);
-                const int czk = k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2]);
-                const int tw = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
-                               (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
-                const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
-                const R d0 = (R(i) - st.fx[0]) * D.dx, d1 = (R(j) - st.fx[1]) * D.dx, d2 = (R(k) - st.fx[2]) * D.dx;
-                const unsigned cell = (unsigned)(cxi + cyj + czk);
-                if (in) tile_add(tile + tw, w * mass_unit);
-                else gatomic(D.vin, cell, 0, w * D.p_mass);
-                for (int c = 0; c < 3; ++c) {
-                    const R val = w * (pv[c] + aff[3 * c] * d0 + aff[3 * c + 1] * d1 + aff[3 * c + 2] * d2);
-                    if (in) tile_add(tile + tw + (1 + c) * TILE_WORDS, val * to_tile);
-                    else gatomic(D.vin, cell, 1 + c, val);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                R mi[3] = {m0[0] + R(i) * a0[0], m0[1] + R(i) * a0[1], m0[2] + R(i) * a0[2]};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const R wij = st.w[i][0] * st.w[j][1];
+                    R mj[3] = {mi[0] + R(j) * a1[0], mi[1] + R(j) * a1[1], mi[2] + R(j) * a1[2]};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const R w = wij * st.w[k][2];
+                        const R val[3] = {w * (mj[0] + R(k) * a2[0]), w * (mj[1] + R(k) * a2[1]), w * (mj[2] + R(k) * a2[2])};
+                        if (nd.in_tile(i, j, k)) {
+                            W* tp = tile + nd.tile(i, j, k);
+                            tile_add(tp, w * mass_unit);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) tile_add(tp + (1 + c) * TILE_WORDS, val[c] * to_tile);
+                        } else {
+                            const unsigned cell = nd.cell(i, j, k);
+                            gatomic(D.vin, cell, 0, w * D.p_mass);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) gatomic(D.vin, cell, 1 + c, val[c]);
+                        }
+                    }
                 }
             }
         }
@@ -838,8 +846,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
         WGrad<R> wg;
         wg.zero();
         R gfx[3] = {R(0), R(0), R(0)};
-        if ((nd.okx & nd.oky & nd.okz) == 7) {
-            // Whole stencil inside the tile.  Everything is affine in the node offset:
+        {
+            // Everything is affine in the node offset:
             //   scatter  t(i,j,k)[c] = T0[c] + i gC[c][0] + j gC[c][1] + k gC[c][2],   T0 = gnv - gC f       (3 adds per node)
             //   weight adjoint  Q(i,j,k) = g(i,j,k) . t(i,j,k), folded along z, y, x into Gx,Gy,Gz
             //   dpos adjoint    gfx[d] = - sum_c gC[c][d] M0[c],  M0 = sum w g   (one 3-vector, not 27 x 9 products)
@@ -849,82 +857,63 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
             R M0[3] = {R(0), R(0), R(0)};
             R gwx[3] = {R(0), R(0), R(0)};
             const int tbase = nd.tx[0] + nd.ty[0] + nd.tz[0];
-            // one x-plane (9 nodes) per trip: rolled, so only 9 gathered records are live at a time
+            // One x-plane (9 nodes) per trip: rolled, so only 9 gathered records are live at a time.  MIXED = some lane
+            // of the wave drifted out of its block since the last sort: same code with a per-node choice between the LDS
+            // tiles and global memory - one pass for all lanes instead of a fast and a slow path run one after the other.
+            auto planes = [&](auto mixed_tag) {
+                constexpr bool MIXED = decltype(mixed_tag)::value;
 #pragma unroll 1
-            for (int i = 0; i < 3; ++i) {
-                const R fi = (R)i;
-                const R wxi = i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0]);
-                const int ti0 = tbase + i * TSX;
-                R ti[3] = {T0[0] + fi * gC1[0], T0[1] + fi * gC1[3], T0[2] + fi * gC1[6]};
-                R s0[3] = {R(0), R(0), R(0)};
-                R gxi = R(0);
+                for (int i = 0; i < 3; ++i) {
+                    const R fi = (R)i;
+                    const R wxi = i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0]);
+                    const int ti0 = tbase + i * TSX;
+                    const int cxi = i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2]);
+                    const int okxi = (nd.okx >> i) & 1;
+                    R ti[3] = {T0[0] + fi * gC1[0], T0[1] + fi * gC1[3], T0[2] + fi * gC1[6]};
+                    R s0[3] = {R(0), R(0), R(0)};
+                    R gxi = R(0);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const R wij = wxi * st.w[j][1];
-                    R tj[3] = {ti[0] + R(j) * gC1[1], ti[1] + R(j) * gC1[4], ti[2] + R(j) * gC1[7]};
-                    R aq = R(0);                    // sum_k Q wz_k
-                    R r0[3] = {R(0), R(0), R(0)};   // sum_k wz_k g
+                    for (int j = 0; j < 3; ++j) {
+                        const R wij = wxi * st.w[j][1];
+                        R tj[3] = {ti[0] + R(j) * gC1[1], ti[1] + R(j) * gC1[4], ti[2] + R(j) * gC1[7]};
+                        R aq = R(0);                    // sum_k Q wz_k
+                        R r0[3] = {R(0), R(0), R(0)};   // sum_k wz_k g
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int tw = ti0 + j * TSY + k;
-                        const Vec4<R> g = gt[tw];
-                        const R tk[3] = {tj[0] + R(k) * gC1[2], tj[1] + R(k) * gC1[5], tj[2] + R(k) * gC1[8]};
-                        const R w = wij * st.w[k][2];
+                        for (int k = 0; k < 3; ++k) {
+                            const int tw = ti0 + j * TSY + k;
+                            const bool in = !MIXED || (okxi & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
+                            const unsigned cell = (unsigned)(cxi + nd.cy[j] + nd.cz[k]);
+                            const Vec4<R> g = in ? gt[tw] : gld(D.vout, cell);
+                            const R tk[3] = {tj[0] + R(k) * gC1[2], tj[1] + R(k) * gC1[5], tj[2] + R(k) * gC1[8]};
+                            const R w = wij * st.w[k][2];
+                            if (in) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) tile_add(tile + tw + c * TILE_WORDS, (w * to_tile) * tk[c]);
-                        const R Q = g.x * tk[0] + g.y * tk[1] + g.z * tk[2];
-                        aq += Q * st.w[k][2];
-                        wg.g[k][2] += Q * wij;
-                        r0[0] += st.w[k][2] * g.x; r0[1] += st.w[k][2] * g.y; r0[2] += st.w[k][2] * g.z;
+                                for (int c = 0; c < 3; ++c) tile_add(tile + tw + c * TILE_WORDS, (w * to_tile) * tk[c]);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) gatomic(D.aout, cell, c, w * tk[c]);
+                            }
+                            const R Q = g.x * tk[0] + g.y * tk[1] + g.z * tk[2];
+                            aq += Q * st.w[k][2];
+                            wg.g[k][2] += Q * wij;
+                            r0[0] += st.w[k][2] * g.x; r0[1] += st.w[k][2] * g.y; r0[2] += st.w[k][2] * g.z;
+                        }
+                        gxi += aq * st.w[j][1];
+                        wg.g[j][1] += aq * wxi;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) s0[c] += st.w[j][1] * r0[c];
                     }
-                    gxi += aq * st.w[j][1];
-                    wg.g[j][1] += aq * wxi;
+                    gwx[0] += i == 0 ? gxi : R(0); gwx[1] += i == 1 ? gxi : R(0); gwx[2] += i == 2 ? gxi : R(0);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) s0[c] += st.w[j][1] * r0[c];
+                    for (int c = 0; c < 3; ++c) M0[c] += wxi * s0[c];
                 }
-                gwx[0] += i == 0 ? gxi : R(0); gwx[1] += i == 1 ? gxi : R(0); gwx[2] += i == 2 ? gxi : R(0);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) M0[c] += wxi * s0[c];
-            }
+            };
+            if (__all((nd.okx & nd.oky & nd.okz) == 7)) planes(std::false_type{});
+            else planes(std::true_type{});
 #pragma unroll
             for (int a = 0; a < 3; ++a) wg.g[a][0] += gwx[a];
 #pragma unroll
             for (int d = 0; d < 3; ++d) gfx[d] -= gC1[d] * M0[0] + gC1[3 + d] * M0[1] + gC1[6 + d] * M0[2];   // dpos = offset - fx
-        } else {
-#pragma unroll 1
-            for (int n = 0; n < 27; ++n) {                 // drifted particle: per-node test, global memory outside the tile
-                const int i = n / 9, j = (n / 3) % 3, k = n % 3;
-                const R wx = i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0]);
-                const R wy = j == 0 ? st.w[0][1] : (j == 1 ? st.w[1][1] : st.w[2][1]);
-                const R wz = k == 0 ? st.w[0][2] : (k == 1 ? st.w[1][2] : st.w[2][2]);
-                const int cxi = i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2]);
-                const int cyj = j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2]);
-                const int czk = k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2]);
-                const int tw = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
-                               (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
-                const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
-                const R w = wx * wy * wz;
-                const R dp[3] = {R(i) - st.fx[0], R(j) - st.fx[1], R(k) - st.fx[2]};
-                const unsigned cell = (unsigned)(cxi + cyj + czk);
-                const Vec4<R> g = gld(D.vout, cell);
-                const R gvn[3] = {g.x, g.y, g.z};
-                R gw = R(0);
-                R gdp[3] = {R(0), R(0), R(0)};
-                for (int c = 0; c < 3; ++c) {
-                    const R tt = gnv[c] + gC1[3 * c] * dp[0] + gC1[3 * c + 1] * dp[1] + gC1[3 * c + 2] * dp[2];
-                    if (in) tile_add(tile + tw + c * TILE_WORDS, (w * to_tile) * tt);
-                    else gatomic(D.aout, cell, c, w * tt);
-                    gw += gvn[c] * tt;
-                    for (int d = 0; d < 3; ++d) gdp[d] += gvn[c] * gC1[3 * c + d];
-                }
-                // weight adjoints with runtime offsets (rare path)
-                for (int a = 0; a < 3; ++a) {
-                    wg.g[a][0] += (a == i) ? gw * wy * wz : R(0);
-                    wg.g[a][1] += (a == j) ? gw * wx * wz : R(0);
-                    wg.g[a][2] += (a == k) ? gw * wx * wy : R(0);
-                }
-                for (int d = 0; d < 3; ++d) gfx[d] -= w * gdp[d];
-            }
         }
         wg.to_fx(st, gfx);
 #pragma unroll

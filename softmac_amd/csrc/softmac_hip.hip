@@ -269,7 +269,7 @@ template <class R> struct Sim final : ISim {
         D.open_x = (c.flags >> 1) & 3;                               // flags bits 1,2: neighbour slab at the low / high x end
         D.nb = c.n_grid / 4;
         nblocks = D.nb * D.nb * D.nb;
-        sort_interval = c.sort_interval > 0 ? c.sort_interval : 16;
+        sort_interval = c.sort_interval > 0 ? c.sort_interval : 32;
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_vmax, sizeof(unsigned)));
         HIP_TRY(hipMalloc((void**)&d_vmax_part, ((size_t)D.Npad / 64 + 8) * sizeof(float)));

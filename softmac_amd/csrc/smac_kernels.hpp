@@ -135,10 +135,11 @@ template <> __device__ __forceinline__ void tile_scale<float>(float bound, float
     if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = bound;
     __syncthreads();
     const float B = fmaxf(fmaxf(scratch4[0], scratch4[1]), fmaxf(scratch4[2], scratch4[3]));
-    // (a chunk whose largest contribution is below 1e-30 scatters zeros; a non-finite bound - an exploded state - does too)
+    // a chunk whose largest contribution is below 1e-30 scatters zeros; a non-finite bound (an exploded state) turns the
+    // chunk's nodes into NaN, as floating-point accumulation would have
     const bool usable = B > 1e-30f && B < 3e38f;
     to_tile = usable ? FIX_RANGE / B : 0.f;
-    from_tile = usable ? B * (1.0f / FIX_RANGE) : 0.f;
+    from_tile = usable ? B * (1.0f / FIX_RANGE) : (B <= 1e-30f ? 0.f : __builtin_nanf(""));
 }
 template <class R> __device__ __forceinline__ void lds_add(tile_t* p, R v) {
     __hip_atomic_fetch_add(p, (tile_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -43,7 +43,7 @@ namespace smac {
 #define SMAC_OCC_G2P 4
 #endif
 #ifndef SMAC_OCC_P2G
-#define SMAC_OCC_P2G 4
+#define SMAC_OCC_P2G 6
 #endif
 constexpr int BLOCK = 256;
 enum { CX = 0, CV = 3, CC = 6, CF = 15, NCOMP = 24 };

@@ -140,6 +140,11 @@ int smac_count_active_cells(smac_handle h, int f, int64_t* cells); /* cells with
  *   x.grad[f] += weight * d(chamfer)/dx  - what `with ti.ad.Tape(loss)` leaves in x.grad[f] for a loss weight `weight`. */
 int smac_loss_set_target(smac_handle h, const double* target, int m);
 int smac_loss_chamfer(smac_handle h, int f, double weight, int add_grad, double* loss_out);
+/* loss_door.py:49-61 / loss_transport.py:58-76: value = min over the particles with ids in [id_begin, id_end) of
+ * max(|x_i - center|^2 - offset, 0) at frame f.  out4 = {value, d(weight value^2)/d center}; with add_grad != 0 the seed
+ * d(weight value^2)/dx of the winning particle is added to x.grad[f] (Taichi's atomic_min routes the adjoint to the winner). */
+int smac_loss_min_dist(smac_handle h, int f, int id_begin, int id_end, const double center[3], double offset, double weight, int add_grad,
+                       double out4[4]);
 int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /* particles inside a contact band / work items holding one, last forward substep */
 
 /* ---- raw device views for the multi-GPU halo exchange (softmac_amd/parallel.py wraps them as

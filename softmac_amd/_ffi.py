@@ -81,6 +81,7 @@ SIGNATURES = {
     "smac_contact_counts": (C.c_int, [H, c_int32_p, c_int32_p]),
     "smac_loss_set_target": (C.c_int, [H, c_double_p, C.c_int]),
     "smac_loss_chamfer": (C.c_int, [H, C.c_int, C.c_double, C.c_int, c_double_p]),
+    "smac_loss_min_dist": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_double_p, C.c_double, C.c_double, C.c_int, c_double_p]),
     "smac_grid_device_ptr": (C.c_int, [H, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "smac_stream_handle": (C.c_int, [H, C.POINTER(C.c_void_p)]),
     "smac_set_stream": (C.c_int, [H, C.c_void_p]),

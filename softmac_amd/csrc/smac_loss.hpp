@@ -170,4 +170,46 @@ __global__ void k_chamfer_target_to_cur(int M, const double* target, PointIndex 
     if ((threadIdx.x & 63) == 0 && d2 != 0) atomicAdd(loss, d2);
 }
 
+// Contact-distance term of the door / transport losses (losses/loss_door.py:49-61, loss_transport.py:58-76):
+//   d_i = max(|x_i - c|^2 - offset, 0) over the particles whose caller-side id lies in [id0, id1);   value = min_i d_i
+// The winner is kept as (float bits of d, storage slot) packed in 64 bits, so one atomicMin finds value and argmin.
+template <class R>
+__global__ void k_min_dist(int N, const R* x0, const R* x1, const R* x2, const int* orig_id, int id0, int id1, double cx, double cy,
+                           double cz, double offset, unsigned long long* best) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long key = ~0ull;
+    if (p < N) {
+        const int id = orig_id ? orig_id[p] : p;
+        if (id >= id0 && id < id1) {
+            const double dx = (double)x0[p] - cx, dy = (double)x1[p] - cy, dz = (double)x2[p] - cz;
+            const float d = (float)fmax(dx * dx + dy * dy + dz * dz - offset, 0.0);
+            key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)p;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o, 64);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key != ~0ull && key < *best) atomicMin(best, key);
+}
+// value (f64, recomputed from the winner) and, on request, the seed of loss = weight * value^2 into x.grad[f][slot]
+template <class R>
+__global__ void k_min_dist_finish(const R* x0, const R* x1, const R* x2, const unsigned long long* best, double cx, double cy, double cz,
+                                  double offset, double weight, int add_grad, R* g0, R* g1, R* g2, double* out /* value, gcx, gcy, gcz */) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    const unsigned long long key = *best;
+    if (key == ~0ull) return;
+    const int p = (int)(key & 0xffffffffu);
+    const double dx = (double)x0[p] - cx, dy = (double)x1[p] - cy, dz = (double)x2[p] - cz;
+    const double raw = dx * dx + dy * dy + dz * dz - offset;
+    const double v = raw > 0.0 ? raw : 0.0;
+    out[0] = v;
+    if (v > 0.0) {                                   // d(weight v^2)/dx = 2 weight v * 2 (x - c);  -that for the centre
+        const double k = 4.0 * weight * v;
+        out[1] = -k * dx; out[2] = -k * dy; out[3] = -k * dz;
+        if (add_grad) { g0[p] += (R)(k * dx); g1[p] += (R)(k * dy); g2[p] += (R)(k * dz); }
+    }
+}
+
 }  // namespace smac

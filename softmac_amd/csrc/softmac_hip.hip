@@ -79,6 +79,7 @@ struct ISim {
     virtual int contact_counts(int32_t* nhits, int32_t* nchunks_hit) = 0;
     virtual int loss_set_target(const double* target, int m) = 0;
     virtual int loss_chamfer(int f, double weight, int add_grad, double* loss_out) = 0;
+    virtual int loss_min_dist(int f, int id0, int id1, const double* c3, double offset, double weight, int add_grad, double* out4) = 0;
     virtual int grid_ptr(const char* field, void** p, int64_t* n, int32_t* bytes) = 0;
     virtual int substep_phase_v(int f, int phase) = 0;
     virtual int substep_grad_phase_v(int f, const double* ext_f_grad, int phase) = 0;
@@ -175,7 +176,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
-        hipFree(d_target); hipFree(d_loss);
+        hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
         hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
         for (auto e : pool) hipEventDestroy(e);
@@ -589,18 +590,7 @@ template <class R> struct Sim final : ISim {
         const R* Sf = D.S + (size_t)f * frame_scalars();
         if ((rc = pi_build(pi_cur, D.N, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad, nullptr, e > 0 ? (const int*)epochs[e].orig : nullptr))) return rc;
         R* Af = nullptr;
-        if (add_grad) {
-            if ((rc = need_grad())) return rc;
-            if (adj_epoch[f] < 0) {
-                if ((rc = adj_make_zero(f))) return rc;
-            } else if (adj_epoch[f] != e) {                                   // seeds stored in another particle order
-                const R* tmp = nullptr;
-                if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
-                HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
-            }
-            adj_epoch[f] = e;
-            Af = D.A + (size_t)f * frame_scalars();
-        }
+        if (add_grad && (rc = adjoint_frame_for_seeding(f, &Af))) return rc;
         if (!d_loss) HIP_TRY(hipMalloc((void**)&d_loss, sizeof(double)));
         HIP_TRY(hipMemsetAsync(d_loss, 0, sizeof(double), stream));
         R* g0 = Af; R* g1 = Af ? Af + D.Npad : nullptr; R* g2 = Af ? Af + 2 * (size_t)D.Npad : nullptr;
@@ -612,6 +602,48 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemcpyAsync(&h, d_loss, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (loss_out) *loss_out = h;
+        return check_launch();
+    }
+    // adjoint frame f made addressable in the particle order of state frame f (zeroed / re-ordered as needed)
+    int adjoint_frame_for_seeding(int f, R** Af) {
+        int rc;
+        if ((rc = need_grad())) return rc;
+        const int e = frame_epoch[f];
+        if (adj_epoch[f] < 0) {
+            if ((rc = adj_make_zero(f))) return rc;
+        } else if (adj_epoch[f] != e) {
+            const R* tmp = nullptr;
+            if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
+            HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        }
+        adj_epoch[f] = e;
+        *Af = D.A + (size_t)f * frame_scalars();
+        return SMAC_OK;
+    }
+    unsigned long long* d_best = nullptr;
+    double* d_md_out = nullptr;
+    int loss_min_dist(int f, int id0, int id1, const double* c3, double offset, double weight, int add_grad, double* out4) override {
+        int rc;
+        if ((rc = check_frame(f))) return rc;
+        REQUIRE(c3 && out4, "null argument");
+        REQUIRE(frame_epoch[f] >= 0, "loss_min_dist: frame holds no state");
+        REQUIRE(id0 >= 0 && id0 < id1 && id1 <= D.N, "loss_min_dist: bad particle range");
+        const int e = frame_epoch[f];
+        const R* Sf = D.S + (size_t)f * frame_scalars();
+        R* Af = nullptr;
+        if (add_grad && (rc = adjoint_frame_for_seeding(f, &Af))) return rc;
+        if (!d_best) {
+            HIP_TRY(hipMalloc((void**)&d_best, sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&d_md_out, 4 * sizeof(double)));
+        }
+        HIP_TRY(hipMemsetAsync(d_best, 0xff, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(k_min_dist<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad,
+                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, id0, id1, c3[0], c3[1], c3[2], offset, d_best);
+        hipLaunchKernelGGL(k_min_dist_finish<R>, dim3(1), dim3(64), 0, stream, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad,
+                           (const unsigned long long*)d_best, c3[0], c3[1], c3[2], offset, weight, add_grad ? 1 : 0, Af,
+                           Af ? Af + D.Npad : (R*)nullptr, Af ? Af + 2 * (size_t)D.Npad : (R*)nullptr, d_md_out);
+        HIP_TRY(hipMemcpyAsync(out4, d_md_out, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         return check_launch();
     }
     // particles inside a contact band / chunks holding one, as left by the most recent forward substep
@@ -1462,6 +1494,10 @@ int smac_count_active_cells(smac_handle h, int f, int64_t* cells) { return FWD(c
 int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit) { return FWD(contact_counts(nhits, nchunks_hit)); }
 int smac_loss_set_target(smac_handle h, const double* target, int m) { return FWD(loss_set_target(target, m)); }
 int smac_loss_chamfer(smac_handle h, int f, double weight, int add_grad, double* loss_out) { return FWD(loss_chamfer(f, weight, add_grad, loss_out)); }
+int smac_loss_min_dist(smac_handle h, int f, int id_begin, int id_end, const double center[3], double offset, double weight, int add_grad,
+                       double out4[4]) {
+    return FWD(loss_min_dist(f, id_begin, id_end, center, offset, weight, add_grad, out4));
+}
 int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64_t* n_scalars, int32_t* scalar_bytes) {
     return FWD(grid_ptr(field, dev_ptr, n_scalars, scalar_bytes));
 }

@@ -1,3 +1,4 @@
 from .loss_chamfer import ChamferPoseLoss, GripLoss, PourLoss
+from .loss_contact import DoorLoss, TransportLoss
 
-__all__ = ["ChamferPoseLoss", "PourLoss", "GripLoss"]
+__all__ = ["ChamferPoseLoss", "PourLoss", "GripLoss", "DoorLoss", "TransportLoss"]

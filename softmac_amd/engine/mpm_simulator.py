@@ -269,6 +269,15 @@ class MPMSimulator:
         self._h.call("smac_loss_chamfer", int(f), C.c_double(float(weight)), 1 if add_grad else 0, C.byref(out))
         return float(out.value)
 
+    def loss_min_dist(self, f, id_begin, id_end, center, offset=0.01, weight=1.0, add_grad=False):
+        """min over particles [id_begin, id_end) of max(|x - center|^2 - offset, 0) at frame f, and the gradient of
+        weight * value^2 with respect to `center`; with add_grad the winner's x.grad[f] is seeded too."""
+        c = _ffi.as_f64(np.asarray(center, dtype=np.float64).reshape(3))
+        out = np.zeros(4)
+        self._h.call("smac_loss_min_dist", int(f), int(id_begin), int(id_end), _ffi.dptr(c), C.c_double(float(offset)),
+                     C.c_double(float(weight)), 1 if add_grad else 0, _ffi.dptr(out))
+        return float(out[0]), out[1:].copy()
+
     def contact_counts(self):
         """(particles inside a contact band, work items holding one) after the most recent forward substep."""
         a, b = C.c_int32(0), C.c_int32(0)

@@ -179,3 +179,53 @@ def test_fullsize_chamfer_far_and_near():
         assert abs(got - ref) < 1e-9 * ref, (shift, got, ref)
         assert H.rel_err(sim.get_grad(0)[0], g_ref) < 5e-6
         assert dt < 20.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("float64", 1e-12), ("float32", 2e-6)])
+def test_door_and_transport_losses(precision, tol):
+    """min-distance contact term on the device + host pose / velocity terms against numpy, including the seeds the tape
+    stand-in leaves in x.grad[f] and in the primitive's state adjoint; after two re-sorts, so ids and slots differ."""
+    import types
+    from softmac_amd.engine.losses import DoorLoss, TransportLoss
+    n = 5000
+    state = H.make_cloud(n, 64, seed=21, lo=(0.35, 0.35, 0.35), hi=(0.65, 0.65, 0.65))
+    d = H.load_palm()
+    spec = dict(d, friction=0.5, softness=666.0, contact=False)
+    q = np.array([0.95, 0.1, -0.2, 0.15]); q /= np.linalg.norm(q)
+    s13 = np.concatenate([[0.52, 0.9, 0.47], q, [0.1, -0.2, 0.05], [0.3, 0.2, -0.4]])
+    cfg = H.sim_cfg(n, n_grid=64, precision=precision, max_steps=8, sort_interval=2)
+    sim, prims = H.build_engine(cfg, 2e-3, [spec], [[s13]] * 8)
+    sim.reset(state)
+    sim.run_substeps(0, 4)
+    x = sim.get_x(4)
+    for cls, ncon in ((DoorLoss, 1), (TransportLoss, 2)):
+        loss = cls(types.SimpleNamespace(weight=(0.7, 0.3, 2.0)), sim)
+        loss.initialize()
+        if ncon == 2:
+            loss.set_target([0.4, 0.8, 0.5])
+        sim.clear_grads()
+        with loss.tape():
+            info = loss.compute_loss(4)
+        gx_ref = np.zeros((n, 3)); gp_ref = np.zeros(13); contact = 0.0
+        per = n // ncon
+        for k in range(ncon):
+            xs = x[k * per:(k + 1) * per]
+            dd = np.maximum(((xs - s13[:3]) ** 2).sum(1) - 0.01, 0.0)
+            i = int(dd.argmin()); v = dd[i]
+            contact += v * v
+            gx_ref[k * per + i] += 2.0 * 4.0 * v * (xs[i] - s13[:3])
+            gp_ref[:3] -= 2.0 * 4.0 * v * (xs[i] - s13[:3])
+        assert contact > 0
+        gp_ref[7:10] += 0.3 * 2 * s13[7:10]
+        if ncon == 1:
+            pose = (s13[3] - np.cos(np.pi / 8)) ** 2
+            gp_ref[3] += 0.7 * 2 * (s13[3] - np.cos(np.pi / 8))
+        else:
+            pose = ((s13[:3] - [0.4, 0.8, 0.5]) ** 2).sum()
+            gp_ref[:3] += 0.7 * 2 * (s13[:3] - [0.4, 0.8, 0.5])
+        assert abs(info["contact_loss"] - 2.0 * contact) < max(tol, 1e-9) * 2.0 * contact * 10
+        ptol = 1e-12 if precision == "float64" else 1e-7            # the primitive's state lives on the device in R
+        assert abs(info["pose_loss"] - 0.7 * pose) < ptol and abs(info["vel_loss"] - 0.3 * (s13[7:10] ** 2).sum()) < ptol
+        assert H.rel_err(sim.get_grad(4)[0], gx_ref) < tol * 10
+        assert H.rel_err(prims[0].get_all_states_grad(4), gp_ref) < tol * 10

@@ -145,7 +145,7 @@ int smac_loss_chamfer(smac_handle h, int f, double weight, int add_grad, double*
  * d(weight value^2)/dx of the winning particle is added to x.grad[f] (Taichi's atomic_min routes the adjoint to the winner). */
 int smac_loss_min_dist(smac_handle h, int f, int id_begin, int id_end, const double center[3], double offset, double weight, int add_grad,
                        double out4[4]);
-int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /* particles inside a contact band / work items holding one, last forward substep */
+int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /* particles inside a contact band after the last forward substep (nchunks_hit: retired, 0) */
 
 /* ---- raw device views for the multi-GPU halo exchange (softmac_amd/parallel.py wraps them as
  * torch tensors for torch.distributed/RCCL; no reference counterpart - SURVEY 8e). */

@@ -81,10 +81,10 @@ template <class R> struct DevSim {
     Vec4<R>* slab;               // [nchunks][TILE_WORDS] per-chunk tiles (P2G: {m,p} ; G2P adjoint: {grid_v_out.grad,0})
     struct Hit* hits;            // particles inside a contact band this frame (written by k_p2g)
     int* nhits;
-    int* cand;                   // chunks holding at least one such particle
+    int* cand;                   // (unused since the contact kernels walk the hit list; kept for the counter pair)
     int* ncand;
     int* last_counts;            // {nhits, ncand} of the last forward substep (k_g2p empties the lists)
-    int* pmask;                  // per particle slot: bit i = inside primitive i's band (valid for candidate chunks)
+    int* pmask;                  // per particle slot: bit i = inside primitive i's band (collision_type 1 only)
     int any_contact;
     int cur_frame;               // frame of the substep being processed (kernels without an f argument)
     const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
@@ -344,13 +344,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
             D.hits[hit_slot(D.nhits)] = h;
         }
     }
-    const int any = __syncthreads_or(cmask);
-    if (D.collision_type == CONTACT_PARTICLE) {
-        if (valid) D.pmask[p] = cmask;
-    } else if (any) {
-        if (valid) D.pmask[p] = cmask;
-        if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = cid;
-    }
+    if (D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;
 }
 
 // Grid checkpoint: the three value fields of the active blocks, packed [active slot][field][64 cells].
@@ -523,16 +517,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
             }
         }
     }
-    if (D.any_contact && D.collision_type == CONTACT_MIXED) {
-        const int any = __syncthreads_or(cmask);
-        if (any) {
-            if (valid) D.pmask[p] = cmask;
-            if (t == 0) D.cand[atomicAdd(D.ncand, 1)] = cid;
-        }
-    } else {
-        if (D.any_contact && D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;   // read back by p2g.grad
-        __syncthreads();
-    }
+    if (D.any_contact && D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;   // read back by p2g.grad
+    __syncthreads();
     tile_store<R, 4>(D, tile, sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1), from_tile);
 }
 
@@ -620,90 +606,84 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
             }
 }
 
-// grid_op_mixed2 + mixed3 + mixed4 for the chunks that hold particles inside a contact band.
-// The velocity corrections of a chunk are pre-reduced in an LDS tile and flushed once: contacting
-// particles share a few hundred grid nodes, and per-particle global atomics serialise on their cache lines.
-// The primitive loop is rolled (one copy of collide_mixed in the instruction stream).
+// grid_op_mixed2 + mixed3 + mixed4, one group of 32 lanes per particle of the hit list (the layout of k_contact_grad):
+// lane n < 27 owns stencil node n (gather of v_mixed, scatter of the correction), every lane evaluates the particle's
+// collide_mixed chain, 8 hits per workgroup share an LDS tile over the block of the first one.  (A per-chunk
+// form walking a candidate-chunk list and a per-particle mask took 24 instead of 17 us: three more dependent loads and
+// half as many busy workgroups.)
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_contact(DevSim<R> D, int f) {
-    __shared__ tile_t tile[3 * TILE_WORDS];
-    // reaction wrenches are summed per workgroup in LDS and leave it once: every wave adding to the 6 P words of ext_f
-    // itself serialises in L2 (same cache line, ~35 ns per wave) and used to dominate this kernel
+__global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
+    __shared__ tile_t ctile[3 * TILE_WORDS];
     __shared__ double ext_acc[MAX_PRIMS * 6];
     if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
-    const int nc = *D.ncand;
-    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
-        SMAC_CHUNK_PROLOGUE_AT(D.cand[ci])
-        for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = 0.0;
+    const int nh = *D.nhits;
+    const int grp = threadIdx.x >> 5, d = threadIdx.x & 31;
+    const R life = R(1) / R(D.substeps - f % D.substeps);                                   // :425
+    for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
+        for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) ctile[i] = 0.0;
+        const int wg_block = D.hits[base].block;
         __syncthreads();
-        const int mask = valid ? D.pmask[p] : 0;
+        const int hi = base + grp;
+        Hit h = {0, 0, 0, 0};
+        if (hi < nh) h = D.hits[hi];
+        const int mask = h.mask, p = h.p;
         R x[3] = {R(0.5), R(0.5), R(0.5)};
-        R v_tmp[3] = {R(0), R(0), R(0)}, v_tgt[3] = {R(0), R(0), R(0)};
+        if (mask) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
         Stencil<R> st;
         Nodes nd;
-        int mmask = 0;
-        if (mask) {
-            load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
-            stencil_at(D, x, st, nd, ch.block);
-            gather_vec(D, D.vmix, st, nd, v_tmp);                                           // mixed2
-            v_tgt[0] = v_tmp[0]; v_tgt[1] = v_tmp[1]; v_tgt[2] = v_tmp[2];
-            // which of the 27 nodes carry mass (mixed4's test): fetched here, all loads in flight together,
-            // instead of one dependent load per trip of the rolled scatter loop below
-#pragma unroll
-            for (int n = 0; n < 27; ++n)
-                mmask |= (gld(D.vin, nd.cell(n / 9, (n / 3) % 3, n % 3)).x > R(1e-10) ? 1 : 0) << n;
+        stencil_at(D, x, st, nd, h.block);
+        const int n = d < 27 ? d : 0;
+        const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+        const R wn = d < 27 ? (ni == 0 ? st.w[0][0] : (ni == 1 ? st.w[1][0] : st.w[2][0])) * (nj == 0 ? st.w[0][1] : (nj == 1 ? st.w[1][1] : st.w[2][1])) *
+                                  (nk == 0 ? st.w[0][2] : (nk == 1 ? st.w[1][2] : st.w[2][2]))
+                            : R(0);
+        const unsigned cell = (unsigned)((ni == 0 ? nd.cx[0] : (ni == 1 ? nd.cx[1] : nd.cx[2])) + (nj == 0 ? nd.cy[0] : (nj == 1 ? nd.cy[1] : nd.cy[2])) +
+                                         (nk == 0 ? nd.cz[0] : (nk == 1 ? nd.cz[1] : nd.cz[2])));
+        Vec4<R> vm = {R(0), R(0), R(0), R(0)};
+        bool has = false;
+        if (mask && d < 27) {
+            vm = gld(D.vmix, cell);
+            has = gld(D.vin, cell).x > R(1e-10);
         }
-        const R life = R(1) / R(D.substeps - f % D.substeps);                               // :425
+        R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v_tmp[c] += __shfl_xor(v_tmp[c], o, 64);
+        R v_tgt[3] = {v_tmp[0], v_tmp[1], v_tmp[2]};
 #pragma unroll 1
         for (int i = 0; i < D.P; ++i) {                                                     // mixed3
-            const bool act = (mask >> i) & 1;
-            if (!__ballot(act)) continue;
-            R ext[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
-            if (act) {
-                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-                R s13[13];
-                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, ext);
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const R sum = wave_sum(ext[c]);
-                if ((threadIdx.x & 63) == 0 && sum != R(0))
-                    __hip_atomic_fetch_add(ext_acc + i * 6 + c, (double)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!((mask >> i) & 1)) continue;
+            const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+            R s13[13], ext[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, ext);
+            if (d < 6) {                                                                    // lane c adds component c
+                const R e = d == 0 ? ext[0] : (d == 1 ? ext[1] : (d == 2 ? ext[2] : (d == 3 ? ext[3] : (d == 4 ? ext[4] : ext[5]))));
+                if (e != R(0)) __hip_atomic_fetch_add(ext_acc + i * 6 + d, (double)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        if (mask) {
-            const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
-#pragma unroll 1
-            for (int n = 0; n < 27; ++n) {                                                  // mixed4
-                const int i = n / 9, j = (n / 3) % 3, k = n % 3;
-                const R w = R(2) * (i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0])) *
-                            (j == 0 ? st.w[0][1] : (j == 1 ? st.w[1][1] : st.w[2][1])) *
-                            (k == 0 ? st.w[0][2] : (k == 1 ? st.w[1][2] : st.w[2][2]));         // alpha = 2, :437
-                const unsigned cell = (unsigned)((i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2])) + (j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2])) +
-                                                 (k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2])));
-                const int tw = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
-                               (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
-                const bool in = ((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
-                if ((mmask >> n) & 1) {
-                    for (int c = 0; c < 3; ++c) {
-                        if (in) lds_add(tile + tw + c * TILE_WORDS, -w * diff[c]);
-                        else gatomic(D.vout, cell, c, -w * diff[c]);
-                    }
-                }
+        if (mask && d < 27 && has) {                                                        // mixed4, alpha = 2 (:437)
+            const bool in_tile = h.block == wg_block && ((nd.okx >> ni) & (nd.oky >> nj) & (nd.okz >> nk) & 1) != 0;
+            const int tw = (ni == 0 ? nd.tx[0] : (ni == 1 ? nd.tx[1] : nd.tx[2])) + (nj == 0 ? nd.ty[0] : (nj == 1 ? nd.ty[1] : nd.ty[2])) +
+                           (nk == 0 ? nd.tz[0] : (nk == 1 ? nd.tz[1] : nd.tz[2]));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const R val = -R(2) * wn * (v_tmp[c] - v_tgt[c]);
+                if (in_tile) lds_add(ctile + tw + c * TILE_WORDS, val);
+                else gatomic(D.vout, cell, c, val);
             }
         }
         __syncthreads();
-        // flush the non-zero corrections of this chunk's tile
         {
             const int nb = D.nb;
-            const int bz = ch.block % nb, by = (ch.block / nb) % nb, bx = ch.block / (nb * nb);
-            for (int idx = t; idx < TILE_WORDS; idx += BLOCK) {
-                const R a0 = (R)tile[idx], a1 = (R)tile[TILE_WORDS + idx], a2 = (R)tile[2 * TILE_WORDS + idx];
+            const int bz = wg_block % nb, by = (wg_block / nb) % nb, bx = wg_block / (nb * nb);
+            for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
+                const R a0 = (R)ctile[idx], a1 = (R)ctile[TILE_WORDS + idx], a2 = (R)ctile[2 * TILE_WORDS + idx];
                 if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
                     const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
-                    const unsigned cell = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
-                    gatomic(D.vout, cell, 0, a0); gatomic(D.vout, cell, 1, a1); gatomic(D.vout, cell, 2, a2);
+                    const unsigned c2 = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
+                    gatomic(D.vout, c2, 0, a0); gatomic(D.vout, c2, 1, a1); gatomic(D.vout, c2, 2, a2);
                 }
             }
         }

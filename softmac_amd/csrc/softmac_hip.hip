@@ -905,7 +905,6 @@ template <class R> struct Sim final : ISim {
     }
     int ngrid_blocks() const { return (D.nactive + 3) / 4; }
     int nchunk_blocks() const { return ((D.nchunks + 7) / 8) * 8; }   // XCD-aware chunk mapping (xcd_chunk) needs a multiple of 8
-    int contact_grid() const { return D.nchunks < 1024 ? D.nchunks : 1024; }  // fixed grid walking the candidate-chunk list
     // hit list: 8 hits per workgroup and pass; the count lives on the device, so size the grid for the chip (a group
     // that finds no hit left exits at once) - a short grid turns the list into a serial chain of SDF-lookup latencies
     int contact_grad_grid() const { const int need = (D.N + 7) / 8; return need < 2048 ? (need > 0 ? need : 1) : 2048; }
@@ -944,7 +943,7 @@ template <class R> struct Sim final : ISim {
         prof_end();
         if (stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED) {
             prof_begin(K_CONTACT);
-            hipLaunchKernelGGL(k_contact<R>, dim3(contact_grid()), dim3(BLOCK), 0, stream, Dc, f);
+            hipLaunchKernelGGL(k_contact_hits<R>, dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
         }
         return check_launch();

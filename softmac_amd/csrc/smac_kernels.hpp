@@ -257,23 +257,48 @@ template <class R, int NS, class W> __device__ __forceinline__ void tile_store(c
 // along each dimension in which the cell's local coordinate is <= 1).
 template <class R>
 __device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, Vec4<R>& acc) {
+    // Called by a whole wave for the 64 cells of block b.  The <= 8 source blocks (b and its -1 neighbours) are the same
+    // for every lane: lanes 0..7 fetch their chunk ranges in ONE round trip and broadcast them; then up to 4 slab
+    // records per source are loaded back to back (predicated), so the loads overlap instead of forming a chain of
+    // ~24 dependent L2 round trips per wave (which is what made the grid kernels take 15 us).
     const int nb = D.nb;
     const int bz = b % nb, by = (b / nb) % nb, bx = b / (nb * nb);
     const int lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
-    const int ex = (lx <= 1 && bx > 0) ? 1 : 0, ey = (ly <= 1 && by > 0) ? 1 : 0, ez = (lz <= 1 && bz > 0) ? 1 : 0;
-    for (int dx = 0; dx <= ex; ++dx)
-        for (int dy = 0; dy <= ey; ++dy)
-            for (int dz = 0; dz <= ez; ++dz) {
-                const int src = ((bx - dx) * nb + (by - dy)) * nb + (bz - dz);
-                const int nch = D.block_chunks[src];
-                if (nch == 0) continue;
-                const int w = tile_index(lx + 4 * dx, ly + 4 * dy, lz + 4 * dz);
-                const Vec4<R>* sl = D.slab + (size_t)D.block_chunk_start[src] * TILE_WORDS + w;
-                for (int c = 0; c < nch; ++c, sl += TILE_WORDS) {
-                    const Vec4<R> v = *sl;
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                }
+    const int ex = (lx <= 1) ? 1 : 0, ey = (ly <= 1) ? 1 : 0, ez = (lz <= 1) ? 1 : 0;
+    const int lane = threadIdx.x & 63;
+    int my_nch = 0, my_start = 0;
+    if (lane < 8) {
+        const int sx = bx - (lane >> 2), sy = by - ((lane >> 1) & 1), sz = bz - (lane & 1);
+        if (sx >= 0 && sy >= 0 && sz >= 0) {
+            const int src = (sx * nb + sy) * nb + sz;
+            my_nch = D.block_chunks[src];
+            my_start = D.block_chunk_start[src];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int nch = __shfl(my_nch, q, 64), start = __shfl(my_start, q, 64);        // wave-uniform
+        if (nch == 0) continue;
+        const int dx = q >> 2, dy = (q >> 1) & 1, dz = q & 1;
+        const bool mine = dx <= ex && dy <= ey && dz <= ez;
+        const int w = tile_index(lx + 4 * dx, ly + 4 * dy, lz + 4 * dz);
+        const Vec4<R>* sl = D.slab + (size_t)start * TILE_WORDS + w;
+        const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+        Vec4<R> v0 = z, v1 = z, v2 = z, v3 = z;
+        if (mine) {
+            v0 = sl[0];
+            if (nch > 1) v1 = sl[TILE_WORDS];
+            if (nch > 2) v2 = sl[2 * TILE_WORDS];
+            if (nch > 3) v3 = sl[3 * TILE_WORDS];
+        }
+        acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+        acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+        if (mine)
+            for (int c = 4; c < nch; ++c) {
+                const Vec4<R> v = sl[(size_t)c * TILE_WORDS];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
+    }
 }
 
 // Stage the 6x6x6 node records of `field` around this chunk's block into LDS (gather tile).

@@ -1,0 +1,58 @@
+// Microbenchmark: streaming one particle frame (read 3 scalars, write 15 per particle - the traffic of k_g2p) with
+//   SoA rows      addr(c, p) = c * Npad + p
+//   AoSoA tiles   addr(c, p) = (p / 64) * (NC * 64) + c * 64 + (p % 64)
+// Build: hipcc --offload-arch=gfx950 -O3 frame_layout.hip -o frame_layout
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+constexpr int NC = 24;
+template <bool TILED> __device__ __forceinline__ size_t at(int c, int p, int Npad) {
+    return TILED ? (size_t)(p >> 6) * (NC * 64) + (size_t)c * 64 + (p & 63) : (size_t)c * Npad + p;
+}
+template <bool TILED, int NR, int NW>
+__global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* __restrict__ dst, int N, int Npad, int work) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < NR; ++c) acc += src[at<TILED>(c, p, Npad)];
+    for (int i = 0; i < work; ++i) acc = acc * 1.0001f + 0.5f;          // stand-in for the stencil arithmetic
+#pragma unroll
+    for (int c = 0; c < NW; ++c) dst[at<TILED>(c + 3, p, Npad)] = acc + c;
+}
+
+template <bool TILED, int NR, int NW> void run(const char* name, float* a, float* b, int N, int Npad, int work) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<TILED, NR, NW>), dim3((N + 255) / 256), dim3(256), 0, 0, a, b, N, Npad, work);
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL((k<TILED, NR, NW>), dim3((N + 255) / 256), dim3(256), 0, 0, a, b, N, Npad, work);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)N * 4 * (NR + NW);
+    printf("%-34s read %2d write %2d work %4d : %7.1f us  %6.2f TB/s\n", name, NR, NW, work, ms / 20 * 1e3, bytes / (ms / 20 * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
+    const int N = 1 << 20;
+    float *a, *b;
+    (void)hipMalloc(&a, (size_t)NC * (N + (1 << 20)) * 4);
+    (void)hipMalloc(&b, (size_t)NC * (N + (1 << 20)) * 4);
+    (void)hipMemset(a, 0, (size_t)NC * (N + (1 << 20)) * 4);
+    // row-stride skews (scalars) for the SoA layout: does the g2p-like slowdown depend on the stride between rows?
+    for (int skew : {0, 32, 96, 160, 224, 4128, 4192, 4160, 32 * 17, 32 * 33, 32 * 65}) {
+        char name[64];
+        snprintf(name, sizeof name, "SoA skew %6d (g2p-like)", skew);
+        run<false, 3, 15>(name, a, b, N, N + skew, 256);
+    }
+    run<true, 3, 15>("AoSoA 64   (g2p-like)", a, b, N, N, 256);
+    for (int skew : {0, 4160, 4128, 32 * 33}) {
+        char name[64];
+        snprintf(name, sizeof name, "SoA skew %6d (p2g_grad-like)", skew);
+        run<false, 21, 21>(name, a, b, N, N + skew, 256);
+    }
+    run<true, 21, 21>("AoSoA 64   (p2g_grad-like)", a, b, N, N, 256);
+    return 0;
+}

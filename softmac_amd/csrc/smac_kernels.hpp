@@ -754,9 +754,10 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
         R s0[3] = {R(0), R(0), R(0)}, sy[3] = {R(0), R(0), R(0)}, sz[3] = {R(0), R(0), R(0)};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const Vec4<R> g0 = all_in ? gt[nd.tile(i, j, 0)] : gld(D.vout, nd.cell(i, j, 0));
-            const Vec4<R> g1 = all_in ? gt[nd.tile(i, j, 1)] : gld(D.vout, nd.cell(i, j, 1));
-            const Vec4<R> g2 = all_in ? gt[nd.tile(i, j, 2)] : gld(D.vout, nd.cell(i, j, 2));
+            // LDS reads are unconditional (index 0 for a drifted lane) so that they can be issued in batches; the global
+            // loads of drifted lanes sit behind a branch no wave without such a lane takes
+            Vec4<R> g0 = gt[all_in ? nd.tile(i, j, 0) : 0], g1 = gt[all_in ? nd.tile(i, j, 1) : 0], g2 = gt[all_in ? nd.tile(i, j, 2) : 0];
+            if (!all_in) { g0 = gld(D.vout, nd.cell(i, j, 0)); g1 = gld(D.vout, nd.cell(i, j, 1)); g2 = gld(D.vout, nd.cell(i, j, 2)); }
             const R r0[3] = {st.w[0][2] * g0.x + st.w[1][2] * g1.x + st.w[2][2] * g2.x, st.w[0][2] * g0.y + st.w[1][2] * g1.y + st.w[2][2] * g2.y,
                              st.w[0][2] * g0.z + st.w[1][2] * g1.z + st.w[2][2] * g2.z};
             const R r1[3] = {wz1 * g1.x + wz2 * g2.x, wz1 * g1.y + wz2 * g2.y, wz1 * g1.z + wz2 * g2.z};
@@ -1370,7 +1371,8 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
             R r0[3] = {R(0), R(0), R(0)}, r1[3] = {R(0), R(0), R(0)};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const Vec4<R> a = all_in ? gt[txi + nd.ty[j] + nd.tz[k]] : gld(D.ain, (unsigned)(cxi + nd.cy[j] + nd.cz[k]));
+                Vec4<R> a = gt[all_in ? txi + nd.ty[j] + nd.tz[k] : 0];      // unconditional LDS read (see k_g2p)
+                if (!all_in) a = gld(D.ain, (unsigned)(cxi + nd.cy[j] + nd.cz[k]));
                 const R Q = a.x * D.p_mass + a.y * (mj[0] + R(k) * a2[0]) + a.z * (mj[1] + R(k) * a2[1]) + a.w * (mj[2] + R(k) * a2[2]);
                 aq += Q * st.w[k][2];
                 wg.g[k][2] += Q * wij;

@@ -892,7 +892,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
                             const int tw = ti0 + j * TSY + k;
                             const bool in = !MIXED || (okxi & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
                             const unsigned cell = (unsigned)(cxi + nd.cy[j] + nd.cz[k]);
-                            const Vec4<R> g = in ? gt[tw] : gld(D.vout, cell);
+                            Vec4<R> g = gt[in ? tw : 0];                 // unconditional LDS read (see k_g2p)
+                            if (MIXED && !in) g = gld(D.vout, cell);
                             const R tk[3] = {tj[0] + R(k) * gC1[2], tj[1] + R(k) * gC1[5], tj[2] + R(k) * gC1[8]};
                             const R w = wij * st.w[k][2];
                             if (in) {

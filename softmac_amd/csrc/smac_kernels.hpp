@@ -421,8 +421,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     __shared__ W tile[4 * TILE_WORDS];
     __shared__ R smax[4];
     SMAC_CHUNK_PROLOGUE
-    for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = W(0);
-    __syncthreads();
+    for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = W(0);     // (made visible by the barrier inside tile_scale)
     int cmask = 0;
     R x[3] = {R(0.5), R(0.5), R(0.5)}, pv[3] = {R(0), R(0), R(0)}, aff[9];
 #pragma unroll
@@ -726,13 +725,13 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
         *D.nhits = 0; *D.ncand = 0;
     }
     SMAC_CHUNK_PROLOGUE
-    gather_tile_load(D, D.vout, ch.block, gt);
-    __syncthreads();
-    if (!valid) return;
     const R* Sf = frame(D.S, f, D.Npad);
     R* Sn = frame(D.S, f + 1, D.Npad);
     R x[3];
-    load_vec(Sf, CX, 3, D.Npad, p, x);
+    load_vec(Sf, CX, 3, D.Npad, p, x);              // issued before the tile load's barrier: one round trip, not two
+    gather_tile_load(D, D.vout, ch.block, gt);
+    __syncthreads();
+    if (!valid) return;
     Stencil<R> st;
     Nodes nd;
     stencil_at(D, x, st, nd, ch.block);
@@ -822,8 +821,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     __shared__ R smax[4];
     SMAC_CHUNK_PROLOGUE
     for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0);
-    gather_tile_load(D, D.vout, ch.block, gt);
-    __syncthreads();
+    gather_tile_load(D, D.vout, ch.block, gt);      // (its barrier is the one inside tile_scale below: the particle loads
+                                                    //  that follow are then in flight together with the tile's)
     R x[3] = {R(0.5), R(0.5), R(0.5)}, gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) gC1[c] = R(0);

@@ -21,10 +21,27 @@ class McPrim(C.Structure):
                 ("upper", C.c_double * 3), ("sdf_dx", C.c_double), ("friction", C.c_double), ("softness", C.c_double)]
 
 
+def _cpu_stamp():
+    """The library is built with -march=native: a copy that travelled from another machine must be rebuilt."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                import hashlib
+                return hashlib.sha1(line.encode()).hexdigest()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def load():
     so = HERE / "_build" / "libmpm_cpu.so"
-    if not so.exists() or so.stat().st_mtime < (HERE / "mpm_cpu.cpp").stat().st_mtime:
-        subprocess.check_call(["make", "-C", str(HERE), "-s"])
+    stamp = HERE / "_build" / "cpu.stamp"
+    stale = not so.exists() or so.stat().st_mtime < (HERE / "mpm_cpu.cpp").stat().st_mtime
+    if not stale and (not stamp.exists() or stamp.read_text() != _cpu_stamp()):
+        stale = True
+    if stale:
+        subprocess.check_call(["make", "-C", str(HERE), "-s", "-B"])
+        stamp.write_text(_cpu_stamp())
     lib = C.CDLL(str(so))
     lib.mc_threads.restype = C.c_int
     return lib

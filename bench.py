@@ -202,8 +202,9 @@ def main():
             "value": value, "unit": "substeps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * wall / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
-                                   f"3 gripper SDF primitives (2 in forecast contact), fwd+bwd",
+            "config": {"workload": (f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
+                                    f"3 gripper SDF primitives (2 in forecast contact), fwd+bwd") if args.workload == "s-grip" else
+                                   f"{args.workload}: {N} particles, {args.grid}^3 grid, elastic fixed-corotated, no primitives, fwd+bwd",
                        "particles_per_gpu": N, "n_grid": args.grid, "touched_cells": G_t, "contact_particles": n_hits,
                        "backward": "forward grid recomputed in substep_grad (reference style)" if args.recompute_backward
                        else "forward grid restored from the per-frame checkpoint saved by substep",

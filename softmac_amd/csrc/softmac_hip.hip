@@ -919,13 +919,14 @@ template <class R> struct Sim final : ISim {
         DevSim<R> Dc = D;                                       // the recompute pass must not double-count ext_f
         if (is_recompute) Dc.ext_f = scratch_ext();
         if (stage != 2) {
-            prof_begin(K_CLEAR);
             // grid_op rewrites v_mixed / v_out of every active cell; {m,p} must start from zero (drifted particles add to
             // it atomically) and is left zeroed by the checkpoint save of the previous substep
-            if (is_recompute) hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 6);
-            else if (!vin_clean) hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 1);
+            if (is_recompute || !vin_clean) {
+                prof_begin(K_CLEAR);
+                hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 1);
+                prof_end();
+            }
             vin_clean = false;
-            prof_end();
             prof_begin(K_P2G);
             if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
             else hipLaunchKernelGGL((k_p2g<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);

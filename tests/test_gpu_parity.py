@@ -271,3 +271,27 @@ def test_particle_and_grid_contact_models(precision, collision_type):
     # the recompute path (no grid checkpoint) must give the same adjoints
     cfg2 = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, precision=precision, collision_type=collision_type, recompute_backward=True)
     _compare_rollout(cfg2, 1e-3, state, 2, specs, pstates, ext_f_grad=eg, tol=tol)
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_forward_only_handle_matches_and_refuses_gradients(precision):
+    """grad_enabled = 0 (no adjoint frames, no grid checkpoints - a different launch sequence per substep): the forward
+    rollout with forecast contact must equal the differentiable handle's, and gradient entry points must fail loudly."""
+    from softmac_amd import _ffi
+    state = np.load(H.GOLDEN / "grip_state_2k.npz")["state"]
+    specs, pstates = _palm_scene(state, 7)
+    outs = []
+    for grad in (True, False):
+        cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, precision=precision, max_steps=8, sort_interval=3, grad_enabled=grad)
+        sim, prims = H.build_engine(cfg, 2e-3, specs, pstates)
+        sim.reset(state)
+        sim.run_substeps(0, 7)
+        outs.append((sim.get_state(7), prims[0].ext_f.to_numpy()))
+        if not grad:
+            with pytest.raises(_ffi.SmacError, match="grad_enabled"):
+                sim.substep_grad(6)
+            with pytest.raises(_ffi.SmacError, match="grad_enabled"):
+                sim.add_grad(7, gx=np.zeros((len(state), 3)))
+    tol = 1e-12 if precision == "float64" else 1e-5
+    assert H.rel_err(outs[1][0], outs[0][0]) < tol
+    assert H.rel_err(outs[1][1], outs[0][1]) < max(tol, 1e-9) * 10

@@ -19,7 +19,7 @@ CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libsoftmac_hip.so"
 SOURCES = [CSRC / "softmac_hip.hip"]
-DEPS = [CSRC / "smac_kernels.hpp", CSRC / "smac_math.hpp", ROOT.parent / "include" / "softmac_hip.h"]
+DEPS = sorted(CSRC.glob("*.hpp")) + [ROOT.parent / "include" / "softmac_hip.h"]
 ARCH = "gfx950"
 
 

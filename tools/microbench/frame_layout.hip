@@ -6,10 +6,13 @@
 #include <cstdio>
 
 constexpr int NC = 24;
-template <bool TILED> __device__ __forceinline__ size_t at(int c, int p, int Npad) {
-    return TILED ? (size_t)(p >> 6) * (NC * 64) + (size_t)c * 64 + (p & 63) : (size_t)c * Npad + p;
+// TILED: 0 = SoA rows, 1 = AoSoA tiles of 64 particles, 2 = AoSoA tiles of 4096 particles (16 KB per component)
+template <int TILED> __device__ __forceinline__ size_t at(int c, int p, int Npad) {
+    if (TILED == 1) return (size_t)(p >> 6) * (NC * 64) + (size_t)c * 64 + (p & 63);
+    if (TILED == 2) return (size_t)(p >> 12) * (NC * 4096) + (size_t)c * 4096 + (p & 4095);
+    return (size_t)c * Npad + p;
 }
-template <bool TILED, int NR, int NW>
+template <int TILED, int NR, int NW>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* __restrict__ dst, int N, int Npad, int work) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= N) return;
@@ -57,7 +60,7 @@ template <int NR, int NW> void run_staged(const char* name, float* a, float* b, 
     printf("%-34s read %2d write %2d work %4d : %7.1f us  %6.2f TB/s\n", name, NR, NW, work, ms / 20 * 1e3, bytes / (ms / 20 * 1e-3) / 1e12);
 }
 
-template <bool TILED, int NR, int NW> void run(const char* name, float* a, float* b, int N, int Npad, int work) {
+template <int TILED, int NR, int NW> void run(const char* name, float* a, float* b, int N, int Npad, int work) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipLaunchKernelGGL((k<TILED, NR, NW>), dim3((N + 255) / 256), dim3(256), 0, 0, a, b, N, Npad, work);
@@ -81,16 +84,18 @@ int main(int argc, char** argv) {
     for (int skew : {0, 4160}) {
         char name[64];
         snprintf(name, sizeof name, "SoA skew %6d (g2p-like)", skew);
-        run<false, 3, 15>(name, a, b, N, N + skew, 256);
+        run<0, 3, 15>(name, a, b, N, N + skew, 256);
     }
-    run<true, 3, 15>("AoSoA 64   (g2p-like)", a, b, N, N, 256);
+    run<1, 3, 15>("AoSoA 64   (g2p-like)", a, b, N, N, 256);
+    run<2, 3, 15>("AoSoA 4096 (g2p-like)", a, b, N, N, 256);
     run_staged<3, 15>("SoA staged 1 KB runs (g2p-like)", a, b, N, N + 4160, 256);
     run_staged<21, 21>("SoA staged 1 KB runs (p2g_grad)", a, b, N, N + 4160, 256);
     for (int skew : {0, 4160, 4128, 32 * 33}) {
         char name[64];
         snprintf(name, sizeof name, "SoA skew %6d (p2g_grad-like)", skew);
-        run<false, 21, 21>(name, a, b, N, N + skew, 256);
+        run<0, 21, 21>(name, a, b, N, N + skew, 256);
     }
-    run<true, 21, 21>("AoSoA 64   (p2g_grad-like)", a, b, N, N, 256);
+    run<1, 21, 21>("AoSoA 64   (p2g_grad-like)", a, b, N, N, 256);
+    run<2, 21, 21>("AoSoA 4096 (p2g_grad-like)", a, b, N, N, 256);
     return 0;
 }

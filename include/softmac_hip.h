@@ -93,6 +93,7 @@ int smac_sync(smac_handle h);
 int smac_reset(smac_handle h, const double* state, int cols);                 /* reset :514-519, cols = 3 or 24 */
 int smac_set_frame(smac_handle h, int f, const double* x, const double* v, const double* F, const double* C); /* setframe/set_x/set_v */
 int smac_get_frame(smac_handle h, int f, double* x, double* v, double* F, double* C);                         /* readframe/get_x/get_v */
+int smac_get_state(smac_handle h, int f, double* state24);                                                     /* get_state :541-548: (N,24) = x3 v3 F9 C9 in one transfer */
 int smac_copy_frame(smac_handle h, int src, int dst);                         /* copyframe :468-479 (particles + primitives) */
 int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC);   /* get_grad :570-574 (+F,C) */
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC); /* loss kernels' `x.grad[f,i] +=` */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "smac_reset": (C.c_int, [H, c_double_p, C.c_int]),
     "smac_set_frame": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
     "smac_get_frame": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "smac_get_state": (C.c_int, [H, C.c_int, c_double_p]),
     "smac_copy_frame": (C.c_int, [H, C.c_int, C.c_int]),
     "smac_get_grad": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
     "smac_add_grad": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),

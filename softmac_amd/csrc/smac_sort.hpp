@@ -118,6 +118,36 @@ __global__ void k_sort_dest(int N, const int* key, const int* slot, const int* b
     orig_new[q] = orig_old ? orig_old[p] : p;
 }
 
+// Host IO: f64 AOS arrays in the caller's particle order <-> component rows of a frame in the order of an epoch
+// (orig[q] = caller's id of the particle in slot q; nullptr = identity).  `ident`: the rows hold F - I, the host sees F.
+template <class R>
+__global__ void k_rows_from_aos(int N, int Npad, const double* src, int stride, int offset, int cnt, const int* orig, int ident, R* rows) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Npad) return;
+    const size_t id = q < N ? (size_t)(orig ? orig[q] : q) : 0;
+    for (int c = 0; c < cnt; ++c) {
+        const double sub = (ident && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
+        rows[(size_t)c * Npad + q] = q < N ? (R)(src[id * stride + offset + c] - sub) : R(0);
+    }
+}
+template <class R>
+__global__ void k_rows_add_aos(int N, int Npad, const double* src, int cnt, const int* orig, R* rows) {     // rows[c][q] += src[id][c]
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const size_t id = (size_t)(orig ? orig[q] : q);
+    for (int c = 0; c < cnt; ++c) rows[(size_t)c * Npad + q] += (R)src[id * cnt + c];
+}
+template <class R>
+__global__ void k_rows_to_aos(int N, int Npad, const R* rows, int cnt, const int* orig, int ident, double* dst, int stride, int offset) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const size_t id = (size_t)(orig ? orig[q] : q);
+    for (int c = 0; c < cnt; ++c) {
+        const double add = (ident && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
+        dst[id * stride + offset + c] = (double)rows[(size_t)c * Npad + q] + add;
+    }
+}
+
 // pass 3: move one component row of a frame
 template <class R>
 __global__ void k_sort_move(int N, const int* dest, const R* src, R* dst, int Npad, int ncomp) {

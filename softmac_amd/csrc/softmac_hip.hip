@@ -48,6 +48,7 @@ struct ISim {
     virtual int reset(const double* state, int cols) = 0;
     virtual int set_frame(int f, const double* x, const double* v, const double* F, const double* C) = 0;
     virtual int get_frame(int f, double* x, double* v, double* F, double* C) = 0;
+    virtual int get_state24(int f, double* out) = 0;
     virtual int copy_frame(int src, int dst) = 0;
     virtual int get_grad(int f, double* gx, double* gv, double* gF, double* gC) = 0;
     virtual int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) = 0;
@@ -106,7 +107,6 @@ template <class R> struct Sim final : ISim {
     std::vector<hipEvent_t> pool;
     double prof_ms[K_COUNT] = {};
     int64_t prof_n[K_COUNT] = {};
-    std::vector<R> stage;
 
     // ---- epochs: one per re-sort.  Epoch 0 is the identity order of user-provided frames.
     struct Epoch {
@@ -122,7 +122,6 @@ template <class R> struct Sim final : ISim {
         int* block_active = nullptr;
         int frame = 0;              // frame at which the sort happened
         int interval = 1;           // substeps this binning is used for (<= sort_interval, shortened for fast particles)
-        std::vector<int> h_orig;    // host copy (lazy) for IO
         bool live = false;
     };
     std::vector<Epoch> epochs;      // [0] = identity
@@ -176,6 +175,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
+        hipFree(d_io);
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
         hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits);
         for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
@@ -348,45 +348,38 @@ template <class R> struct Sim final : ISim {
 
     // ---- IO -----------------------------------------------------------------------------
     // host copy of an epoch's slot -> original-id table (identity for epoch 0)
-    const int* host_orig(int e) {
-        if (e <= 0) return nullptr;
-        Epoch& ep = epochs[e];
-        if (ep.h_orig.empty()) {
-            ep.h_orig.resize(D.N);
-            hipMemcpyAsync(ep.h_orig.data(), ep.orig, D.N * sizeof(int), hipMemcpyDeviceToHost, stream);
-            hipStreamSynchronize(stream);
+    // The conversion (f64 AOS in the caller's order <-> R rows in the frame's order) runs on the device: the host only
+    // copies the caller's array (1M particles: reset 89 -> 30 ms).
+    double* d_io = nullptr;
+    size_t io_cap = 0;
+    int io_buffer(size_t doubles) {
+        if (doubles > io_cap) {
+            hipFree(d_io);
+            d_io = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_io, doubles * sizeof(double)));
+            io_cap = doubles;
         }
-        return ep.h_orig.data();
-    }
-    // src is in ORIGINAL particle order; the frame is stored in the order of epoch `e`
-    int upload_comp(R* base, int f, int c0, int cnt, const double* src, bool minus_identity, int e) {
-        stage.resize((size_t)cnt * D.Npad);
-        const int* orig = host_orig(e);
-        for (int c = 0; c < cnt; ++c) {
-            R* dst = stage.data() + (size_t)c * D.Npad;
-            const double sub = (minus_identity && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
-            if (orig) for (int q = 0; q < D.N; ++q) dst[q] = (R)(src[(size_t)orig[q] * cnt + c] - sub);
-            else for (int q = 0; q < D.N; ++q) dst[q] = (R)(src[(size_t)q * cnt + c] - sub);
-            for (int q = D.N; q < D.Npad; ++q) dst[q] = 0;
-        }
-        R* d = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
-        HIP_TRY(hipMemcpyAsync(d, stage.data(), stage.size() * sizeof(R), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
+    }
+    int upload_comp(R* base, int f, int c0, int cnt, const double* src, bool minus_identity, int e) {
+        int rc;
+        if ((rc = io_buffer((size_t)D.N * cnt))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_io, src, (size_t)D.N * cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+        R* d = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
+        hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cnt, 0, cnt,
+                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, minus_identity ? 1 : 0, d);
+        HIP_TRY(hipStreamSynchronize(stream));
+        return check_launch();
     }
     int download_comp(const R* base, int f, int c0, int cnt, double* dst, bool plus_identity, int e) {
-        stage.resize((size_t)cnt * D.Npad);
+        int rc;
+        if ((rc = io_buffer((size_t)D.N * cnt))) return rc;
         const R* s = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
-        HIP_TRY(hipMemcpyAsync(stage.data(), s, stage.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(k_rows_to_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, s, cnt,
+                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, plus_identity ? 1 : 0, d_io, cnt, 0);
+        HIP_TRY(hipMemcpyAsync(dst, d_io, (size_t)D.N * cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        const int* orig = host_orig(e);
-        for (int c = 0; c < cnt; ++c) {
-            const R* src = stage.data() + (size_t)c * D.Npad;
-            const double add = (plus_identity && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
-            if (orig) for (int q = 0; q < D.N; ++q) dst[(size_t)orig[q] * cnt + c] = (double)src[q] + add;
-            else for (int q = 0; q < D.N; ++q) dst[(size_t)q * cnt + c] = (double)src[q] + add;
-        }
-        return SMAC_OK;
+        return check_launch();
     }
     int check_frame(int f) {
         REQUIRE(f >= 0 && f < cfg.max_frames, "frame index out of range");
@@ -405,6 +398,23 @@ template <class R> struct Sim final : ISim {
         if (F && (rc = upload_comp(D.S, f, CF, 9, F, true, e))) return rc;
         return SMAC_OK;
     }
+    int get_state24(int f, double* out) override {                            // mpm_simulator.py:541-548 get_state: (N, 24) = x3 v3 F9 C9
+        int rc = check_frame(f);
+        if (rc) return rc;
+        REQUIRE(out, "null argument");
+        const int e = frame_epoch[f] < 0 ? 0 : frame_epoch[f];
+        if ((rc = io_buffer((size_t)D.N * 24))) return rc;
+        const R* fr = D.S + (size_t)f * frame_scalars();
+        const int* orig = e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr;
+        auto rows = [&](int c0, int cnt, int offset, int ident) {
+            hipLaunchKernelGGL(k_rows_to_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, fr + (size_t)c0 * D.Npad, cnt, orig, ident,
+                               d_io, 24, offset);
+        };
+        rows(CX, 3, 0, 0); rows(CV, 3, 3, 0); rows(CF, 9, 6, 1); rows(CC, 9, 15, 0);
+        HIP_TRY(hipMemcpyAsync(out, d_io, (size_t)D.N * 24 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return check_launch();
+    }
     int get_frame(int f, double* x, double* v, double* F, double* C) override {
         int rc = check_frame(f);
         if (rc) return rc;
@@ -417,20 +427,27 @@ template <class R> struct Sim final : ISim {
     }
     int reset(const double* state, int cols) override {                       // mpm_simulator.py:494-519
         REQUIRE(state && (cols == 3 || cols == 24), "reset: cols must be 3 or 24");
-        const int N = D.N;
-        std::vector<double> x((size_t)N * 3), v((size_t)N * 3, 0.0), F((size_t)N * 9, 0.0), C((size_t)N * 9, 0.0);
-        for (int p = 0; p < N; ++p) {
-            const double* s = state + (size_t)p * cols;
-            for (int j = 0; j < 3; ++j) x[(size_t)p * 3 + j] = s[j];
-            if (cols == 24) {
-                for (int j = 0; j < 3; ++j) v[(size_t)p * 3 + j] = s[3 + j];
-                for (int j = 0; j < 9; ++j) { F[(size_t)p * 9 + j] = s[6 + j]; C[(size_t)p * 9 + j] = s[15 + j]; }
-            } else {
-                F[(size_t)p * 9] = F[(size_t)p * 9 + 4] = F[(size_t)p * 9 + 8] = 1.0;
-            }
-        }
+        int rc;
         frame_epoch[0] = 0;                                                   // user data: identity order, re-binned at the next substep
-        return set_frame(0, x.data(), v.data(), F.data(), C.data());
+        ck_epoch[0] = -1;
+        // the caller's (N, cols) array goes up once; the split into x / v / C / F rows (host layout x3 v3 F9 C9) happens on the device
+        if ((rc = io_buffer((size_t)D.N * cols))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_io, state, (size_t)D.N * cols * sizeof(double), hipMemcpyHostToDevice, stream));
+        R* fr = D.S;
+        auto rows = [&](int c0, int cnt, int offset, int ident) {
+            hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cols, offset,
+                               cnt, (const int*)nullptr, ident, fr + (size_t)c0 * D.Npad);
+        };
+        rows(CX, 3, 0, 0);
+        if (cols == 24) {
+            rows(CV, 3, 3, 0);
+            rows(CF, 9, 6, 1);
+            rows(CC, 9, 15, 0);
+        } else {                                                              // v = 0, C = 0, F = I (stored as E = 0)
+            HIP_TRY(hipMemsetAsync(fr + (size_t)CV * D.Npad, 0, (size_t)(NCOMP - CV) * D.Npad * sizeof(R), stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return check_launch();
     }
     int copy_frame(int src, int dst) override {                               // :468-479
         int rc;
@@ -484,13 +501,14 @@ template <class R> struct Sim final : ISim {
         const int e = adj_epoch[f];
         const double* src[4] = {gx, gv, gC, gF};
         const int c0[4] = {CX, CV, CC, CF}, cnt[4] = {3, 3, 9, 9};
-        std::vector<double> cur;
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < 4; ++a) {                                         // `x.grad[f, i] += ...` on the device
             if (!src[a]) continue;
-            cur.resize((size_t)D.N * cnt[a]);
-            if ((rc = download_comp(D.A, f, c0[a], cnt[a], cur.data(), false, e))) return rc;
-            for (size_t i = 0; i < cur.size(); ++i) cur[i] += src[a][i];
-            if ((rc = upload_comp(D.A, f, c0[a], cnt[a], cur.data(), false, e))) return rc;
+            if ((rc = io_buffer((size_t)D.N * cnt[a]))) return rc;
+            HIP_TRY(hipMemcpyAsync(d_io, src[a], (size_t)D.N * cnt[a] * sizeof(double), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_rows_add_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cnt[a],
+                               e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr,
+                               D.A + (size_t)f * frame_scalars() + (size_t)c0[a] * D.Npad);
+            HIP_TRY(hipStreamSynchronize(stream));                            // d_io is reused by the next component
         }
         return SMAC_OK;
     }
@@ -674,7 +692,6 @@ template <class R> struct Sim final : ISim {
         hipFree(e.orig); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
         e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = nullptr;
         e.chunks = nullptr;
-        e.h_orig.clear(); e.h_orig.shrink_to_fit();
         e.live = false;
     }
     // a dropped epoch hands its device buffers to the pool (kernels still using them are ahead of any new writer on the stream)
@@ -686,7 +703,6 @@ template <class R> struct Sim final : ISim {
         e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = nullptr;
         e.chunks = nullptr;
         e.inv_valid = false;
-        e.h_orig.clear(); e.h_orig.shrink_to_fit();
         e.live = false;
     }
     size_t chunk_capacity() const { return (size_t)D.N / 256 + (size_t)(nblocks < D.N ? nblocks : D.N) + 8; }
@@ -1437,6 +1453,7 @@ int smac_destroy(smac_handle h) {
 int smac_sync(smac_handle h) { return FWD(sync()); }
 int smac_reset(smac_handle h, const double* state, int cols) { return FWD(reset(state, cols)); }
 int smac_set_frame(smac_handle h, int f, const double* x, const double* v, const double* F, const double* C) { return FWD(set_frame(f, x, v, F, C)); }
+int smac_get_state(smac_handle h, int f, double* state24) { return FWD(get_state24(f, state24)); }
 int smac_get_frame(smac_handle h, int f, double* x, double* v, double* F, double* C) { return FWD(get_frame(f, x, v, F, C)); }
 int smac_copy_frame(smac_handle h, int src, int dst) { return FWD(copy_frame(src, dst)); }
 int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC) { return FWD(get_grad(f, gx, gv, gF, gC)); }

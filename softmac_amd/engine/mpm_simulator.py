@@ -181,11 +181,9 @@ class MPMSimulator:
 
     # ------------------------------------------------------------------ IO (:448-574)
     def get_state(self, f):
-        N = self.n_particles
-        x, v = np.zeros((N, 3)), np.zeros((N, 3))
-        F, Cm = np.zeros((N, 3, 3)), np.zeros((N, 3, 3))
-        self._h.call("smac_get_frame", int(f), _ffi.dptr(x), _ffi.dptr(v), _ffi.dptr(F), _ffi.dptr(Cm))
-        return np.hstack([x, v, F.reshape(N, -1), Cm.reshape(N, -1)])
+        out = np.empty((self.n_particles, 24))
+        self._h.call("smac_get_state", int(f), _ffi.dptr(out))
+        return out
 
     def set_state(self, f, state):
         x, v, F, Cm = (_ffi.as_f64(s) for s in state[:4])

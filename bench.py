@@ -22,6 +22,14 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def baseline_metric():
+    """The headline metric, named exactly as BASELINE.json names it."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "MPM substeps/s (fwd+bwd) at 1M particles/128\u00b3 grid, 1/2/4/8 MI355X"
+
+
 def build_sim(args, rank, world):
     from softmac_amd import scenes
     from softmac_amd.config import CfgNode
@@ -198,7 +206,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "MPM substeps/s (fwd+bwd) at 1M particles/128^3 grid",
+            "metric": baseline_metric(),
             "value": value, "unit": "substeps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * wall / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",

@@ -30,20 +30,25 @@ def baseline_metric():
         return "MPM substeps/s (fwd+bwd) at 1M particles/128\u00b3 grid, 1/2/4/8 MI355X"
 
 
-def build_sim(args, rank, world):
+def build_sim(args, rank, world, precision=None, frames=None):
     from softmac_amd import scenes
     from softmac_amd.config import CfgNode
     from softmac_amd.engine.mpm_simulator import MPMSimulator
     from softmac_amd.engine.primitive import Mesh, Primitives
-    frames = args.warmup + args.steps + 2
+    precision = precision or args.precision
+    frames = frames or (args.warmup + args.steps + 2)
     dev = int(os.environ.get("SMAC_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0))) if world > 1 else 0
     slab = None
-    if args.workload == "s-grip" and world > 1:
-        cfg, env_dt, state, specs, s13, slab = scenes.s_grip_slab(rank, world, args.particles, args.grid, frames, args.precision, dev)
+    if args.workload == "s-grip" and world > 1 and args.scaling == "strong":
+        # the metric's own case: ONE 1M-particle / 128^3 scene cut into `world` x-slabs of one global grid
+        cfg, env_dt, state, specs, s13, slab, _own = scenes.s_grip_strong(rank, world, args.particles, args.grid, frames, precision, dev)
+    elif args.workload == "s-grip" and world > 1:
+        cfg, env_dt, state, specs, s13, lh = scenes.s_grip_slab(rank, world, args.particles, args.grid, frames, precision, dev)
+        slab = (lh[0], lh[1], 2)
     elif args.workload == "s-grip":
-        cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, frames, args.precision, dev, seed=1 + rank)
+        cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, frames, precision, dev, seed=1 + rank)
     else:
-        cfg, env_dt, state, specs, s13 = scenes.s_elastic(args.particles, args.grid, frames, args.precision, dev, seed=rank)
+        cfg, env_dt, state, specs, s13 = scenes.s_elastic(args.particles, args.grid, frames, precision, dev, seed=rank)
     cfg.recompute_backward = args.recompute_backward
     cfg.sort_interval = args.sort_interval
     meshes = []
@@ -63,9 +68,9 @@ def build_sim(args, rank, world):
             m.set_all_states(f, st)
     sim.reset(state)
     runner = sim
-    if slab is not None:                                   # slab decomposition: halo exchange of 2 shared x-planes over RCCL
+    if slab is not None:                                   # slab decomposition: halo exchange of the shared x-planes over RCCL
         from softmac_amd.parallel import HipSlabEngine, SlabRunner
-        runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], 2, has_contact=True)
+        runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=True)
     return sim, runner, cfg
 
 
@@ -115,23 +120,121 @@ def cpu_baseline(args):
                       f"f64 C++/OpenMP restatement of the reference's kernel decomposition (not Taichi), {dt:.1f} s on {port.threads()} threads"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); spawned here when not already under torchrun")
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=3, help="the K-step window is timed this many times; the median is reported")
     ap.add_argument("--workload", default="s-grip", choices=["s-grip", "s-elastic"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the metric's one 1M-particle scene cut into N slabs; weak = N bars of 1M particles each")
     ap.add_argument("--particles", type=int, default=1 << 20)
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--precision", default="float32", choices=["float32", "float64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64", action="store_true", help="skip the float64 sub-record (the mode that equals the reference's dtype)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
-    ap.add_argument("--sort-interval", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--sort-interval", type=int, default=0, help="0: min(32, steps), so that every timed window holds a re-sort")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="spawn the ranks, rendezvous (gloo), report - no simulator, no GPU call (CPU test of the launcher)")
+    return ap.parse_args(argv)
 
+
+def launch_children(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start N fresh ranks (one per GPU) BEFORE anything here touches the GPU -
+    this parent never imports torch or the HIP library - and pass their exit code on."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL / cross-process device memory on this host driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, world, rank):
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("SMAC_DIST_BACKEND", "gloo"))
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", -1)), "pid": os.getpid()}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, mine)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "requested": args.gpus, "backend": dist.get_backend(),
+                          "ranks": sorted(ranks, key=lambda r: r["rank"])}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist):
+    """W warm-up substep pairs, then `repeats` windows of EXACTLY K forward + K backward substeps on frames [W, W+K).
+    Returns (per-window wall seconds after MAX over ranks, per-window device ms)."""
+    K, W = args.steps, args.warmup
+    env = max(sim.substeps, 1)
+
+    def forward(f0, n):
+        if reducer is None:
+            run.run_substeps(f0, n)
+            return
+        f = f0
+        while f < f0 + n:                                   # per env step: substeps, then the wrench sums of all slabs
+            m = min(env - f % env, f0 + n - f)
+            run.run_substeps(f, m)
+            f += m
+            reducer.allreduce_ext_f(clear=True)
+
+    def backward(f0, n):
+        run.run_substeps_grad(f0, n)
+        if reducer is not None:
+            reducer.allreduce_state_grad(f0, f0 + n)
+
+    forward(0, W)
+    sim.clear_grads()
+    sim.add_grad(W, gx=seed_gx)
+    backward(0, W)
+    walls, devs = [], []
+    for _ in range(max(args.repeats, 1)):
+        sim.clear_grads()
+        sim.add_grad(W + K, gx=seed_gx)
+        for m in sim.primitives:
+            m.clear_ext_f()
+        barrier()
+        t0 = time.perf_counter()
+        sim.timer_start()
+        forward(W, K)
+        backward(W, K)
+        dev_ms = sim.timer_stop()
+        barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([wall], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        walls.append(wall)
+        devs.append(dev_ms)
+    return walls, devs, forward, backward
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    under_launcher = "WORLD_SIZE" in os.environ
+    if not under_launcher and args.gpus and args.gpus > 1:
+        sys.exit(launch_children(args, argv))
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
+    if args.gpus is not None and args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    if args.launch_check:
+        return launch_check(args, world, rank)
+    if args.sort_interval <= 0:
+        args.sort_interval = min(32, max(args.steps, 1))
     dist = None
     if world > 1:
         import torch
@@ -140,10 +243,15 @@ def main():
         dist.init_process_group(os.environ.get("SMAC_DIST_BACKEND", "nccl"))      # "nccl" is RCCL on ROCm
 
     sim, run, cfg = build_sim(args, rank, world)
-    N, K, W = args.particles, args.steps, args.warmup
+    N_local, K, W = int(cfg.n_particles), args.steps, args.warmup
+    N = args.particles
     sbytes = 4 if args.precision == "float32" else 8
     rng = np.random.default_rng(7 + rank)
-    seed_gx = rng.standard_normal((N, 3))
+    seed_gx = rng.standard_normal((N_local, 3))
+    reducer = None
+    if world > 1:
+        from softmac_amd.parallel import PrimitiveReducer
+        reducer = PrimitiveReducer(sim)
 
     def barrier():
         sim.sync()
@@ -152,52 +260,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warmup: W fwd + W bwd on frames [0, W)
-    run.run_substeps(0, W)
-    sim.clear_grads()
-    sim.add_grad(W, gx=seed_gx)
-    run.run_substeps_grad(0, W)
-    sim.clear_grads()
-    sim.add_grad(W + K, gx=seed_gx)
-    for m in sim.primitives:
-        m.clear_ext_f()
-    barrier()
+    walls, devs, forward, backward = timed_windows(args, sim, run, reducer, seed_gx, barrier, dist)
+    order = sorted(range(len(walls)), key=lambda i: walls[i])
+    mid = order[len(order) // 2]
+    wall, dev_ms = walls[mid], devs[mid]
+    strong = world > 1 and args.scaling == "strong" and args.workload == "s-grip"
+    value = (1 if (strong or world == 1) else world) * K / wall
 
-    # timed: K forward substeps then K backward substeps, frames [W, W+K)
-    t0 = time.perf_counter()
-    sim.timer_start()
-    run.run_substeps(W, K)
-    run.run_substeps_grad(W, K)
-    dev_ms = sim.timer_stop()
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall], device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    value = world * K / wall
-
-    # per-kernel HIP-event profile over a second identical pass (kept out of the timed region)
+    # per-kernel HIP-event profile over one more identical pass (kept out of the timed region)
     sim.clear_grads()
     sim.add_grad(W + K, gx=seed_gx)
     sim.profile(True)
-    run.run_substeps(W, K)
-    run.run_substeps_grad(W, K)
+    forward(W, K)
+    backward(W, K)
     prof = sim.profile_report()
     sim.profile(False)
     G_t = sim.count_active_cells(W)
     n_hits, n_hit_chunks = sim.contact_counts()
+    counts = [N_local, G_t, n_hits]
+    if dist is not None:
+        allc = [None] * world
+        dist.all_gather_object(allc, counts)
+    else:
+        allc = [counts]
 
     if rank == 0:
         kern = {k: v for k, v in prof.items() if v[1] > 0}
-        dom = max(kern, key=lambda k: kern[k][0])
+        per_step = {k: v[0] / K for k, v in kern.items()}                        # ms per substep pair, amortised (sort: 1 per interval)
+        dom = max((k for k in kern if k not in ("sort", "reorder_adjoint")), key=lambda k: kern[k][0])
         avg_ms = kern[dom][0] / kern[dom][1]
         pp, pc = KERNEL_BYTES[dom]
-        alg = (pp * N + pc * G_t) * sbytes
+        alg = (pp * N_local + pc * G_t) * sbytes
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        ab = algorithmic_bytes(N, G_t, sbytes)
-        sub_gbs = (ab["fwd"] + ab["bwd"]) * (K / (dev_ms * 1e-3)) / 1e9
+        Gsum = sum(c[1] for c in allc)
+        ab = algorithmic_bytes(sum(c[0] for c in allc), Gsum, sbytes)
+        steps_per_s_dev = K / (dev_ms * 1e-3)
+        sub_gbs = (ab["fwd"] + ab["bwd"]) * steps_per_s_dev / 1e9 / world            # per GPU (all ranks' bytes / ranks)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -205,20 +303,33 @@ def main():
                 traffic = json.load(open(tpath)).get(dom)
             except Exception:
                 traffic = None
+        if world == 1:
+            par = "1 gpu"
+        elif strong:
+            par = (f"strong scaling: the one {N}-particle scene cut into {world} x-slabs of one global {args.grid}^3 grid, balanced by particle count "
+                   f"({[c[0] for c in allc]} particles per rank); per substep neighbour-only RCCL send/recv of the 4 shared grid planes "
+                   f"(fwd: m,p + contact corrections; bwd: grid_v_out.grad + grid_v_mixed.grad); ext_f all-reduced per env step, "
+                   f"primitive adjoints per window")
+        else:
+            par = (f"weak scaling: {world} x-slabs of one bar, {N} particles each; value counts every slab's substep; per substep "
+                   f"neighbour-only RCCL send/recv of 2 shared grid planes")
         out = {
             "metric": baseline_metric(),
             "value": value, "unit": "substeps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * wall / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * wall / K, "higher_is_better": True,
+            "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",
             "config": {"workload": (f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
                                     f"3 gripper SDF primitives (2 in forecast contact), fwd+bwd") if args.workload == "s-grip" else
                                    f"{args.workload}: {N} particles, {args.grid}^3 grid, elastic fixed-corotated, no primitives, fwd+bwd",
-                       "particles_per_gpu": N, "n_grid": args.grid, "touched_cells": G_t, "contact_particles": n_hits,
+                       "particles_per_gpu": [c[0] for c in allc] if world > 1 else N, "n_grid": args.grid,
+                       "touched_cells": Gsum if world > 1 else G_t, "contact_particles": sum(c[2] for c in allc),
                        "backward": "forward grid recomputed in substep_grad (reference style)" if args.recompute_backward
                        else "forward grid restored from the per-frame checkpoint saved by substep",
-                       "parallelism": "1 gpu" if world == 1 else
-                       f"{world} x-slabs of one bar, {N} particles each; per substep neighbour-only RCCL send/recv of 2 shared grid planes "
-                       f"(fwd: m,p + contact corrections; bwd: grid_v_out.grad + grid_v_mixed.grad)"},
+                       "resort_interval": args.sort_interval, "resorts_in_window": int(kern.get("sort", (0, 0))[1]),
+                       "parallelism": par},
+            "repeats": len(walls), "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
+            "spread": (max(walls) - min(walls)) / wall,
             "device_ms_per_step": dev_ms / K,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
@@ -226,7 +337,20 @@ def main():
             "roofline_substep": {"algorithmic_bytes_fwd_bwd": ab["fwd"] + ab["bwd"], "achieved": sub_gbs,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sub_gbs / PEAK_HBM_GBS},
             "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in kern.items()},
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
         }
+    if world == 1 and args.precision == "float32" and not args.no_f64:
+        # the mode that computes in the reference's own dtype (mpm_simulator.py:19) and meets 1e-9: one window, same workload
+        del run
+        sim._h.close()
+        del sim
+        a64 = argparse.Namespace(**vars(args))
+        a64.precision, a64.repeats = "float64", 1
+        sim, run, cfg = build_sim(a64, rank, world)
+        w64, d64, _, _ = timed_windows(a64, sim, run, None, seed_gx, lambda: sim.sync(), None)
+        out["f64"] = {"value": K / w64[0], "unit": "substeps/s", "ms_per_step": 1e3 * w64[0] / K, "device_ms_per_step": d64[0] / K,
+                      "dtype": "f64", "note": "same workload, arithmetic and storage in float64 (parity 1e-9 state / 1e-8 gradients)"}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

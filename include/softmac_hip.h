@@ -99,6 +99,7 @@ int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, doub
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC); /* loss kernels' `x.grad[f,i] +=` */
 int smac_clear_grads(smac_handle h);                                          /* ti.ad.clear_all_gradients() */
 int smac_set_control_idx(smac_handle h, const int32_t* idx);                  /* set_control_idx :599-602 */
+int smac_set_action(smac_handle h, const double* action);                     /* set_action :589-592: (n_control, 3); zeroes action.grad (:584-586) */
 int smac_compute_grid_m(smac_handle h, int f, double* grid_m);                /* compute_grid_m_kernel :607-617, (n,n,n) out */
 
 /* ---- the hot path (mpm_simulator.py:320-378).

@@ -37,14 +37,23 @@ def is_stale() -> bool:
     return any(p.stat().st_mtime > t for p in SOURCES + DEPS)
 
 
-def build(force: bool = False, report: bool = False, verbose: bool = True) -> pathlib.Path:
+def build(force: bool = False, report: bool = False, verbose: bool = True, defines=(), out=None, extra=()) -> pathlib.Path:
+    """`defines` / `out`: experiment builds of the same ABI (e.g. defines=["SMAC_CONST_F64=1"], out="libsoftmac_hip_cf64.so"),
+    loaded with SMAC_LIB=<path> (tools/ab.sh, tools/prec_probe.py)."""
+    if out is not None:
+        return _compile(LIBDIR / out, list(defines), report, verbose, list(extra))
     if not force and not report and not is_stale():
         return LIB
+    return _compile(LIB, list(defines), report, verbose, list(extra))
+
+
+def _compile(LIB, defines, report, verbose, extra=()):
     LIBDIR.mkdir(exist_ok=True)
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=fast",
            "-fno-slp-vectorize",      # the SLP packer's v_pk_* f32 ops cost more v_mov shuffles than they save (measured +12%)
            "-ffast-math",             # the reference runs Taichi with fast_math=True (taichi_env.py:13); +4.5 %, all parity tolerances unchanged
-           "-Wno-unused-value", "-shared", "-fPIC", "-o", str(LIB)] + [str(s) for s in SOURCES]
+           "-fno-finite-math-only",   # ... but NaN / Inf keep their meaning: an exploded state must stay visibly non-finite (tile_scale)
+           "-Wno-unused-value", "-shared", "-fPIC", "-o", str(LIB)] + [f"-D{d}" for d in defines] + list(extra) + [str(s) for s in SOURCES]
     if report:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     if verbose:
@@ -75,4 +84,7 @@ def build(force: bool = False, report: bool = False, verbose: bool = True) -> pa
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, report="--report" in sys.argv)
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
+    extra = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--flag=")]      # e.g. --flag=-fno-fast-math (later flags win)
+    build(force="--force" in sys.argv, report="--report" in sys.argv, defines=defs, out=outs[0] if outs else None, extra=extra)

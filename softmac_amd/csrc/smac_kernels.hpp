@@ -45,6 +45,12 @@ namespace smac {
 #ifndef SMAC_OCC_P2G
 #define SMAC_OCC_P2G 6
 #endif
+// arithmetic type of the constitutive model (SVD, stress, their adjoint) inside the particle kernels: the storage type R,
+// or double whatever R is (SMAC_CONST_F64=1; measured for the f32 accuracy study, tools/prec_probe.py)
+#ifndef SMAC_CONST_F64
+#define SMAC_CONST_F64 0
+#endif
+template <class R> struct const_t { typedef typename std::conditional<SMAC_CONST_F64 != 0, double, R>::type type; };
 constexpr int BLOCK = 256;
 enum { CX = 0, CV = 3, CC = 6, CF = 15, NCOMP = 24 };
 
@@ -61,11 +67,15 @@ template <class R> struct DevSim {
     // grid: one 4-scalar record per cell and field, so a stencil node is ONE 16-byte access
     Vec4<R> *vin, *vmix, *vout;         // {m, p_x, p_y, p_z} / {v_mixed, 0} / {v_out, 0}
     Vec4<R> *ain, *amix, *aout;         // adjoints: {grid_m.grad, grid_v_in.grad} / {grid_v_mixed.grad, 0} / {grid_v_out.grad, 0}
-    PrimTable<R> prim[MAX_PRIMS];
-    R* prim_state;
-    R* prim_grad;
-    R* ext_f;
-    R* ext_f_grad;
+    PrimTable<R> prim[MAX_PRIMS];        // tables in R: band filter, collision types 0 / 1
+    PrimTable<double> prim64[MAX_PRIMS]; // tables in f64: the forecast contact chain (k_contact_hits / k_contact_grad) runs in double
+    // rigid-body state, its adjoint and the wrench accumulators are f64 whatever R is: a pose rounded to float (3e-8 at 0.5)
+    // would be divided by dt in the forecast push-out like a position error
+    double* prim_state;
+    double* prim_grad;
+    double* ext_f;
+    double* ext_f_grad;
+    double dt64;
     const int* control_idx;      // indexed by ORIGINAL particle id
     R* action;
     R* action_grad;
@@ -90,6 +100,7 @@ template <class R> struct DevSim {
     const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
     const int* block_chunks;
     int* drift_flag;
+    int check_next;              // k_g2p: frame f+1 is processed with THIS binning too, so x[f+1] must still lie inside the halo
     int open_x;                  // slab decomposition: bit 0 / bit 1 = no wall at the low / high x end (neighbour slab there)
     const int* block_active;     // dense per-block flag of the current epoch (halo packing)
 };
@@ -174,6 +185,25 @@ template <class R> __device__ __forceinline__ void load_vec(const R* fr, int c0,
 #pragma unroll
     for (int i = 0; i < cnt; ++i) out[i] = fr[(size_t)(c0 + i) * Npad + p];
 }
+// position rows (smac_math.hpp pos_of): doubles, or 32-bit fixed point in the float slots
+template <class R> __device__ __forceinline__ void load_pos(const R* fr, int Npad, int p, typename pos_of<R>::type* out) {
+    typedef typename pos_of<R>::type P;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = ((const P*)fr)[(size_t)(CX + i) * Npad + p];
+}
+template <class R> __device__ __forceinline__ void store_pos(R* fr, int Npad, int p, int i, typename pos_of<R>::type v) {
+    typedef typename pos_of<R>::type P;
+    ((P*)fr)[(size_t)(CX + i) * Npad + p] = v;
+}
+template <class R, class P> __device__ __forceinline__ void pos_to(const P* x, R* out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = (R)pos_get(x[i]);
+}
+template <class R> __device__ __forceinline__ typename pos_of<R>::type pos_mid() {
+    typename pos_of<R>::type v;
+    pos_set(0.5, v);
+    return v;
+}
 
 // Addresses of the 27 stencil nodes: block-major global cell = cx[i] + cy[j] + cz[k]; tile-local word
 // = tx[i] + ty[j] + tz[k] when the node lies inside the chunk's 6^3 tile (bit i of okx etc.).
@@ -187,8 +217,8 @@ struct Nodes {
     __device__ __forceinline__ bool in_tile(int i, int j, int k) const { return ((okx >> i) & (oky >> j) & (okz >> k) & 1) != 0; }
     __device__ __forceinline__ int tile(int i, int j, int k) const { return tx[i] + ty[j] + tz[k]; }
 };
-template <class R> __device__ __forceinline__ void stencil_at(const DevSim<R>& D, const R* x, Stencil<R>& st, Nodes& nd, int block) {
-    make_stencil(x, D.inv_dx, st);
+template <class R> __device__ __forceinline__ void stencil_at(const DevSim<R>& D, const typename pos_of<R>::type* x, Stencil<R>& st, Nodes& nd, int block) {
+    make_stencil_pos(x, D.n, st);
     const int nb = D.nb;
     const int bz = block % nb, by = (block / nb) % nb, bx = block / (nb * nb);
     const int org[3] = {4 * bx, 4 * by, 4 * bz};
@@ -339,14 +369,24 @@ __device__ __forceinline__ int hit_slot(int* counter) {
 }
 
 // band test shared by k_contact and k_contact_grad: which primitives see this particle
-template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const R* x) {
+// This is a FILTER: in f32 it runs in float on a float copy of the table and lets a margin of 2e-5 through; the contact
+// kernels repeat the test (collide_* return false outside the band) in the arithmetic that decides.
+template <class R> __device__ __forceinline__ void prim_state_R(const DevSim<R>& D, int i, int f, R* s13) {
+    const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+#pragma unroll
+    for (int c = 0; c < 13; ++c) s13[c] = (R)ps[c];
+}
+template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const typename pos_of<R>::type* xp) {
     int mask = 0;
+    R x[3];
+    pos_to(xp, x);
 #pragma unroll
     for (int i = 0; i < MAX_PRIMS; ++i) {
         if (i >= D.P || !D.prim[i].contact) continue;
-        const R* st = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+        R st[13];
+        prim_state_R(D, i, f, st);
         R d = prim_sdf(D.prim[i], st, x);
-        if (d <= R(5e-3)) mask |= 1 << i;
+        if (d <= R(5e-3) + (sizeof(R) == 4 ? R(2e-5) : R(0))) mask |= 1 << i;
     }
     return mask;
 }
@@ -361,8 +401,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
     SMAC_CHUNK_PROLOGUE
     int cmask = 0;
     if (valid) {
-        R x[3];
-        load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+        typename pos_of<R>::type x[3];
+        load_pos(frame(D.S, f, D.Npad), D.Npad, p, x);
         cmask = contact_mask(D, f, x);
         if (cmask) {
             Hit h = {p, cmask, ch.block, 0};
@@ -423,14 +463,16 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     SMAC_CHUNK_PROLOGUE
     for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = W(0);     // (made visible by the barrier inside tile_scale)
     int cmask = 0;
-    R x[3] = {R(0.5), R(0.5), R(0.5)}, pv[3] = {R(0), R(0), R(0)}, aff[9];
+    typedef typename pos_of<R>::type PX;
+    PX x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+    R pv[3] = {R(0), R(0), R(0)}, aff[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) aff[i] = R(0);
     R bound = R(0);                       // no single scattered momentum component of this particle exceeds it
     if (valid) {
         const R* Sf = frame(D.S, f, D.Npad);
         R v[3], C[9], E[9], Et[9], En[9], stress[9];
-        load_vec(Sf, CX, 3, D.Npad, p, x);
+        load_pos(Sf, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
@@ -441,9 +483,18 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
                 D.hits[hit_slot(D.nhits)] = h;
             }
         }
-        f_tmp(C, E, D.dt, Et);
-        ConstState<R> cs;
-        constitutive_fwd(D.mat, Et, En, stress, cs);
+        {
+            typedef typename const_t<R>::type CT;
+            CT Cc[9], Ec[9], Etc[9], Enc[9], sc[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { Cc[i] = (CT)C[i]; Ec[i] = (CT)E[i]; }
+            f_tmp(Cc, Ec, (CT)D.dt, Etc);
+            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam};
+            ConstState<CT> cs;
+            constitutive_fwd(mat, Etc, Enc, sc, cs);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { Et[i] = (R)Etc[i]; En[i] = (R)Enc[i]; stress[i] = (R)sc[i]; }
+        }
         if (STORE_F) {
             R* Sn = frame(D.S, f + 1, D.Npad);
 #pragma unroll
@@ -453,15 +504,16 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
         pv[0] = D.p_mass * v[0]; pv[1] = D.p_mass * v[1]; pv[2] = D.p_mass * v[2];
         if (D.collision_type == CONTACT_PARTICLE && cmask) {                              // :203-206 penalty contact impulse
+            R xr[3];
+            pos_to(x, xr);
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i) {
                 if (!((cmask >> i) & 1)) continue;
-                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                 R s13[13], imp[3], ext[6];
-                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                if (collide_particle(D.prim[i], s13, x, v, D.dt, imp, ext)) {
+                prim_state_R(D, i, f, s13);
+                if (collide_particle(D.prim[i], s13, xr, v, D.dt, imp, ext)) {
                     for (int c = 0; c < 3; ++c) pv[c] += imp[c];
-                    for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + i * 6 + c, ext[c]);   // sparse: a few thousand particles
+                    for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + i * 6 + c, (double)ext[c]);   // sparse: a few thousand particles
                 }
             }
         }
@@ -602,11 +654,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
 #pragma unroll 1
         for (int q = 0; q < D.P; ++q) {
             if (!D.prim[q].contact) continue;
-            const R* ps = D.prim_state + ((size_t)q * D.max_frames + D.cur_frame) * 13;
             R s13[13], ext[6];
-            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            prim_state_R(D, q, D.cur_frame, s13);
             if (collide_grid(D.prim[q], s13, pos, v, m, D.dt, ext))
-                for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + q * 6 + c, ext[c]);
+                for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + q * 6 + c, (double)ext[c]);
         }
     }
     boundary(D, i, j, k, v);
@@ -637,12 +688,13 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
 // half as many busy workgroups.)
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
+    typedef typename pos_of<R>::type PX;
     __shared__ tile_t ctile[3 * TILE_WORDS];
     __shared__ double ext_acc[MAX_PRIMS * 6];
     if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
     const int nh = *D.nhits;
     const int grp = threadIdx.x >> 5, d = threadIdx.x & 31;
-    const R life = R(1) / R(D.substeps - f % D.substeps);                                   // :425
+    const double life = 1.0 / (double)(D.substeps - f % D.substeps);                        // :425
     for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
         for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) ctile[i] = 0.0;
         const int wg_block = D.hits[base].block;
@@ -651,8 +703,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         Hit h = {0, 0, 0, 0};
         if (hi < nh) h = D.hits[hi];
         const int mask = h.mask, p = h.p;
-        R x[3] = {R(0.5), R(0.5), R(0.5)};
-        if (mask) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+        PX x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+        if (mask) load_pos(frame(D.S, f, D.Npad), D.Npad, p, x);
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, h.block);
@@ -674,17 +726,19 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
             for (int c = 0; c < 3; ++c) v_tmp[c] += __shfl_xor(v_tmp[c], o, 64);
-        R v_tgt[3] = {v_tmp[0], v_tmp[1], v_tmp[2]};
+        // mixed3 in double whatever R is: the push-out divides a signed distance by dt
+        const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])};
+        double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
 #pragma unroll 1
         for (int i = 0; i < D.P; ++i) {                                                     // mixed3
             if (!((mask >> i) & 1)) continue;
-            const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-            R s13[13], ext[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+            const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+            double s13[13], ext[6] = {0, 0, 0, 0, 0, 0};
             for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-            collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, ext);
+            collide_mixed(D.prim64[i], s13, x64, v_tgt, (double)D.p_mass, D.dt64, life, ext);
             if (d < 6) {                                                                    // lane c adds component c
-                const R e = d == 0 ? ext[0] : (d == 1 ? ext[1] : (d == 2 ? ext[2] : (d == 3 ? ext[3] : (d == 4 ? ext[4] : ext[5]))));
-                if (e != R(0)) __hip_atomic_fetch_add(ext_acc + i * 6 + d, (double)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const double e = d == 0 ? ext[0] : (d == 1 ? ext[1] : (d == 2 ? ext[2] : (d == 3 ? ext[3] : (d == 4 ? ext[4] : ext[5]))));
+                if (e != 0.0) __hip_atomic_fetch_add(ext_acc + i * 6 + d, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         if (mask && d < 27 && has) {                                                        // mixed4, alpha = 2 (:437)
@@ -693,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
                            (nk == 0 ? nd.tz[0] : (nk == 1 ? nd.tz[1] : nd.tz[2]));
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const R val = -R(2) * wn * (v_tmp[c] - v_tgt[c]);
+                const R val = -R(2) * wn * (R)((double)v_tmp[c] - v_tgt[c]);
                 if (in_tile) lds_add(ctile + tw + c * TILE_WORDS, val);
                 else gatomic(D.vout, cell, c, val);
             }
@@ -714,7 +768,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         __syncthreads();
     }
     __syncthreads();
-    if (threadIdx.x < D.P * 6 && ext_acc[threadIdx.x] != 0.0) atomic_add(D.ext_f + threadIdx.x, (R)ext_acc[threadIdx.x]);
+    if (threadIdx.x < D.P * 6 && ext_acc[threadIdx.x] != 0.0) atomic_add(D.ext_f + threadIdx.x, ext_acc[threadIdx.x]);
 }
 
 template <class R>
@@ -727,8 +781,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
     SMAC_CHUNK_PROLOGUE
     const R* Sf = frame(D.S, f, D.Npad);
     R* Sn = frame(D.S, f + 1, D.Npad);
-    R x[3];
-    load_vec(Sf, CX, 3, D.Npad, p, x);              // issued before the tile load's barrier: one round trip, not two
+    typename pos_of<R>::type x[3];
+    load_pos(Sf, D.Npad, p, x);                     // issued before the tile load's barrier: one round trip, not two
     gather_tile_load(D, D.vout, ch.block, gt);
     __syncthreads();
     if (!valid) return;
@@ -781,11 +835,22 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
         nC[3 * c + 2] = Mz[c] - st.fx[2] * M0[c];
     }
     const R four_inv_dx = R(4) * D.inv_dx;
+    bool leaves = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         Sn[(size_t)(CV + c) * D.Npad + p] = nv[c];
-        Sn[(size_t)(CX + c) * D.Npad + p] = x[c] + D.dt * nv[c];                       // :318
+        typename pos_of<R>::type xn;
+        const double xd = pos_get(x[c]) + D.dt64 * (double)nv[c];                      // :318
+        pos_set(xd, xn);
+        store_pos(Sn, D.Npad, p, c, xn);
+        // the position just written is scattered by the NEXT substep's P2G: if that substep keeps this binning, the new
+        // base must still lie in the blocks around the chunk's own (the only ones that are cleared, reduced and swept)
+        int nbase = (int)(pos_get(xn) * (double)D.n - 0.5);
+        nbase = nbase < 0 ? 0 : (nbase > D.n - 3 ? D.n - 3 : nbase);
+        const int cbk = c == 0 ? ch.block / (D.nb * D.nb) : (c == 1 ? (ch.block / D.nb) % D.nb : ch.block % D.nb);
+        leaves |= (nbase >> 2) < cbk - 1 || (nbase >> 2) > cbk + 1;
     }
+    if (leaves && D.check_next) *D.drift_flag = 1;
 #pragma unroll
     for (int c = 0; c < 9; ++c) Sn[(size_t)(CC + c) * D.Npad + p] = four_inv_dx * nC[c];
 }
@@ -823,7 +888,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0);
     gather_tile_load(D, D.vout, ch.block, gt);      // (its barrier is the one inside tile_scale below: the particle loads
                                                     //  that follow are then in flight together with the tile's)
-    R x[3] = {R(0.5), R(0.5), R(0.5)}, gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
+    typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+    R gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) gC1[c] = R(0);
     R bound = R(0);                       // no single scattered component of this particle exceeds it
@@ -831,7 +897,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
         const R* Sf = frame(D.S, f, D.Npad);
         const R* An = D.An;
         R gv1[3];
-        load_vec(Sf, CX, 3, D.Npad, p, x);
+        load_pos(Sf, D.Npad, p, x);
         load_vec(An, CX, 3, D.Npad, p, gx1);
         load_vec(An, CV, 3, D.Npad, p, gv1);
         load_vec(An, CC, 9, D.Npad, p, gC1);
@@ -970,12 +1036,14 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         Hit h = {0, 0, 0, 0};
         if (hi < nh) h = D.hits[hi];
         const int mask = h.mask, p = h.p;
-        R x[3] = {R(0.5), R(0.5), R(0.5)};
-        if (mask) load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+        typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+        if (mask) load_pos(frame(D.S, f, D.Npad), D.Npad, p, x);
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, h.block);
-        const R life = R(1) / R(D.substeps - f % D.substeps);
+        const double life = 1.0 / (double)(D.substeps - f % D.substeps);
+        const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])};
+        const double pm64 = (double)D.p_mass;
         // this lane's stencil node (lanes 27..31 idle in the node-parallel parts)
         const int n = d < 27 ? d : 0;
         const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
@@ -999,9 +1067,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
             for (int c = 0; c < 3; ++c) { v_tmp[c] += __shfl_xor(v_tmp[c], o, 64); gd[c] += __shfl_xor(gd[c], o, 64); }
-        // forward chain (every lane), then its adjoint primitive by primitive in reverse
-        R v_tgt[3] = {v_tmp[0], v_tmp[1], v_tmp[2]};
-        R dummy[6];
+        // forward chain (every lane), then its adjoint primitive by primitive in reverse - in double whatever R is (the
+        // push-out and its derivative carry a factor 1/dt)
+        double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
+        double dummy[6];
         // One primitive in range (the usual case): the value part of the dual pass below IS the forward result,
         // so the separate forward evaluation - a second chain of dependent SDF lookups - is skipped.
         const bool single = mask != 0 && (mask & (mask - 1)) == 0;
@@ -1009,63 +1078,63 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i)
                 if ((mask >> i) & 1) {
-                    const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-                    R s13[13];
+                    const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                    double s13[13];
                     for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                    collide_mixed(D.prim[i], s13, x, v_tgt, D.p_mass, D.dt, life, dummy);
+                    collide_mixed(D.prim64[i], s13, x64, v_tgt, pm64, D.dt64, life, dummy);
                 }
         }
-        R g[3] = {-gd[0], -gd[1], -gd[2]};             // adjoint of v_tgt
-        R gpos[3] = {R(0), R(0), R(0)};
+        double g[3] = {-(double)gd[0], -(double)gd[1], -(double)gd[2]};             // adjoint of v_tgt
+        double gpos[3] = {0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int i = D.P - 1; i >= 0; --i) {
             const bool act = (mask >> i) & 1;
             if (!__ballot(act)) continue;
-            R out = R(0);
-            R vfwd[3] = {R(0), R(0), R(0)};
+            double out = 0.0;
+            double vfwd[3] = {0.0, 0.0, 0.0};
             if (act) {
-                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                 // velocity entering primitive i: replay the chain up to i
-                R vin[3] = {v_tmp[0], v_tmp[1], v_tmp[2]};
+                double vin[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
                 for (int q = 0; q < i; ++q)
                     if ((mask >> q) & 1) {
-                        const R* pq = D.prim_state + ((size_t)q * D.max_frames + f) * 13;
-                        R sq[13];
+                        const double* pq = D.prim_state + ((size_t)q * D.max_frames + f) * 13;
+                        double sq[13];
                         for (int c = 0; c < 13; ++c) sq[c] = pq[c];
-                        collide_mixed(D.prim[q], sq, x, vin, D.p_mass, D.dt, life, dummy);
+                        collide_mixed(D.prim64[q], sq, x64, vin, pm64, D.dt64, life, dummy);
                     }
                 if (d < 19) {
-                    Dual<R> pos[3], v[3], stt[13], ext[6];
-                    for (int c = 0; c < 3; ++c) pos[c] = Dual<R>(x[c], d == c ? R(1) : R(0));
-                    for (int c = 0; c < 3; ++c) v[c] = Dual<R>(vin[c], d == 3 + c ? R(1) : R(0));
-                    for (int c = 0; c < 13; ++c) stt[c] = Dual<R>(ps[c], d == 6 + c ? R(1) : R(0));
-                    collide_mixed(D.prim[i], stt, pos, v, D.p_mass, D.dt, life, ext);
+                    Dual<double> pos[3], v[3], stt[13], ext[6];
+                    for (int c = 0; c < 3; ++c) pos[c] = Dual<double>(x64[c], d == c ? 1.0 : 0.0);
+                    for (int c = 0; c < 3; ++c) v[c] = Dual<double>(vin[c], d == 3 + c ? 1.0 : 0.0);
+                    for (int c = 0; c < 13; ++c) stt[c] = Dual<double>(ps[c], d == 6 + c ? 1.0 : 0.0);
+                    collide_mixed(D.prim64[i], stt, pos, v, pm64, D.dt64, life, ext);
                     for (int c = 0; c < 3; ++c) out += g[c] * v[c].d;
                     for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * ext[c].d;
                     for (int c = 0; c < 3; ++c) vfwd[c] = v[c].v;
                 }
             }
             {   // forward velocity after this primitive, from the group's first lane
-                const R f0 = __shfl(vfwd[0], lane0, 64), f1 = __shfl(vfwd[1], lane0, 64), f2 = __shfl(vfwd[2], lane0, 64);
+                const double f0 = __shfl(vfwd[0], lane0, 64), f1 = __shfl(vfwd[1], lane0, 64), f2 = __shfl(vfwd[2], lane0, 64);
                 if (act && single) { v_tgt[0] = f0; v_tgt[1] = f1; v_tgt[2] = f2; }
             }
             // direction d of this group's hit sits in lane lane0 + d
-            const R o0 = __shfl(out, lane0 + 0, 64), o1 = __shfl(out, lane0 + 1, 64), o2 = __shfl(out, lane0 + 2, 64);
-            const R o3 = __shfl(out, lane0 + 3, 64), o4 = __shfl(out, lane0 + 4, 64), o5 = __shfl(out, lane0 + 5, 64);
+            const double o0 = __shfl(out, lane0 + 0, 64), o1 = __shfl(out, lane0 + 1, 64), o2 = __shfl(out, lane0 + 2, 64);
+            const double o3 = __shfl(out, lane0 + 3, 64), o4 = __shfl(out, lane0 + 4, 64), o5 = __shfl(out, lane0 + 5, 64);
             if (act) {
                 gpos[0] += o0; gpos[1] += o1; gpos[2] += o2;
                 g[0] = o3; g[1] = o4; g[2] = o5;
             }
             // state adjoint: lanes 6..18 hold component d-6; sum the two groups of the wave, one atomic per wave
-            R sg = (act && d >= 6 && d < 19) ? out : R(0);
+            double sg = (act && d >= 6 && d < 19) ? out : 0.0;
             sg += __shfl_xor(sg, 32, 64);
-            if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != R(0))
-                __hip_atomic_fetch_add(pg_acc + i * 13 + (d - 6), (double)sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != 0.0)
+                __hip_atomic_fetch_add(pg_acc + i * 13 + (d - 6), sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        const R diff[3] = {v_tmp[0] - v_tgt[0], v_tmp[1] - v_tgt[1], v_tmp[2] - v_tgt[2]};
+        const R diff[3] = {(R)((double)v_tmp[0] - v_tgt[0]), (R)((double)v_tmp[1] - v_tgt[1]), (R)((double)v_tmp[2] - v_tgt[2])};
         if (mask) {
             // adjoint of v_tmp = direct (mixed4) + through the chain (mixed3); mixed2.grad scatter by node
-            const R gvt[3] = {gd[0] + g[0], gd[1] + g[1], gd[2] + g[2]};
+            const R gvt[3] = {(R)((double)gd[0] + g[0]), (R)((double)gd[1] + g[1]), (R)((double)gd[2] + g[2])};
             R gw = R(0);
             if (d < 27) {
                 const bool in_tile = h.block == wg_block && ((nd.okx >> ni) & (nd.oky >> nj) & (nd.okz >> nk) & 1) != 0;
@@ -1091,9 +1160,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                 for (int c = 0; c < 3; ++c) gfx[c] += __shfl_xor(gfx[c], o, 64);
             if (d < 3) {
                 R* Af = frame(D.A, f, D.Npad);
-                const R gp = d == 0 ? gpos[0] : (d == 1 ? gpos[1] : gpos[2]);
+                const double gp = d == 0 ? gpos[0] : (d == 1 ? gpos[1] : gpos[2]);
                 const R gf = d == 0 ? gfx[0] : (d == 1 ? gfx[1] : gfx[2]);
-                Af[(size_t)(CX + d) * D.Npad + p] += gp + D.inv_dx * gf;
+                Af[(size_t)(CX + d) * D.Npad + p] += (R)(gp + (double)(D.inv_dx * gf));
             }
         }
         __syncthreads();
@@ -1114,7 +1183,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
     __syncthreads();
     if (threadIdx.x < D.P * 13 && pg_acc[threadIdx.x] != 0.0) {
         const int i = threadIdx.x / 13, c = threadIdx.x % 13;
-        atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + c, (R)pg_acc[threadIdx.x]);
+        atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + c, pg_acc[threadIdx.x]);
     }
 }
 
@@ -1133,14 +1202,16 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
         Hit h = {0, 0, 0, 0};
         if (hi < nh) h = D.hits[hi];
         const int mask = h.mask, p = h.p;
-        R x[3] = {R(0.5), R(0.5), R(0.5)}, v[3] = {R(0), R(0), R(0)};
+        typename pos_of<R>::type xp[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+        R x[3], v[3] = {R(0), R(0), R(0)};
         if (mask) {
-            load_vec(frame(D.S, f, D.Npad), CX, 3, D.Npad, p, x);
+            load_pos(frame(D.S, f, D.Npad), D.Npad, p, xp);
             load_vec(frame(D.S, f, D.Npad), CV, 3, D.Npad, p, v);
         }
+        pos_to(xp, x);
         Stencil<R> st;
         Nodes nd;
-        stencil_at(D, x, st, nd, h.block);
+        stencil_at(D, xp, st, nd, h.block);
         const int n = d < 27 ? d : 0;
         const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
         const R wn = (ni == 0 ? st.w[0][0] : (ni == 1 ? st.w[1][0] : st.w[2][0])) * (nj == 0 ? st.w[0][1] : (nj == 1 ? st.w[1][1] : st.w[2][1])) *
@@ -1162,13 +1233,14 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
             if (!__ballot(act)) continue;
             R out = R(0);
             if (act && d < 19) {
-                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                R ps[13];
+                prim_state_R(D, i, f, ps);
                 Dual<R> xs[3], vs[3], ss[13], im[3], es[6];
                 for (int c = 0; c < 3; ++c) { xs[c] = Dual<R>(x[c], d == c ? R(1) : R(0)); vs[c] = Dual<R>(v[c], d == 3 + c ? R(1) : R(0)); }
                 for (int c = 0; c < 13; ++c) ss[c] = Dual<R>(ps[c], d == 6 + c ? R(1) : R(0));
                 if (collide_particle(D.prim[i], ss, xs, vs, D.dt, im, es)) {
                     for (int c = 0; c < 3; ++c) out += gi[c] * im[c].d;
-                    for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * es[c].d;
+                    for (int c = 0; c < 6; ++c) out += (R)D.ext_f_grad[i * 6 + c] * es[c].d;
                 }
             }
             if (act && d < 6) {
@@ -1185,7 +1257,7 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
     __syncthreads();
     if (threadIdx.x < D.P * 13 && pg_acc[threadIdx.x] != 0.0) {
         const int i = threadIdx.x / 13, c = threadIdx.x % 13;
-        atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + c, (R)pg_acc[threadIdx.x]);
+        atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + c, pg_acc[threadIdx.x]);
     }
 }
 
@@ -1216,9 +1288,8 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
         R dummy[6];
         for (int q = 0; q < D.P; ++q) {
             if (!D.prim[q].contact) continue;
-            const R* ps = D.prim_state + ((size_t)q * D.max_frames + D.cur_frame) * 13;
             R s13[13];
-            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            prim_state_R(D, q, D.cur_frame, s13);
             collide_grid(D.prim[q], s13, pos, v, m, D.dt, dummy);
         }
     }
@@ -1231,14 +1302,12 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
 #pragma unroll 1
         for (int q = D.P - 1; q >= 0; --q) {
             if (!D.prim[q].contact) continue;
-            const R* ps = D.prim_state + ((size_t)q * D.max_frames + D.cur_frame) * 13;
             R s13[13], vq[3] = {v0[0], v0[1], v0[2]}, dummy[6];
-            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            prim_state_R(D, q, D.cur_frame, s13);
             for (int r = 0; r < q; ++r) {           // velocity entering primitive q
                 if (!D.prim[r].contact) continue;
-                const R* pr = D.prim_state + ((size_t)r * D.max_frames + D.cur_frame) * 13;
                 R sr[13];
-                for (int c = 0; c < 13; ++c) sr[c] = pr[c];
+                prim_state_R(D, r, D.cur_frame, sr);
                 collide_grid(D.prim[r], sr, pos, vq, m, D.dt, dummy);
             }
             R probe[3] = {vq[0], vq[1], vq[2]};
@@ -1251,12 +1320,12 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
                 collide_grid(D.prim[q], ss, pos, vs, Dual<R>(m, dir == 3 ? R(1) : R(0)), D.dt, es);
                 R acc = R(0);
                 for (int c = 0; c < 3; ++c) acc += g[c] * vs[c].d;
-                for (int c = 0; c < 6; ++c) acc += D.ext_f_grad[q * 6 + c] * es[c].d;
+                for (int c = 0; c < 6; ++c) acc += (R)D.ext_f_grad[q * 6 + c] * es[c].d;
                 out[dir] = acc;
             }
             g[0] = out[0]; g[1] = out[1]; g[2] = out[2];
             gm_extra += out[3];
-            for (int c = 0; c < 13; ++c) atomic_add(D.prim_grad + ((size_t)q * D.max_frames + D.cur_frame) * 13 + c, out[4 + c]);
+            for (int c = 0; c < 13; ++c) atomic_add(D.prim_grad + ((size_t)q * D.max_frames + D.cur_frame) * 13 + c, (double)out[4 + c]);
         }
     }
     R gm = R(0);
@@ -1275,7 +1344,8 @@ template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SM
 template <class R, bool ACC_VCF>
 __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
     constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
-    __shared__ R stash[(STASH + (STASH_CE ? 18 : 0)) * BLOCK];
+    typedef typename const_t<R>::type CT;
+    __shared__ CT stash[(STASH + (STASH_CE ? 18 : 0)) * BLOCK];
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     gather_tile_load(D, D.ain, ch.block, gt);
@@ -1286,19 +1356,27 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     R* Af = frame(D.A, f, D.Npad);
     // every global load of the kernel is issued here, in one batch (one memory round trip instead of four);
     // C, E and the SVD factors wait in LDS until the constitutive adjoint needs them
-    R x[3], v[3], aff[9], gFn[9];
+    typename pos_of<R>::type x[3];
+    R v[3], aff[9], gFn[9];
     {
-        R C[9], E[9], Et[9], En[9], stress[9];
+        R C[9], E[9];
+        CT Et[9], En[9], stress[9];
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
-        load_vec(Sf, CX, 3, D.Npad, p, x);
+        load_pos(Sf, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(An, CF, 9, D.Npad, p, gFn);
-        f_tmp(C, E, D.dt, Et);
-        ConstState<R> cs;
-        constitutive_fwd(D.mat, Et, En, stress, cs);
+        ConstState<CT> cs;
+        {
+            CT Cc[9], Ec[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];
+            for (int i = 0; i < 9; ++i) { Cc[i] = (CT)C[i]; Ec[i] = (CT)E[i]; }
+            f_tmp(Cc, Ec, (CT)D.dt, Et);
+            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam};
+            constitutive_fwd(mat, Et, En, stress, cs);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * (R)stress[i] + D.p_mass * C[i];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             stash[i * BLOCK + t] = cs.U[i];
@@ -1320,13 +1398,14 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     if (D.collision_type == CONTACT_PARTICLE && D.any_contact) {      // the contact impulse is part of the scattered momentum
         const int cm = D.pmask[p];
         if (cm) {
+            R xr[3];
+            pos_to(x, xr);
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i) {
                 if (!((cm >> i) & 1)) continue;
-                const R* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                 R s13[13], im[3], ex[6];
-                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                if (collide_particle(D.prim[i], s13, x, v, D.dt, im, ex))
+                prim_state_R(D, i, f, s13);
+                if (collide_particle(D.prim[i], s13, xr, v, D.dt, im, ex))
                     for (int c = 0; c < 3; ++c) imp[c] += im[c];
             }
         }
@@ -1413,9 +1492,10 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         else Af[(size_t)(CV + d) * D.Npad + p] = gvv;
     }
     // constitutive adjoint
-    R gEt[9], Et[9];
+    R gEt[9];
     {
-        ConstState<R> cs;
+        ConstState<CT> cs;
+        CT Et[9], G[9], gFc[9], gEc[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             cs.U[i] = stash[i * BLOCK + t];
@@ -1426,10 +1506,12 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         for (int i = 0; i < 3; ++i) { cs.e[i] = stash[(18 + i) * BLOCK + t]; cs.ep[i] = stash[(21 + i) * BLOCK + t]; }
         cs.Jm1 = stash[33 * BLOCK + t];
         cs.has_svd = true;
-        R G[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) G[i] = D.stress_scale * gaff[i];
-        constitutive_bwd(D.mat, Et, cs, G, gFn, gEt);
+        for (int i = 0; i < 9; ++i) { G[i] = (CT)(D.stress_scale * gaff[i]); gFc[i] = (CT)gFn[i]; }
+        const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam};
+        constitutive_bwd(mat, Et, cs, G, gFc, gEc);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gEt[i] = (R)gEc[i];
     }
     // compute_F_tmp.grad: F_tmp = (I + dt C)(I + E)
     R gC[9], gE[9], Ft[9], A1[9];
@@ -1498,9 +1580,11 @@ template <class R>
 __global__ void k_grid_m_only(const R* x0, const R* x1, const R* x2, int N, int n, R inv_dx, R p_mass, R* out) {
     const int p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= N) return;
-    const R x[3] = {x0[p], x1[p], x2[p]};
+    typedef typename pos_of<R>::type PX;
+    const PX x[3] = {((const PX*)x0)[p], ((const PX*)x1)[p], ((const PX*)x2)[p]};
     Stencil<R> st;
-    make_stencil(x, inv_dx, st);
+    make_stencil_pos(x, n, st);
+    (void)inv_dx;
     int cb[3];
     for (int d = 0; d < 3; ++d) cb[d] = st.base[d] < 0 ? 0 : (st.base[d] > n - 3 ? n - 3 : st.base[d]);
     for (int i = 0; i < 3; ++i)
@@ -1521,7 +1605,7 @@ __global__ void k_count_active(const R* gm, size_t G, unsigned long long* out) {
 
 // forward_kinematics :280-283 and its adjoint (13 inputs -> 7 outputs, forward-mode duals)
 template <class R>
-__global__ void k_prim_fk(R* state, int f, R dt) {
+__global__ void k_prim_fk(R* state, int f, R dt) {      // instantiated with R = double: primitive state is f64 in both modes
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     R* s = state + (size_t)f * 13;
     R o[7];

@@ -14,7 +14,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "smac_math.hpp"
+
 namespace smac {
+
+// position rows of a frame (pos_of<R>: doubles, or 32-bit fixed point in f32 mode)
+template <class R> __device__ __forceinline__ double rd_pos(const R* row, int p) {
+    return pos_get(((const typename pos_of<R>::type*)row)[p]);
+}
 
 struct PointIndex {
     int n;                 // fine cells per dimension (multiple of 8)
@@ -39,7 +46,7 @@ template <class R>
 __global__ void k_pi_count(int m, const R* x0, const R* x1, const R* x2, const double* aos, int n, int* count, int* key_out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= m) return;
-    const double q[3] = {aos ? aos[3 * p] : (double)x0[p], aos ? aos[3 * p + 1] : (double)x1[p], aos ? aos[3 * p + 2] : (double)x2[p]};
+    const double q[3] = {aos ? aos[3 * p] : rd_pos(x0, p), aos ? aos[3 * p + 1] : rd_pos(x1, p), aos ? aos[3 * p + 2] : rd_pos(x2, p)};
     int c[3];
     cell_of_point(n, q, c);
     const int key = vox_key(n, c[0], c[1], c[2]);
@@ -55,9 +62,9 @@ __global__ void k_pi_fill(int m, const R* x0, const R* x1, const R* x2, const do
     const int q = cell_start[k] + atomicAdd(fill + k, 1);
     ids[q] = orig_id ? orig_id[p] : p;
     slots[q] = p;
-    pts[3 * q] = aos ? aos[3 * p] : (double)x0[p];
-    pts[3 * q + 1] = aos ? aos[3 * p + 1] : (double)x1[p];
-    pts[3 * q + 2] = aos ? aos[3 * p + 2] : (double)x2[p];
+    pts[3 * q] = aos ? aos[3 * p] : rd_pos(x0, p);
+    pts[3 * q + 1] = aos ? aos[3 * p + 1] : rd_pos(x1, p);
+    pts[3 * q + 2] = aos ? aos[3 * p + 2] : rd_pos(x2, p);
 }
 
 struct Best { double d2; int id, slot; double p[3]; };
@@ -133,7 +140,7 @@ __global__ void k_chamfer_cur_to_target(int N, const R* x0, const R* x1, const R
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double d2 = 0;
     if (p < N) {
-        const double q[3] = {(double)x0[p], (double)x1[p], (double)x2[p]};
+        const double q[3] = {rd_pos(x0, p), rd_pos(x1, p), rd_pos(x2, p)};
         const Best b = nearest(T, q);
         if (b.slot >= 0) {
             d2 = b.d2;
@@ -181,7 +188,7 @@ __global__ void k_min_dist(int N, const R* x0, const R* x1, const R* x2, const i
     if (p < N) {
         const int id = orig_id ? orig_id[p] : p;
         if (id >= id0 && id < id1) {
-            const double dx = (double)x0[p] - cx, dy = (double)x1[p] - cy, dz = (double)x2[p] - cz;
+            const double dx = rd_pos(x0, p) - cx, dy = rd_pos(x1, p) - cy, dz = rd_pos(x2, p) - cz;
             const float d = (float)fmax(dx * dx + dy * dy + dz * dz - offset, 0.0);
             key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)p;
         }
@@ -201,7 +208,7 @@ __global__ void k_min_dist_finish(const R* x0, const R* x1, const R* x2, const u
     const unsigned long long key = *best;
     if (key == ~0ull) return;
     const int p = (int)(key & 0xffffffffu);
-    const double dx = (double)x0[p] - cx, dy = (double)x1[p] - cy, dz = (double)x2[p] - cz;
+    const double dx = rd_pos(x0, p) - cx, dy = rd_pos(x1, p) - cy, dz = rd_pos(x2, p) - cz;
     const double raw = dx * dx + dy * dy + dz * dz - offset;
     const double v = raw > 0.0 ? raw : 0.0;
     out[0] = v;

@@ -397,6 +397,39 @@ template <class R> SMAC_HD void make_stencil(const R* x, R inv_dx, Stencil<R>& s
 }
 
 // ------------------------------------------------------------------------------------------
+// Particle positions.  R = double: plain doubles.  R = float: 32-bit FIXED POINT on [0, 1) carried in the 4-byte slots of
+// the position rows - a resolution of 2^-32 = 2.3e-10 everywhere in the unit box, where a float has 6e-8 at x ~ 0.5.
+// Same bytes, and it is what lets the f32 mode meet 1e-5: the stencil offset fx = x n - base is then exact to f32
+// (a float x costs 4e-6 of a cell at n = 128), x += dt v accumulates increments of 1e-5 without losing them, and the
+// forecast push-out (sdf / dt) n (primitive_base.py:170) divides a position error of 1e-10, not 3e-8, by dt.
+// The reference keeps particles inside [3 dx, 1 - 3 dx] (boundary_condition :268-281); anything outside [0, 1) saturates.
+// ------------------------------------------------------------------------------------------
+template <class R> struct pos_of { typedef R type; };
+template <> struct pos_of<float> { typedef uint32_t type; };
+SMAC_HD double pos_get(double x) { return x; }
+SMAC_HD double pos_get(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
+SMAC_HD void pos_set(double v, double& o) { o = v; }
+SMAC_HD void pos_set(double v, uint32_t& o) {
+    const double s = v * 4294967296.0 + 0.5;
+    o = !(s > 0.0) ? 0u : (s >= 4294967295.0 ? 4294967295u : (uint32_t)s);          // NaN -> 0
+}
+// the stencil of mpm_simulator.py:215-217 from a stored position (n = n_grid = inv_dx)
+template <class R, class P> SMAC_HD void make_stencil_pos(const P* x, int n, Stencil<R>& s) {
+    for (int d = 0; d < 3; ++d) {
+        const double xs = pos_get(x[d]) * (double)n;
+        const int b = (int)(xs - 0.5);                 // .cast(int): truncation
+        const R fx = (R)(xs - (double)b);
+        s.base[d] = b; s.fx[d] = fx;
+        s.w[0][d] = R(0.5) * (R(1.5) - fx) * (R(1.5) - fx);
+        s.w[1][d] = R(0.75) - (fx - R(1)) * (fx - R(1));
+        s.w[2][d] = R(0.5) * (fx - R(0.5)) * (fx - R(0.5));
+        s.dw[0][d] = -(R(1.5) - fx);
+        s.dw[1][d] = R(-2) * (fx - R(1));
+        s.dw[2][d] = fx - R(0.5);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 3x3 helpers (row-major R[9])
 // ------------------------------------------------------------------------------------------
 template <class R> SMAC_HD void mm(const R* A, const R* B, R* C) {          // C = A B
@@ -681,11 +714,15 @@ SMAC_HD void constitutive_bwd(const Material<R>& M, const R* Et, const ConstStat
                         bool inside = (e[i] > R(-2e-3)) && (e[i] < R(3e-3));     // clip passes the gradient
                         T[3 * i + j] = (plastic && inside) ? ma_ij : R(0);
                     } else {
-                        R ds = e[j] - e[i];
+                        // reference: K (ma_ij (a_j - a_i) + ma_ji b + (MB_ij - MB_ji) ds) with a = s s' - 1, b = s_i s'_j - s'_i s_j.
+                        // Written on the differences ds = e_j - e_i, ds' = e'_j - e'_i:
+                        //     a_j - a_i = ds (1 + e'_i) + ds' (1 + e_j),     b = ds' (1 + e_i) - ds (1 + e'_i),
+                        // the bracket is K ds [...] + K ds' [...], and K ds = 1 / (2 + e_i + e_j) outside the clamp: the
+                        // rounding of nearly equal strains cancels instead of being multiplied by K (up to 1e6)
+                        R ds = e[j] - e[i], dsp = ep[j] - ep[i];
                         R K = R(1) / clamp_ref(ds * (R(2) + e[i] + e[j]));       // 1/clamp(s_j^2 - s_i^2)
-                        R a_j = e[j] + ep[j] + e[j] * ep[j], a_i = e[i] + ep[i] + e[i] * ep[i];
-                        R b = (e[i] + ep[j] + e[i] * ep[j]) - (ep[i] + e[j] + ep[i] * e[j]);
-                        T[3 * i + j] = K * (ma_ij * (a_j - a_i) + ma_ji * b + (MB[3 * i + j] - MB[3 * j + i]) * ds);
+                        T[3 * i + j] = (K * ds) * ((ma_ij - ma_ji) * (R(1) + ep[i]) + (MB[3 * i + j] - MB[3 * j + i])) +
+                                       (K * dsp) * (ma_ij * (R(1) + e[j]) + ma_ji * (R(1) + e[i]));
                     }
                     if (!plastic) T[3 * i + j] += MAs[3 * i + j];      // elastic: new_F = F_tmp directly
                 }

@@ -53,10 +53,12 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, 
         vmax_part[blockIdx.x] = m;
     }
     if (p >= N) return;
-    const R x[3] = {x0[p], x1[p], x2[p]};
+    typedef typename pos_of<R>::type PX;                 // position rows: smac_math.hpp pos_of
+    const PX x[3] = {((const PX*)x0)[p], ((const PX*)x1)[p], ((const PX*)x2)[p]};
+    (void)inv_dx;
     int b[3];
     for (int d = 0; d < 3; ++d) {
-        int v = (int)(x[d] * inv_dx - R(0.5));
+        int v = (int)(pos_get(x[d]) * (double)n - 0.5);  // the base of make_stencil_pos
         b[d] = v < 0 ? 0 : (v > n - 3 ? n - 3 : v);
     }
     const size_t cell = cell_of(nb, b[0], b[1], b[2]);
@@ -119,12 +121,22 @@ __global__ void k_sort_dest(int N, const int* key, const int* slot, const int* b
 }
 
 // Host IO: f64 AOS arrays in the caller's particle order <-> component rows of a frame in the order of an epoch
-// (orig[q] = caller's id of the particle in slot q; nullptr = identity).  `ident`: the rows hold F - I, the host sees F.
+// (orig[q] = caller's id of the particle in slot q; nullptr = identity).  `ident` 1: the rows hold F - I, the host sees F;
+// `ident` 2: position rows (pos_of<R>: fixed point in f32 mode), padding slots sit at the middle of the box.
 template <class R>
 __global__ void k_rows_from_aos(int N, int Npad, const double* src, int stride, int offset, int cnt, const int* orig, int ident, R* rows) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Npad) return;
     const size_t id = q < N ? (size_t)(orig ? orig[q] : q) : 0;
+    if (ident == 2) {
+        typedef typename pos_of<R>::type PX;
+        for (int c = 0; c < cnt; ++c) {
+            PX v;
+            pos_set(q < N ? src[id * stride + offset + c] : 0.5, v);
+            ((PX*)rows)[(size_t)c * Npad + q] = v;
+        }
+        return;
+    }
     for (int c = 0; c < cnt; ++c) {
         const double sub = (ident && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
         rows[(size_t)c * Npad + q] = q < N ? (R)(src[id * stride + offset + c] - sub) : R(0);
@@ -142,6 +154,11 @@ __global__ void k_rows_to_aos(int N, int Npad, const R* rows, int cnt, const int
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= N) return;
     const size_t id = (size_t)(orig ? orig[q] : q);
+    if (ident == 2) {
+        typedef typename pos_of<R>::type PX;
+        for (int c = 0; c < cnt; ++c) dst[id * stride + offset + c] = pos_get(((const PX*)rows)[(size_t)c * Npad + q]);
+        return;
+    }
     for (int c = 0; c < cnt; ++c) {
         const double add = (ident && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
         dst[id * stride + offset + c] = (double)rows[(size_t)c * Npad + q] + add;

@@ -37,6 +37,9 @@ static thread_local std::string g_create_error;
     } while (0)
 
 enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_COUNT };
+static const char* kDriftMessage =
+    "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort "
+    "interval): the frames after that substep are invalid - lower sort_interval or dt";
 static const char* kKernelNames[K_COUNT] = {"clear_grid", "grid_checkpoint", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
                                             "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint"};
 
@@ -54,6 +57,7 @@ struct ISim {
     virtual int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) = 0;
     virtual int clear_grads() = 0;
     virtual int set_control_idx(const int32_t* idx) = 0;
+    virtual int set_action_v(const double* action) = 0;
     virtual int compute_grid_m(int f, double* out) = 0;
     virtual int substep(int f, const double* action) = 0;
     virtual int substep_grad(int f, const double* action, const double* ext_f_grad, double* action_grad_out) = 0;
@@ -96,8 +100,9 @@ template <class R> struct Sim final : ISim {
     hipStream_t stream = nullptr;
     Vec4<R>* grid_block = nullptr;   // 6 fields of G 4-scalar records: vin, vmix, vout, then their adjoints
     R* prim_tables[SMAC_MAX_PRIMS][2] = {};
-    R* action_buf = nullptr;      // per-primitive velocity-control action buffer [P][max_frames][6] + its grad
-    R* action_buf_grad = nullptr;
+    double* prim_tables64[SMAC_MAX_PRIMS][2] = {};   // f64 copies for the forecast contact chain (the same buffers when R = double)
+    double* action_buf = nullptr;      // per-primitive velocity-control action buffer [P][max_frames][6] + its grad
+    double* action_buf_grad = nullptr;
     unsigned long long* d_counter = nullptr;
     int* d_control_idx = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -178,7 +183,10 @@ template <class R> struct Sim final : ISim {
         hipFree(d_io);
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
         hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits);
-        for (auto& t : prim_tables) { hipFree(t[0]); hipFree(t[1]); }
+        for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
+            if ((void*)prim_tables64[i][0] != (void*)prim_tables[i][0]) { hipFree(prim_tables64[i][0]); hipFree(prim_tables64[i][1]); }
+            hipFree(prim_tables[i][0]); hipFree(prim_tables[i][1]);
+        }
         for (auto e : pool) hipEventDestroy(e);
         for (auto& r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
         if (t0) hipEventDestroy(t0);
@@ -217,6 +225,7 @@ template <class R> struct Sim final : ISim {
         D.sticky = c.ground_friction >= 10.0 ? 1 : 0;
         D.max_frames = c.max_frames;
         D.dt = (R)c.dt;
+        D.dt64 = c.dt;
         D.inv_dx = (R)c.n_grid;
         D.dx = (R)(1.0 / c.n_grid);
         D.p_mass = (R)c.p_mass;
@@ -244,15 +253,15 @@ template <class R> struct Sim final : ISim {
         D.hits = d_hits;
         D.pmask = d_pmask;
         const int Pn = c.n_primitives > 0 ? c.n_primitives : 1;
-        const size_t ps = (size_t)Pn * c.max_frames * 13 * sizeof(R);
+        const size_t ps = (size_t)Pn * c.max_frames * 13 * sizeof(double);          // primitive state is f64 in both modes
         HIP_TRY(hipMalloc((void**)&D.prim_state, ps));
         HIP_TRY(hipMalloc((void**)&D.prim_grad, ps));
         HIP_TRY(hipMemsetAsync(D.prim_state, 0, ps, stream));
         HIP_TRY(hipMemsetAsync(D.prim_grad, 0, ps, stream));
-        HIP_TRY(hipMalloc((void**)&D.ext_f, 2 * Pn * 6 * sizeof(R)));
-        HIP_TRY(hipMemsetAsync(D.ext_f, 0, 2 * Pn * 6 * sizeof(R), stream));
+        HIP_TRY(hipMalloc((void**)&D.ext_f, 2 * Pn * 6 * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(D.ext_f, 0, 2 * Pn * 6 * sizeof(double), stream));
         D.ext_f_grad = D.ext_f + Pn * 6;
-        const size_t ab = (size_t)Pn * c.max_frames * 6 * sizeof(R);
+        const size_t ab = (size_t)Pn * c.max_frames * 6 * sizeof(double);
         HIP_TRY(hipMalloc((void**)&action_buf, ab));
         HIP_TRY(hipMalloc((void**)&action_buf_grad, ab));
         HIP_TRY(hipMemsetAsync(action_buf, 0, ab, stream));
@@ -305,6 +314,9 @@ template <class R> struct Sim final : ISim {
             D.prim[i].sdf = nullptr; D.prim[i].normal = nullptr; D.prim[i].contact = 0;
             D.prim[i].friction = (R)0.9; D.prim[i].softness = (R)666.0; D.prim[i].inv_dx = (R)1;
             for (int d = 0; d < 3; ++d) { D.prim[i].res[d] = 2; D.prim[i].lower[d] = 0; D.prim[i].upper[d] = 0; }
+            D.prim64[i].sdf = nullptr; D.prim64[i].normal = nullptr; D.prim64[i].contact = 0;
+            D.prim64[i].friction = 0.9; D.prim64[i].softness = 666.0; D.prim64[i].inv_dx = 1.0;
+            for (int d = 0; d < 3; ++d) { D.prim64[i].res[d] = 2; D.prim64[i].lower[d] = 0; D.prim64[i].upper[d] = 0; }
         }
         HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
@@ -361,22 +373,22 @@ template <class R> struct Sim final : ISim {
         }
         return SMAC_OK;
     }
-    int upload_comp(R* base, int f, int c0, int cnt, const double* src, bool minus_identity, int e) {
+    int upload_comp(R* base, int f, int c0, int cnt, const double* src, int kind, int e) {     // kind: k_rows_from_aos `ident`
         int rc;
         if ((rc = io_buffer((size_t)D.N * cnt))) return rc;
         HIP_TRY(hipMemcpyAsync(d_io, src, (size_t)D.N * cnt * sizeof(double), hipMemcpyHostToDevice, stream));
         R* d = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
         hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cnt, 0, cnt,
-                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, minus_identity ? 1 : 0, d);
+                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, kind, d);
         HIP_TRY(hipStreamSynchronize(stream));
         return check_launch();
     }
-    int download_comp(const R* base, int f, int c0, int cnt, double* dst, bool plus_identity, int e) {
+    int download_comp(const R* base, int f, int c0, int cnt, double* dst, int kind, int e) {
         int rc;
         if ((rc = io_buffer((size_t)D.N * cnt))) return rc;
         const R* s = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
         hipLaunchKernelGGL(k_rows_to_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, s, cnt,
-                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, plus_identity ? 1 : 0, d_io, cnt, 0);
+                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, kind, d_io, cnt, 0);
         HIP_TRY(hipMemcpyAsync(dst, d_io, (size_t)D.N * cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return check_launch();
@@ -392,15 +404,15 @@ template <class R> struct Sim final : ISim {
         if (frame_epoch[f] < 0) frame_epoch[f] = 0;          // first write: identity order
         ck_epoch[f] = -1;                                    // the saved forward grid of this frame is stale
         const int e = frame_epoch[f];
-        if (x && (rc = upload_comp(D.S, f, CX, 3, x, false, e))) return rc;
-        if (v && (rc = upload_comp(D.S, f, CV, 3, v, false, e))) return rc;
-        if (C && (rc = upload_comp(D.S, f, CC, 9, C, false, e))) return rc;
-        if (F && (rc = upload_comp(D.S, f, CF, 9, F, true, e))) return rc;
+        if (x && (rc = upload_comp(D.S, f, CX, 3, x, 2, e))) return rc;
+        if (v && (rc = upload_comp(D.S, f, CV, 3, v, 0, e))) return rc;
+        if (C && (rc = upload_comp(D.S, f, CC, 9, C, 0, e))) return rc;
+        if (F && (rc = upload_comp(D.S, f, CF, 9, F, 1, e))) return rc;
         return SMAC_OK;
     }
     int get_state24(int f, double* out) override {                            // mpm_simulator.py:541-548 get_state: (N, 24) = x3 v3 F9 C9
         int rc = check_frame(f);
-        if (rc) return rc;
+        if (rc || (rc = check_drift())) return rc;
         REQUIRE(out, "null argument");
         const int e = frame_epoch[f] < 0 ? 0 : frame_epoch[f];
         if ((rc = io_buffer((size_t)D.N * 24))) return rc;
@@ -410,19 +422,19 @@ template <class R> struct Sim final : ISim {
             hipLaunchKernelGGL(k_rows_to_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, fr + (size_t)c0 * D.Npad, cnt, orig, ident,
                                d_io, 24, offset);
         };
-        rows(CX, 3, 0, 0); rows(CV, 3, 3, 0); rows(CF, 9, 6, 1); rows(CC, 9, 15, 0);
+        rows(CX, 3, 0, 2); rows(CV, 3, 3, 0); rows(CF, 9, 6, 1); rows(CC, 9, 15, 0);
         HIP_TRY(hipMemcpyAsync(out, d_io, (size_t)D.N * 24 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return check_launch();
     }
     int get_frame(int f, double* x, double* v, double* F, double* C) override {
         int rc = check_frame(f);
-        if (rc) return rc;
+        if (rc || (rc = check_drift())) return rc;
         const int e = frame_epoch[f] < 0 ? 0 : frame_epoch[f];
-        if (x && (rc = download_comp(D.S, f, CX, 3, x, false, e))) return rc;
-        if (v && (rc = download_comp(D.S, f, CV, 3, v, false, e))) return rc;
-        if (C && (rc = download_comp(D.S, f, CC, 9, C, false, e))) return rc;
-        if (F && (rc = download_comp(D.S, f, CF, 9, F, true, e))) return rc;
+        if (x && (rc = download_comp(D.S, f, CX, 3, x, 2, e))) return rc;
+        if (v && (rc = download_comp(D.S, f, CV, 3, v, 0, e))) return rc;
+        if (C && (rc = download_comp(D.S, f, CC, 9, C, 0, e))) return rc;
+        if (F && (rc = download_comp(D.S, f, CF, 9, F, 1, e))) return rc;
         return SMAC_OK;
     }
     int reset(const double* state, int cols) override {                       // mpm_simulator.py:494-519
@@ -438,7 +450,7 @@ template <class R> struct Sim final : ISim {
             hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cols, offset,
                                cnt, (const int*)nullptr, ident, fr + (size_t)c0 * D.Npad);
         };
-        rows(CX, 3, 0, 0);
+        rows(CX, 3, 0, 2);
         if (cols == 24) {
             rows(CV, 3, 3, 0);
             rows(CF, 9, 6, 1);
@@ -461,11 +473,11 @@ template <class R> struct Sim final : ISim {
         for (int i = 0; i < D.P; ++i)
             for (int j = 0; j < cfg.substeps; ++j) {
                 if (src + j >= cfg.max_frames || dst + j >= cfg.max_frames) break;
-                R* base = D.prim_state + (size_t)i * cfg.max_frames * 13;
-                HIP_TRY(hipMemcpyAsync(base + (size_t)(dst + j) * 13, base + (size_t)(src + j) * 13, 13 * sizeof(R),
+                double* base = D.prim_state + (size_t)i * cfg.max_frames * 13;
+                HIP_TRY(hipMemcpyAsync(base + (size_t)(dst + j) * 13, base + (size_t)(src + j) * 13, 13 * sizeof(double),
                                        hipMemcpyDeviceToDevice, stream));
-                R* ab = action_buf + (size_t)i * cfg.max_frames * 6;
-                HIP_TRY(hipMemcpyAsync(ab + (size_t)(dst + j) * 6, ab + (size_t)(src + j) * 6, 6 * sizeof(R),
+                double* ab = action_buf + (size_t)i * cfg.max_frames * 6;
+                HIP_TRY(hipMemcpyAsync(ab + (size_t)(dst + j) * 6, ab + (size_t)(src + j) * 6, 6 * sizeof(double),
                                        hipMemcpyDeviceToDevice, stream));
             }
         return SMAC_OK;
@@ -484,13 +496,13 @@ template <class R> struct Sim final : ISim {
     }
     int get_grad(int f, double* gx, double* gv, double* gF, double* gC) override {
         int rc;
-        if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
+        if ((rc = need_grad()) || (rc = check_frame(f)) || (rc = check_drift())) return rc;
         if (adj_epoch[f] < 0 && (rc = adj_make_zero(f))) return rc;
         const int e = adj_epoch[f] < 0 ? 0 : adj_epoch[f];
-        if (gx && (rc = download_comp(D.A, f, CX, 3, gx, false, e))) return rc;
-        if (gv && (rc = download_comp(D.A, f, CV, 3, gv, false, e))) return rc;
-        if (gC && (rc = download_comp(D.A, f, CC, 9, gC, false, e))) return rc;
-        if (gF && (rc = download_comp(D.A, f, CF, 9, gF, false, e))) return rc;
+        if (gx && (rc = download_comp(D.A, f, CX, 3, gx, 0, e))) return rc;
+        if (gv && (rc = download_comp(D.A, f, CV, 3, gv, 0, e))) return rc;
+        if (gC && (rc = download_comp(D.A, f, CC, 9, gC, 0, e))) return rc;
+        if (gF && (rc = download_comp(D.A, f, CF, 9, gF, 0, e))) return rc;
         return SMAC_OK;
     }
     int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) override {
@@ -516,9 +528,9 @@ template <class R> struct Sim final : ISim {
         if (D.A) adj_stale.assign(cfg.max_frames, 1);                              // zeroed on demand (adj_make_zero)
         adj_epoch.assign(cfg.max_frames, -1);
         const int Pn = D.P > 0 ? D.P : 1;
-        HIP_TRY(hipMemsetAsync(D.prim_grad, 0, (size_t)Pn * cfg.max_frames * 13 * sizeof(R), stream));
-        HIP_TRY(hipMemsetAsync(action_buf_grad, 0, (size_t)Pn * cfg.max_frames * 6 * sizeof(R), stream));
-        HIP_TRY(hipMemsetAsync(D.ext_f_grad, 0, Pn * 6 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(D.prim_grad, 0, (size_t)Pn * cfg.max_frames * 13 * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(action_buf_grad, 0, (size_t)Pn * cfg.max_frames * 6 * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(D.ext_f_grad, 0, Pn * 6 * sizeof(double), stream));
         HIP_TRY(hipMemsetAsync(D.action_grad, 0, (D.n_control > 0 ? D.n_control : 1) * 3 * sizeof(R), stream));
         HIP_TRY(hipMemsetAsync(grid_block + 3 * D.G, 0, 3 * D.G * sizeof(Vec4<R>), stream));
         return SMAC_OK;
@@ -601,7 +613,7 @@ template <class R> struct Sim final : ISim {
     }
     int loss_chamfer(int f, double weight, int add_grad, double* loss_out) override {   // loss_pour.py:44-70 (+ its adjoint)
         int rc;
-        if ((rc = check_frame(f))) return rc;
+        if ((rc = check_frame(f)) || (rc = check_drift())) return rc;
         REQUIRE(n_target > 0, "loss_chamfer: no target set (smac_loss_set_target)");
         REQUIRE(frame_epoch[f] >= 0, "loss_chamfer: frame holds no state");
         const int e = frame_epoch[f];
@@ -642,7 +654,7 @@ template <class R> struct Sim final : ISim {
     double* d_md_out = nullptr;
     int loss_min_dist(int f, int id0, int id1, const double* c3, double offset, double weight, int add_grad, double* out4) override {
         int rc;
-        if ((rc = check_frame(f))) return rc;
+        if ((rc = check_frame(f)) || (rc = check_drift())) return rc;
         REQUIRE(c3 && out4, "null argument");
         REQUIRE(frame_epoch[f] >= 0, "loss_min_dist: frame holds no state");
         REQUIRE(id0 >= 0 && id0 < id1 && id1 <= D.N, "loss_min_dist: bad particle range");
@@ -789,12 +801,9 @@ template <class R> struct Sim final : ISim {
         int drifted = 0;
         if (read_drift) HIP_TRY(hipMemcpyAsync(&drifted, d_drift, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (drifted) {                                                        // same report as check_drift(), without its own sync
-            HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
-            epoch_pool.push_back(std::move(ep));
-            err = "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort interval): lower sort_interval or dt";
-            return SMAC_ERR_INVALID;
-        }
+        // a drift error of the epoch that ends here is reported AFTER the new epoch is committed: S[f] is already in the
+        // new order, so frame_epoch[f] must name it or every later get_state / set_frame of this frame would be scrambled
+        if (drifted) HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
         {
             // A particle may move 4 cells (its block's halo) before the binning breaks; budget 2 cells for the fastest
             // particle at its current speed, which leaves a factor two for acceleration inside the interval.
@@ -807,7 +816,11 @@ template <class R> struct Sim final : ISim {
         }
         ep.nchunks = totals[0];
         ep.nactive = totals[1];
-        REQUIRE((size_t)ep.nchunks <= chunk_capacity(), "internal: chunk list capacity exceeded");
+        if ((size_t)ep.nchunks > chunk_capacity()) {
+            epoch_pool.push_back(std::move(ep));                                  // (device buffers go back to the pool)
+            err = "internal: chunk list capacity exceeded";
+            return SMAC_ERR_INVALID;
+        }
         hipLaunchKernelGGL(k_emit_lists, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.N, (const int*)d_bin_start,
                            (const int*)d_block_start, (const int*)d_block_chunks, (const int*)d_chunk_start,
                            (const int*)d_active_flag, (const int*)d_active_start, ep.chunks, ep.active);
@@ -825,6 +838,10 @@ template <class R> struct Sim final : ISim {
             slab_chunks = (size_t)epochs[e_new].nchunks + epochs[e_new].nchunks / 8 + 16;
             HIP_TRY(hipMalloc((void**)&slab, slab_chunks * TILE_WORDS * sizeof(Vec4<R>)));
             HIP_TRY(hipMalloc((void**)&d_cand, slab_chunks * sizeof(int)));
+        }
+        if (drifted) {
+            err = kDriftMessage;
+            return SMAC_ERR_INVALID;
         }
         return check_launch();
     }
@@ -884,7 +901,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h) {
             HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
-            err = "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort interval): lower sort_interval or dt";
+            err = kDriftMessage;
             return SMAC_ERR_INVALID;
         }
         return SMAC_OK;
@@ -895,6 +912,10 @@ template <class R> struct Sim final : ISim {
         for (int i = 0; i < D.P; ++i)
             if (D.prim[i].contact) return true;
         return false;
+    }
+    int set_action_v(const double* action) override {
+        REQUIRE(action, "null action");
+        return set_action(action);
     }
     int set_action(const double* action) {                                    // :579-592
         REQUIRE(D.n_control > 0, "action given but n_control == 0");
@@ -914,9 +935,9 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     // the recompute pass of substep_grad must not double-count ext_f: send its wrench sums to a scratch slot
-    R* scratch = nullptr;
-    R* scratch_ext() {
-        if (!scratch) hipMalloc((void**)&scratch, SMAC_MAX_PRIMS * 6 * sizeof(R));
+    double* scratch = nullptr;
+    double* scratch_ext() {
+        if (!scratch) (void)hipMalloc((void**)&scratch, SMAC_MAX_PRIMS * 6 * sizeof(double));
         return scratch;
     }
     int ngrid_blocks() const { return (D.nactive + 3) / 4; }
@@ -1026,6 +1047,7 @@ template <class R> struct Sim final : ISim {
             }
             if (D.nchunks > 0) {
                 prof_begin(K_G2P);
+                D.check_next = (f + 1 - epochs[e].frame < epochs[e].interval) ? 1 : 0;     // else substep(f+1) re-bins first
                 hipLaunchKernelGGL(k_g2p<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
             }
@@ -1049,9 +1071,7 @@ template <class R> struct Sim final : ISim {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
             if (ext_f_grad && D.P > 0) {                                          // :342-344
-                R tmp[6 * SMAC_MAX_PRIMS];
-                for (int i = 0; i < 6 * D.P; ++i) tmp[i] = (R)ext_f_grad[i];
-                HIP_TRY(hipMemcpyAsync(D.ext_f_grad, tmp, 6 * D.P * sizeof(R), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(D.ext_f_grad, ext_f_grad, 6 * D.P * sizeof(double), hipMemcpyHostToDevice, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
             }
             if ((rc = bind_epoch(e))) return rc;
@@ -1180,8 +1200,8 @@ template <class R> struct Sim final : ISim {
         REQUIRE(prim >= 0 && prim < D.P, "primitive index out of range");
         return SMAC_OK;
     }
-    R* pstate(int prim) { return D.prim_state + (size_t)prim * cfg.max_frames * 13; }
-    R* pgrad(int prim) { return D.prim_grad + (size_t)prim * cfg.max_frames * 13; }
+    double* pstate(int prim) { return D.prim_state + (size_t)prim * cfg.max_frames * 13; }
+    double* pgrad(int prim) { return D.prim_grad + (size_t)prim * cfg.max_frames * 13; }
     int prim_upload_sdf(int prim, const double* sdf, const double* normal, const int32_t* res, const double* lower,
                         const double* upper, double dx) override {
         int rc = check_prim(prim);
@@ -1189,18 +1209,38 @@ template <class R> struct Sim final : ISim {
         REQUIRE(sdf && normal && res && lower && upper && dx > 0, "null table");
         REQUIRE(res[0] >= 2 && res[1] >= 2 && res[2] >= 2, "sdf res < 2");
         const size_t cells = (size_t)res[0] * res[1] * res[2];
-        std::vector<R> ts(cells), tn(cells * 3);
-        for (size_t i = 0; i < cells; ++i) ts[i] = (R)sdf[i];
-        for (size_t i = 0; i < cells * 3; ++i) tn[i] = (R)normal[i];
+        HIP_TRY(hipStreamSynchronize(stream));
+        if ((void*)prim_tables64[prim][0] != (void*)prim_tables[prim][0]) { hipFree(prim_tables64[prim][0]); hipFree(prim_tables64[prim][1]); }
         hipFree(prim_tables[prim][0]); hipFree(prim_tables[prim][1]);
-        HIP_TRY(hipMalloc((void**)&prim_tables[prim][0], cells * sizeof(R)));
-        HIP_TRY(hipMalloc((void**)&prim_tables[prim][1], cells * 3 * sizeof(R)));
-        HIP_TRY(hipMemcpy(prim_tables[prim][0], ts.data(), cells * sizeof(R), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(prim_tables[prim][1], tn.data(), cells * 3 * sizeof(R), hipMemcpyHostToDevice));
+        prim_tables[prim][0] = prim_tables[prim][1] = nullptr;
+        prim_tables64[prim][0] = prim_tables64[prim][1] = nullptr;
+        // f64 tables for the forecast contact chain; in f32 mode a float copy serves the band filter and collision types 0 / 1
+        HIP_TRY(hipMalloc((void**)&prim_tables64[prim][0], cells * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&prim_tables64[prim][1], cells * 3 * sizeof(double)));
+        HIP_TRY(hipMemcpy(prim_tables64[prim][0], sdf, cells * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(prim_tables64[prim][1], normal, cells * 3 * sizeof(double), hipMemcpyHostToDevice));
+        if (sizeof(R) == sizeof(double)) {
+            prim_tables[prim][0] = (R*)prim_tables64[prim][0];
+            prim_tables[prim][1] = (R*)prim_tables64[prim][1];
+        } else {
+            std::vector<R> ts(cells), tn(cells * 3);
+            for (size_t i = 0; i < cells; ++i) ts[i] = (R)sdf[i];
+            for (size_t i = 0; i < cells * 3; ++i) tn[i] = (R)normal[i];
+            HIP_TRY(hipMalloc((void**)&prim_tables[prim][0], cells * sizeof(R)));
+            HIP_TRY(hipMalloc((void**)&prim_tables[prim][1], cells * 3 * sizeof(R)));
+            HIP_TRY(hipMemcpy(prim_tables[prim][0], ts.data(), cells * sizeof(R), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(prim_tables[prim][1], tn.data(), cells * 3 * sizeof(R), hipMemcpyHostToDevice));
+        }
         PrimTable<R>& T = D.prim[prim];
+        PrimTable<double>& T64 = D.prim64[prim];
         T.sdf = prim_tables[prim][0]; T.normal = prim_tables[prim][1];
-        for (int d = 0; d < 3; ++d) { T.res[d] = res[d]; T.lower[d] = (R)lower[d]; T.upper[d] = (R)upper[d]; }
+        T64.sdf = prim_tables64[prim][0]; T64.normal = prim_tables64[prim][1];
+        for (int d = 0; d < 3; ++d) {
+            T.res[d] = res[d]; T.lower[d] = (R)lower[d]; T.upper[d] = (R)upper[d];
+            T64.res[d] = res[d]; T64.lower[d] = lower[d]; T64.upper[d] = upper[d];
+        }
         T.inv_dx = (R)(1.0 / dx);                                             // mesh.py:29
+        T64.inv_dx = 1.0 / dx;
         ++config_gen;
         return SMAC_OK;
     }
@@ -1208,6 +1248,7 @@ template <class R> struct Sim final : ISim {
         int rc = check_prim(prim);
         if (rc) return rc;
         D.prim[prim].friction = (R)friction; D.prim[prim].softness = (R)softness; D.prim[prim].contact = contact ? 1 : 0;
+        D.prim64[prim].friction = friction; D.prim64[prim].softness = softness; D.prim64[prim].contact = contact ? 1 : 0;
         ++config_gen;
         return SMAC_OK;
     }
@@ -1216,41 +1257,39 @@ template <class R> struct Sim final : ISim {
         if (rc) return rc;
         REQUIRE(s13 && f0 >= 0 && f1 <= cfg.max_frames && f0 < f1, "prim_set_state: bad frame range");
         for (int f = f0; f < f1; ++f) ck_epoch[f] = -1;
-        std::vector<R> tmp((size_t)(f1 - f0) * 13);
+        std::vector<double> tmp((size_t)(f1 - f0) * 13);
         for (int f = 0; f < f1 - f0; ++f)
-            for (int c = 0; c < 13; ++c) tmp[(size_t)f * 13 + c] = (R)s13[c];
-        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)f0 * 13, tmp.data(), tmp.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+            for (int c = 0; c < 13; ++c) tmp[(size_t)f * 13 + c] = s13[c];
+        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)f0 * 13, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
     }
     int prim_get_state(int prim, int f, double* s13) override {
         int rc;
         if ((rc = check_prim(prim)) || (rc = check_frame(f))) return rc;
-        R tmp[13];
-        HIP_TRY(hipMemcpyAsync(tmp, pstate(prim) + (size_t)f * 13, sizeof tmp, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(s13, pstate(prim) + (size_t)f * 13, 13 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        for (int c = 0; c < 13; ++c) s13[c] = (double)tmp[c];
         return SMAC_OK;
     }
     int prim_get_state_grad(int prim, int f0, int f1, double* g13) override {
         int rc = check_prim(prim);
         if (rc) return rc;
         REQUIRE(g13 && f0 >= 0 && f1 <= cfg.max_frames && f0 < f1, "prim_get_state_grad: bad frame range");
-        std::vector<R> tmp((size_t)(f1 - f0) * 13);
-        HIP_TRY(hipMemcpyAsync(tmp.data(), pgrad(prim) + (size_t)f0 * 13, tmp.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        std::vector<double> tmp((size_t)(f1 - f0) * 13);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), pgrad(prim) + (size_t)f0 * 13, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         for (int c = 0; c < 13; ++c) g13[c] = 0;
         for (int f = 0; f < f1 - f0; ++f)
-            for (int c = 0; c < 13; ++c) g13[c] += (double)tmp[(size_t)f * 13 + c];
+            for (int c = 0; c < 13; ++c) g13[c] += tmp[(size_t)f * 13 + c];
         return SMAC_OK;
     }
     int prim_add_state_grad(int prim, int f, const double* g13) override {
         int rc;
         if ((rc = check_prim(prim)) || (rc = check_frame(f))) return rc;
-        R tmp[13];
+        double tmp[13];
         HIP_TRY(hipMemcpyAsync(tmp, pgrad(prim) + (size_t)f * 13, sizeof tmp, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        for (int c = 0; c < 13; ++c) tmp[c] += (R)g13[c];
+        for (int c = 0; c < 13; ++c) tmp[c] += g13[c];
         HIP_TRY(hipMemcpyAsync(pgrad(prim) + (size_t)f * 13, tmp, sizeof tmp, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
@@ -1260,7 +1299,7 @@ template <class R> struct Sim final : ISim {
         if (rc) return rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");
         prof_begin(K_FK);
-        hipLaunchKernelGGL(k_prim_fk<R>, dim3(1), dim3(64), 0, stream, pstate(prim), f, D.dt);
+        hipLaunchKernelGGL(k_prim_fk<double>, dim3(1), dim3(64), 0, stream, pstate(prim), f, D.dt64);
         prof_end();
         return check_launch();
     }
@@ -1269,24 +1308,22 @@ template <class R> struct Sim final : ISim {
         if (rc) return rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "forward_kinematics.grad: frame out of range");
         prof_begin(K_FK);
-        hipLaunchKernelGGL(k_prim_fk_grad<R>, dim3(1), dim3(64), 0, stream, (const R*)pstate(prim), pgrad(prim), f, D.dt);
+        hipLaunchKernelGGL(k_prim_fk_grad<double>, dim3(1), dim3(64), 0, stream, (const double*)pstate(prim), pgrad(prim), f, D.dt64);
         prof_end();
         return check_launch();
     }
     int prim_get_ext_f(int prim, double* e6) override {
         int rc = check_prim(prim);
         if (rc) return rc;
-        R tmp[6];
-        HIP_TRY(hipMemcpyAsync(tmp, D.ext_f + prim * 6, sizeof tmp, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(e6, D.ext_f + prim * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        for (int c = 0; c < 6; ++c) e6[c] = (double)tmp[c];
         return SMAC_OK;
     }
     int prim_clear_ext_f(int prim) override {                                 // :183-187 (value and grad)
         int rc = check_prim(prim);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(D.ext_f + prim * 6, 0, 6 * sizeof(R), stream));
-        HIP_TRY(hipMemsetAsync(D.ext_f_grad + prim * 6, 0, 6 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(D.ext_f + prim * 6, 0, 6 * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(D.ext_f_grad + prim * 6, 0, 6 * sizeof(double), stream));
         return SMAC_OK;
     }
     // velocity control (primitive_base.py:285-319): action_buffer[s] = a6 ; v[j] = a[3:6], w[j] = a[0:3] for j in [s n, (s+1) n)
@@ -1295,15 +1332,13 @@ template <class R> struct Sim final : ISim {
         if (rc) return rc;
         REQUIRE(a6 && s >= 0 && n >= 1 && (s + 1) * n <= cfg.max_frames, "prim_set_action: frames out of range");
         for (int f = s * n; f < (s + 1) * n; ++f) ck_epoch[f] = -1;
-        R a[6];
-        for (int c = 0; c < 6; ++c) a[c] = (R)a6[c];
-        HIP_TRY(hipMemcpyAsync(action_buf + ((size_t)prim * cfg.max_frames + s) * 6, a, sizeof a, hipMemcpyHostToDevice, stream));
-        std::vector<R> cur((size_t)n * 13);
-        HIP_TRY(hipMemcpyAsync(cur.data(), pstate(prim) + (size_t)s * n * 13, cur.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(action_buf + ((size_t)prim * cfg.max_frames + s) * 6, a6, 6 * sizeof(double), hipMemcpyHostToDevice, stream));
+        std::vector<double> cur((size_t)n * 13);
+        HIP_TRY(hipMemcpyAsync(cur.data(), pstate(prim) + (size_t)s * n * 13, cur.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         for (int j = 0; j < n; ++j)
-            for (int k = 0; k < 3; ++k) { cur[(size_t)j * 13 + 7 + k] = a[3 + k]; cur[(size_t)j * 13 + 10 + k] = a[k]; }
-        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)s * n * 13, cur.data(), cur.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+            for (int k = 0; k < 3; ++k) { cur[(size_t)j * 13 + 7 + k] = a6[3 + k]; cur[(size_t)j * 13 + 10 + k] = a6[k]; }
+        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)s * n * 13, cur.data(), cur.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
     }
@@ -1311,9 +1346,9 @@ template <class R> struct Sim final : ISim {
         int rc = check_prim(prim);
         if (rc) return rc;
         REQUIRE(g6 && s >= 0 && n >= 1 && (s + 1) * n <= cfg.max_frames, "prim_get_action_grad: frames out of range");
-        std::vector<R> g((size_t)n * 13);
-        R acc[6];
-        HIP_TRY(hipMemcpyAsync(g.data(), pgrad(prim) + (size_t)s * n * 13, g.size() * sizeof(R), hipMemcpyDeviceToHost, stream));
+        std::vector<double> g((size_t)n * 13);
+        double acc[6];
+        HIP_TRY(hipMemcpyAsync(g.data(), pgrad(prim) + (size_t)s * n * 13, g.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(acc, action_buf_grad + ((size_t)prim * cfg.max_frames + s) * 6, sizeof acc, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         // set_velocity_from_action_kernel.grad accumulates into action_buffer.grad[s] (:315-319)
@@ -1321,17 +1356,17 @@ template <class R> struct Sim final : ISim {
             for (int k = 0; k < 3; ++k) { acc[3 + k] += g[(size_t)j * 13 + 7 + k]; acc[k] += g[(size_t)j * 13 + 10 + k]; }
         HIP_TRY(hipMemcpyAsync(action_buf_grad + ((size_t)prim * cfg.max_frames + s) * 6, acc, sizeof acc, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        for (int c = 0; c < 6; ++c) g6[c] = (double)acc[c];
+        for (int c = 0; c < 6; ++c) g6[c] = acc[c];
         return SMAC_OK;
     }
     int prim_reset(int prim) override {                                       // :271-275
         int rc = check_prim(prim);
         if (rc) return rc;
         ++config_gen;
-        HIP_TRY(hipMemsetAsync(pstate(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(R), stream));
-        HIP_TRY(hipMemsetAsync(pgrad(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(R), stream));
-        HIP_TRY(hipMemsetAsync(action_buf + (size_t)prim * cfg.max_frames * 6, 0, (size_t)cfg.max_frames * 6 * sizeof(R), stream));
-        HIP_TRY(hipMemsetAsync(action_buf_grad + (size_t)prim * cfg.max_frames * 6, 0, (size_t)cfg.max_frames * 6 * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(pstate(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(pgrad(prim), 0, (size_t)cfg.max_frames * 13 * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(action_buf + (size_t)prim * cfg.max_frames * 6, 0, (size_t)cfg.max_frames * 6 * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(action_buf_grad + (size_t)prim * cfg.max_frames * 6, 0, (size_t)cfg.max_frames * 6 * sizeof(double), stream));
         return prim_clear_ext_f(prim);
     }
 
@@ -1374,6 +1409,17 @@ template <class R> struct Sim final : ISim {
                 *p = t.ptr;
                 if (n) *n = t.n;
                 if (bytes) *bytes = (int32_t)sizeof(R);
+                return SMAC_OK;
+            }
+        // primitive accumulators (always f64): ext_f[P][6], state.grad[P][max_frames][13] - what the slabs all-reduce per env step
+        const int Pn = D.P > 0 ? D.P : 1;
+        struct { const char* name; double* ptr; int64_t n; } tab64[] = {
+            {"ext_f", D.ext_f, (int64_t)Pn * 6}, {"prim_state.grad", D.prim_grad, (int64_t)Pn * cfg.max_frames * 13}};
+        for (auto& t : tab64)
+            if (!strcmp(t.name, field)) {
+                *p = t.ptr;
+                if (n) *n = t.n;
+                if (bytes) *bytes = 8;
                 return SMAC_OK;
             }
         err = std::string("unknown grid field ") + field;
@@ -1460,6 +1506,7 @@ int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, doub
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC) { return FWD(add_grad(f, gx, gv, gF, gC)); }
 int smac_clear_grads(smac_handle h) { return FWD(clear_grads()); }
 int smac_set_control_idx(smac_handle h, const int32_t* idx) { return FWD(set_control_idx(idx)); }
+int smac_set_action(smac_handle h, const double* action) { return FWD(set_action_v(action)); }
 int smac_compute_grid_m(smac_handle h, int f, double* grid_m) { return FWD(compute_grid_m(f, grid_m)); }
 int smac_substep(smac_handle h, int f, const double* action) { return FWD(substep(f, action)); }
 int smac_substep_grad(smac_handle h, int f, const double* action, const double* ext_f_grad, double* action_grad_out) {

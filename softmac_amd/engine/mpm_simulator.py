@@ -160,7 +160,7 @@ class MPMSimulator:
         a = None if action is None else _ffi.as_f64(np.asarray(action).reshape(self.n_control, self.dim))
         e = None
         if ext_f_grad is not None:
-            e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]))
+            e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]), (self.n_primitive, 6))
         out = None if action is None else np.zeros((self.n_control, self.dim))
         self._h.call("smac_substep_grad", int(s), _ffi.dptr(a), _ffi.dptr(e), _ffi.dptr(out))
         if action is None:
@@ -176,7 +176,7 @@ class MPMSimulator:
         self._push_contact_flags()
         e = None
         if ext_f_grad is not None:
-            e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]))
+            e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]), (self.n_primitive, 6))
         self._h.call("smac_substeps_grad", int(s0), int(count), _ffi.dptr(e))
 
     # ------------------------------------------------------------------ IO (:448-574)
@@ -186,8 +186,19 @@ class MPMSimulator:
         return out
 
     def set_state(self, f, state):
-        x, v, F, Cm = (_ffi.as_f64(s) for s in state[:4])
+        N = self.n_particles
+        x, v, F, Cm = (_ffi.as_f64(s, shp) for s, shp in zip(state[:4], ((N, 3), (N, 3), (N, 3, 3), (N, 3, 3))))
         self._h.call("smac_set_frame", int(f), _ffi.dptr(x), _ffi.dptr(v), _ffi.dptr(F), _ffi.dptr(Cm))
+
+    def readframe(self, f, x, v, F, C):                     # :449-456 (fills the caller's arrays)
+        N = self.n_particles
+        for a, shp in ((x, (N, 3)), (v, (N, 3)), (F, (N, 3, 3)), (C, (N, 3, 3))):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == shp):
+                raise ValueError(f"readframe: expected a C-contiguous float64 array of shape {shp}")
+        self._h.call("smac_get_frame", int(f), _ffi.dptr(x), _ffi.dptr(v), _ffi.dptr(F), _ffi.dptr(C))
+
+    def setframe(self, f, x, v, F, C):                      # :458-466
+        self.set_state(f, (x, v, F, C))
 
     def reset(self, x):
         x = _ffi.as_f64(x)
@@ -226,19 +237,23 @@ class MPMSimulator:
 
     def add_grad(self, f, gx=None, gv=None, gF=None, gC=None):
         """`x.grad[f, i] += ...` as done by the loss kernels (reference loss_pour.py:130-140)."""
-        arrs = [None if a is None else _ffi.as_f64(a) for a in (gx, gv, gF, gC)]
+        N = self.n_particles
+        arrs = [None if a is None else _ffi.as_f64(np.asarray(a).reshape(shp) if np.asarray(a).size == int(np.prod(shp)) else a, shp)
+                for a, shp in zip((gx, gv, gF, gC), ((N, 3), (N, 3), (N, 3, 3), (N, 3, 3)))]
         self._h.call("smac_add_grad", int(f), *[_ffi.dptr(a) for a in arrs])
 
     def clear_grads(self):
         self._h.call("smac_clear_grads")
 
     # ------------------------------------------------------------------ control (:579-602)
-    def set_action(self, action):
-        # forwarded with the next substep()/substep_grad(), which is where the reference uploads it
-        raise NotImplementedError("pass `action` to substep()/substep_grad() as the reference's callers do")
+    def set_action(self, action):                           # :589-592 (the device copy persists until the next set_action)
+        a = _ffi.as_f64(np.asarray(action, dtype=np.float64).reshape(self.n_control, self.dim))
+        self._h.call("smac_set_action", _ffi.dptr(a))
 
     def set_control_idx(self, idx=None):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if idx.shape != (self.n_particles,):
+            raise ValueError(f"set_control_idx: expected shape ({self.n_particles},), got {idx.shape}")
         if self.n_control == 0:
             idx = idx * 0
         self._h.call("smac_set_control_idx", idx.ctypes.data_as(_ffi.c_int32_p))

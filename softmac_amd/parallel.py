@@ -140,6 +140,62 @@ class SlabRunner:
             self.substep_grad(f, ext_f_grad)
 
 
+class _DevArray:
+    """A library-owned device buffer as seen by torch (zero copy, __cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class PrimitiveReducer:
+    """SUM over the slabs of the per-rank partial wrench sums `ext_f` and primitive-state adjoints, in place in the library's
+    device buffers - once per env step, where the reference consumes them (rigid_simulator.py:92-93, 203-208).  Small
+    all-reduces (6 P and 13 P substeps scalars), not grid traffic."""
+
+    def __init__(self, sim, group=None):
+        self.sim, self.group = sim, group
+        self.P = len(sim.primitives)
+        self.frames = sim.max_steps
+        dev = torch.device("cuda", sim.device)
+        self.gloo = dist.get_backend(group) == "gloo"
+
+        def view(field):
+            p, n, b = C.c_void_p(), C.c_int64(0), C.c_int32(0)
+            sim._h.call("smac_grid_device_ptr", field.encode(), C.byref(p), C.byref(n), C.byref(b))
+            assert b.value == 8
+            return torch.as_tensor(_DevArray(p.value, n.value, "<f8"), device=dev)
+
+        self.ext_f = view("ext_f") if self.P else None
+        self.pgrad = view("prim_state.grad").view(max(self.P, 1), self.frames, 13) if self.P else None
+
+    def _sum(self, t):
+        if self.gloo:                                        # gloo moves host memory (CPU tests / ranks sharing one GPU)
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce_ext_f(self, clear=False):
+        """every rank ends with the total wrench; `clear` then zeroes it as the reference's clear_ext_f does after the read"""
+        if self.ext_f is None:
+            return None
+        self.sim.sync()
+        self._sum(self.ext_f)
+        total = self.ext_f.clone()
+        if clear:
+            self.ext_f.zero_()
+        return total
+
+    def allreduce_state_grad(self, f0, f1):
+        if self.pgrad is None:
+            return
+        self.sim.sync()
+        sl = self.pgrad[:, f0:f1].contiguous()
+        self._sum(sl)
+        self.pgrad[:, f0:f1] = sl
+
+
 def allreduce_primitives(tensors, group=None):
     """Sum per-rank partials of ext_f / primitive-state adjoints (small, once per env step)."""
     for t in tensors:

@@ -136,3 +136,41 @@ def s_grip_slab(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, pre
            np.array([xc, 0.3, z0 - 0.05 + 0.002] + ident + [0, 0, 0.3] + [0, 0, 0], dtype=np.float64),
            np.array([xc, 0.3, z0 + side * dx + 0.05 - 0.002] + ident + [0, 0, -0.3] + [0, 0, 0], dtype=np.float64)]
     return cfg, dt * substeps, state, specs, s13, (lo, hi)
+
+
+def balanced_slab_bounds(base_x, world, n_grid, min_width=2):
+    """Slab boundaries from the per-plane particle prefix sum: rank r owns stencil bases lo[r] <= base.x < lo[r+1].
+    Interior slabs are at least `min_width` planes wide: with a drift tolerance of t cells a slab's particles touch planes
+    [lo - t, hi + 2 + t), and only NEIGHBOURING slabs exchange, so slabs r-1 and r+1 must not meet: width >= 2 + 2 t."""
+    cnt = np.bincount(np.clip(base_x, 0, n_grid - 1), minlength=n_grid)
+    cum = np.concatenate([[0], np.cumsum(cnt)])
+    occ = np.nonzero(cnt)[0]
+    first, last = int(occ[0]), int(occ[-1]) + 1
+    if last - first < min_width * max(world - 2, 0) + 2 * min(world - 1, 1):
+        raise ValueError(f"{world} slabs of >= {min_width} planes do not fit the {last - first} occupied planes")
+    bounds = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        b = int(np.argmin(np.abs(cum - target)))
+        lo_ok = first + 1 if r == 1 else bounds[-1] + min_width
+        hi_ok = last - 1 - min_width * (world - 1 - r)
+        bounds.append(min(max(b, lo_ok), hi_ok))
+    bounds.append(n_grid)
+    return bounds
+
+
+def s_grip_strong(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
+                  substeps=10, drift_tol=1):
+    """Strong-scaling form of S-grip (the metric's "1M particles / 128^3 on 1/2/4/8 GPUs"): the SAME scene as `s_grip`
+    - one block, one global grid, the shared gripper primitives - cut into `world` x-slabs balanced by particle count.
+    Every rank works in global coordinates on its own copy of the block-sparse grid (only its slab's blocks are active).
+    Returns (cfg, env_dt, state of the owned particles, specs, s13, (left_plane0, right_plane0, nplanes), owned ids)."""
+    cfg, env_dt, state, specs, s13 = s_grip(n_particles, n_grid, max_steps, precision, device, seed=seed, dt=dt, substeps=substeps)
+    base = (state[:, 0] * n_grid - 0.5).astype(np.int64)
+    bounds = balanced_slab_bounds(base, world, n_grid, min_width=2 + 2 * drift_tol)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    own = np.nonzero((base >= lo) & (base < hi))[0]
+    cfg.n_particles = len(own)
+    cfg.slab_flags = (2 if rank > 0 else 0) | (4 if rank < world - 1 else 0)      # smac_config.flags bits 1,2: open x ends
+    nplanes = 2 + 2 * drift_tol
+    return cfg, env_dt, state[own], specs, s13, (max(lo - drift_tol, 0), min(hi - drift_tol, n_grid - nplanes), nplanes), own

@@ -1,0 +1,59 @@
+"""`python bench.py --gpus N` must really start N ranks (VERDICT r1 #3 / ADVICE): the launcher itself is driven here on the
+CPU (`--launch-check`: spawn, gloo rendezvous, report - no simulator, the product has no CPU path); on the GPU box the
+2-rank slab bench goes through the same launcher with both ranks on the one card."""
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, env=e, timeout=timeout, cwd=str(ROOT))
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_gpus_flag_spawns_that_many_ranks(n):
+    r = _run(["--gpus", str(n), "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["launch_check"] and d["n_gpus"] == n and d["requested"] == n
+    assert [x["rank"] for x in d["ranks"]] == list(range(n))
+    assert len({x["pid"] for x in d["ranks"]}) == n                      # n distinct processes
+
+
+def test_world_size_mismatch_fails_loudly():
+    r = _run(["--gpus", "4", "--launch-check"], env={"WORLD_SIZE": "2", "RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_single_process_launch_check():
+    r = _run(["--gpus", "1", "--launch-check"], env={"WORLD_SIZE": "1", "RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29998"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _last_json(r.stdout)["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_two_rank_strong_scaling_bench_through_the_launcher():
+    """2 ranks on the one GPU of the test box (gloo staging, SMAC_FORCE_DEVICE=0): the strong-scaling slab path end to end."""
+    r = _run(["--gpus", "2", "--steps", "12", "--warmup", "2", "--repeats", "1", "--particles", "65536", "--grid", "64", "--no-cpu-baseline"],
+             env={"SMAC_DIST_BACKEND": "gloo", "SMAC_FORCE_DEVICE": "0"}, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert sum(d["config"]["particles_per_gpu"]) == 65536
+    assert d["config"]["resorts_in_window"] >= 1

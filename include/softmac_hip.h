@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMAC_ABI_VERSION 1
+#define SMAC_ABI_VERSION 2
 #define SMAC_MAX_PRIMS 4
 
 typedef struct smac_sim* smac_handle;
@@ -67,6 +67,12 @@ typedef struct smac_config {
     int32_t flags;            /* bit 0: substep_grad recomputes the forward grid like the reference (:352-359) instead of
                                  restoring the copy saved by substep (DESIGN.md "grid checkpoint");
                                  bit 1 / bit 2: slab decomposition - no wall at the low / high x end */
+    int32_t adjoint_frames;   /* 0: an adjoint frame per state frame, like the reference's `needs_grad` fields (:53-56).
+                                 k >= 3: ROLLING adjoint storage of k frames - substep_grad(f) only needs .grad[f] and .grad[f+1]
+                                 plus the frames a loss has seeded and the backward sweep has not reached yet; a frame is released
+                                 two substeps after the sweep has passed it (get_grad on it then fails).  What lets a 2000-substep
+                                 episode at 1M particles fit one GPU. */
+    int32_t reserved0;
     double dt;
     double mu, lam;
     double p_vol, p_mass;

@@ -13,7 +13,7 @@ import numpy as np
 _LIB = None
 LIB_PATH = pathlib.Path(__file__).resolve().parent / "lib" / "libsoftmac_hip.so"
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_PRIMS = 4
 
 c_double_p = C.POINTER(C.c_double)
@@ -27,7 +27,7 @@ class SmacConfig(C.Structure):
         ("grad_enabled", C.c_int32), ("substeps", C.c_int32), ("ptype", C.c_int32),
         ("material_model", C.c_int32), ("collision_type", C.c_int32), ("n_control", C.c_int32),
         ("n_primitives", C.c_int32), ("rigid_velocity_control", C.c_int32),
-        ("sort_interval", C.c_int32), ("flags", C.c_int32),
+        ("sort_interval", C.c_int32), ("flags", C.c_int32), ("adjoint_frames", C.c_int32), ("reserved0", C.c_int32),
         ("dt", C.c_double), ("mu", C.c_double), ("lam", C.c_double),
         ("p_vol", C.c_double), ("p_mass", C.c_double), ("gravity", C.c_double * 3),
         ("ground_friction", C.c_double), ("yield_stress", C.c_double),

@@ -64,6 +64,7 @@ template <class R> struct DevSim {
     Material<R> mat;
     R* S;
     R* A;
+    R* Af;                       // adjoint frame of the substep being reversed (frames may live in rolling slots: set per launch)
     // grid: one 4-scalar record per cell and field, so a stencil node is ONE 16-byte access
     Vec4<R> *vin, *vmix, *vout;         // {m, p_x, p_y, p_z} / {v_mixed, 0} / {v_out, 0}
     Vec4<R> *ain, *amix, *aout;         // adjoints: {grid_m.grad, grid_v_in.grad} / {grid_v_mixed.grad, 0} / {grid_v_out.grad, 0}
@@ -131,6 +132,12 @@ constexpr float FIX_RANGE = 8388000.0f;      // < 2^31 / 256: |q| <= FIX_RANGE p
 constexpr float W_MAX = 0.421875f;           // 0.75^3
 constexpr float WD_MAX = 0.140625f;          // 0.25 * 0.75^2
 __device__ __forceinline__ void tile_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void tile_add(double* p, float v) { __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Fixed point resolves a node sum to 2^-23 of the CHUNK's largest contribution.  That is f32-grade where a node collects
+// many contributions, but a node that only sees weights of 1e-4 (isolated particles, spray, the rim of a thin sheet) keeps
+// 1e-3 relative precision, and grid_op divides by such a mass (its adjoint by its square).  Chunks of at most SPARSE_MAX
+// particles - where that regime lives, and where LDS atomics are not the bottleneck - accumulate in f64 words instead.
+constexpr int SPARSE_MAX = 128;
 __device__ __forceinline__ void tile_add(int* p, float v) {
     __hip_atomic_fetch_add(p, __float2int_rn(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -418,9 +425,13 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
 // hit_ck / nhit_ck (optional): the frame's contact hit list travels with the checkpoint, so the backward pass
 // does not have to repeat the band test over all particles (k_contact_mask)
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck) {
+__global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
     if (hit_ck) {
-        const int nh = *D.nhits;
+        int nh = *D.nhits;
+        if (nh > hit_cap) {                  // more particles in contact bands than a checkpoint slot holds: reported, never truncated silently
+            if (blockIdx.x == 0 && threadIdx.x == 0) *D.drift_flag = 2;
+            nh = 0;
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0) *nhit_ck = nh;
         for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += gridDim.x * BLOCK) hit_ck[i] = D.hits[i];
     }
@@ -458,10 +469,14 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
 template <class R, bool STORE_F>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_p2g(DevSim<R> D, int f) {
     typedef typename ScatterTile<R>::word W;
-    __shared__ W tile[4 * TILE_WORDS];
+    __shared__ double tile_raw[4 * TILE_WORDS];
     __shared__ R smax[4];
     SMAC_CHUNK_PROLOGUE
-    for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = W(0);     // (made visible by the barrier inside tile_scale)
+    W* const tile = (W*)tile_raw;
+    double* const tile64 = tile_raw;
+    const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;       // workgroup-uniform: f64 words instead of fixed point
+    if (sparse) { for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
+    else { for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }     // (made visible by the barrier inside tile_scale)
     int cmask = 0;
     typedef typename pos_of<R>::type PX;
     PX x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
@@ -546,7 +561,27 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         // block since the last sort) the same unrolled code with a per-node choice LDS tile / global atomic - ONE pass
         // for all lanes, where a separate slow loop would make the whole wave run both paths.
         const bool wave_in = __all((nd.okx & nd.oky & nd.okz) == 7);
-        if (wave_in) {
+        if (sparse) {
+#pragma unroll 1
+            for (int n = 0; n < 27; ++n) {
+                const int i = n / 9, j = (n / 3) % 3, k = n % 3;
+                const R w = (i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0])) * (j == 0 ? st.w[0][1] : (j == 1 ? st.w[1][1] : st.w[2][1])) *
+                            (k == 0 ? st.w[0][2] : (k == 1 ? st.w[1][2] : st.w[2][2]));
+                const R val[3] = {w * (m0[0] + R(i) * a0[0] + R(j) * a1[0] + R(k) * a2[0]), w * (m0[1] + R(i) * a0[1] + R(j) * a1[1] + R(k) * a2[1]),
+                                  w * (m0[2] + R(i) * a0[2] + R(j) * a1[2] + R(k) * a2[2])};
+                const int tix = (i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2])) + (j == 0 ? nd.ty[0] : (j == 1 ? nd.ty[1] : nd.ty[2])) +
+                                (k == 0 ? nd.tz[0] : (k == 1 ? nd.tz[1] : nd.tz[2]));
+                if (((nd.okx >> i) & (nd.oky >> j) & (nd.okz >> k) & 1) != 0) {
+                    tile_add(tile64 + tix, w * D.p_mass);
+                    for (int c = 0; c < 3; ++c) tile_add(tile64 + tix + (1 + c) * TILE_WORDS, val[c]);
+                } else {
+                    const unsigned cell = (unsigned)((i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2])) + (j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2])) +
+                                                     (k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2])));
+                    gatomic(D.vin, cell, 0, w * D.p_mass);
+                    for (int c = 0; c < 3; ++c) gatomic(D.vin, cell, 1 + c, val[c]);
+                }
+            }
+        } else if (wave_in) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 R mi[3] = {m0[0] + R(i) * a0[0], m0[1] + R(i) * a0[1], m0[2] + R(i) * a0[2]};
@@ -595,7 +630,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     }
     if (D.any_contact && D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;   // read back by p2g.grad
     __syncthreads();
-    tile_store<R, 4>(D, tile, sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1), from_tile);
+    if (sparse) tile_store<R, 4>(D, tile64, R(1), R(1));
+    else tile_store<R, 4>(D, tile, sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1), from_tile);
 }
 
 // boundary_condition :268-281 on a velocity; returns mask bits of the components that were zeroed
@@ -881,11 +917,15 @@ template <class R> struct WGrad {
 template <class R, bool ACC_X>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k_g2p_grad(DevSim<R> D, int f) {
     typedef typename ScatterTile<R>::word W;
-    __shared__ W tile[3 * TILE_WORDS];
+    __shared__ double tile_raw[3 * TILE_WORDS];
     __shared__ Vec4<R> gt[TILE_WORDS];
     __shared__ R smax[4];
     SMAC_CHUNK_PROLOGUE
-    for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0);
+    W* const tile = (W*)tile_raw;
+    double* const tile64 = tile_raw;
+    const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;       // f64 words instead of fixed point (see SPARSE_MAX)
+    if (sparse) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
+    else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
     gather_tile_load(D, D.vout, ch.block, gt);      // (its barrier is the one inside tile_scale below: the particle loads
                                                     //  that follow are then in flight together with the tile's)
     typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
@@ -913,7 +953,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     R to_tile, from_tile;
     tile_scale<R>(bound, smax, to_tile, from_tile);                                        // one barrier (all threads)
     if (valid) {
-        R* Af = frame(D.A, f, D.Npad);
+        R* Af = D.Af;
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, ch.block);
@@ -934,7 +974,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
             // One x-plane (9 nodes) per trip: rolled, so only 9 gathered records are live at a time.  MIXED = some lane
             // of the wave drifted out of its block since the last sort: same code with a per-node choice between the LDS
             // tiles and global memory - one pass for all lanes instead of a fast and a slow path run one after the other.
-            auto planes = [&](auto mixed_tag) {
+            auto planes = [&](auto mixed_tag, auto* tl, const R to_tl) {
                 constexpr bool MIXED = decltype(mixed_tag)::value;
 #pragma unroll 1
                 for (int i = 0; i < 3; ++i) {
@@ -963,7 +1003,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
                             const R w = wij * st.w[k][2];
                             if (in) {
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) tile_add(tile + tw + c * TILE_WORDS, (w * to_tile) * tk[c]);
+                                for (int c = 0; c < 3; ++c) tile_add(tl + tw + c * TILE_WORDS, (w * to_tl) * tk[c]);
                             } else {
 #pragma unroll
                                 for (int c = 0; c < 3; ++c) gatomic(D.aout, cell, c, w * tk[c]);
@@ -983,8 +1023,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
                     for (int c = 0; c < 3; ++c) M0[c] += wxi * s0[c];
                 }
             };
-            if (__all((nd.okx & nd.oky & nd.okz) == 7)) planes(std::false_type{});
-            else planes(std::true_type{});
+            if (sparse) planes(std::true_type{}, tile64, R(1));
+            else if (__all((nd.okx & nd.oky & nd.okz) == 7)) planes(std::false_type{}, tile, to_tile);
+            else planes(std::true_type{}, tile, to_tile);
 #pragma unroll
             for (int a = 0; a < 3; ++a) wg.g[a][0] += gwx[a];
 #pragma unroll
@@ -999,7 +1040,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
         }
     }
     __syncthreads();
-    tile_store<R, 3>(D, tile, from_tile, from_tile);
+    if (sparse) tile_store<R, 3>(D, tile64, R(1), R(1));
+    else tile_store<R, 3>(D, tile, from_tile, from_tile);
 }
 
 // completes the G2P-adjoint scatter: grid_v_out.grad += sum of overlapping slabs
@@ -1159,7 +1201,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) gfx[c] += __shfl_xor(gfx[c], o, 64);
             if (d < 3) {
-                R* Af = frame(D.A, f, D.Npad);
+                R* Af = D.Af;
                 const double gp = d == 0 ? gpos[0] : (d == 1 ? gpos[1] : gpos[2]);
                 const R gf = d == 0 ? gfx[0] : (d == 1 ? gfx[1] : gfx[2]);
                 Af[(size_t)(CX + d) * D.Npad + p] += (R)(gp + (double)(D.inv_dx * gf));
@@ -1244,7 +1286,7 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
                 }
             }
             if (act && d < 6) {
-                R* Af = frame(D.A, f, D.Npad);
+                R* Af = D.Af;
                 Af[(size_t)((d < 3 ? CX : CV - 3) + d) * D.Npad + p] += out;
             }
             R sg = (act && d >= 6 && d < 19) ? out : R(0);
@@ -1353,7 +1395,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     if (!valid) return;
     const R* Sf = frame(D.S, f, D.Npad);
     const R* An = D.An;
-    R* Af = frame(D.A, f, D.Npad);
+    R* Af = D.Af;
     // every global load of the kernel is issued here, in one batch (one memory round trip instead of four);
     // C, E and the SVD factors wait in LDS until the constitutive adjoint needs them
     typename pos_of<R>::type x[3];

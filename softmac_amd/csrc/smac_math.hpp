@@ -23,6 +23,15 @@
 #define SMAC_HD inline
 #endif
 
+// The SVD, the constitutive update and its adjoint are compiled with PRECISE floating-point semantics even though the
+// library is built with -ffast-math: for the few particles inside the reference's backward_svd clamp the adjoint is
+// ill-conditioned (K up to 1e6 on a singular-value difference), and there fast-math's reassociation / approximate
+// division cost a factor 4 in accuracy (4.5e-5 -> 9e-6 on the grip fixture, tools/prec_probe.py) for 3 % of the time.
+#if defined(__clang__)
+#define SMAC_PRECISE_FP _Pragma("float_control(precise, on)")
+#else
+#define SMAC_PRECISE_FP
+#endif
 namespace smac {
 
 enum : int { MODEL_COROTATED = 0, MODEL_NEOHOOKEAN = 1 };
@@ -433,18 +442,21 @@ template <class R, class P> SMAC_HD void make_stencil_pos(const P* x, int n, Ste
 // 3x3 helpers (row-major R[9])
 // ------------------------------------------------------------------------------------------
 template <class R> SMAC_HD void mm(const R* A, const R* B, R* C) {          // C = A B
+    SMAC_PRECISE_FP
     R t[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
     for (int i = 0; i < 9; ++i) C[i] = t[i];
 }
 template <class R> SMAC_HD void mtm(const R* A, const R* B, R* C) {         // C = A^T B
+    SMAC_PRECISE_FP
     R t[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) t[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
     for (int i = 0; i < 9; ++i) C[i] = t[i];
 }
 template <class R> SMAC_HD void mmt(const R* A, const R* B, R* C) {         // C = A B^T
+    SMAC_PRECISE_FP
     R t[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
@@ -453,6 +465,7 @@ template <class R> SMAC_HD void mmt(const R* A, const R* B, R* C) {         // C
 
 // det(I + E) - 1, evaluated without the cancellation of det(F) - 1
 template <class R> SMAC_HD R det_minus_one(const R* E) {
+    SMAC_PRECISE_FP
     R tr = E[0] + E[4] + E[8];
     R m2 = (E[0] * E[4] - E[1] * E[3]) + (E[0] * E[8] - E[2] * E[6]) + (E[4] * E[8] - E[5] * E[7]);
     R d3 = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
@@ -460,6 +473,7 @@ template <class R> SMAC_HD R det_minus_one(const R* E) {
 }
 // cofactor matrix of F = I + E:  cof(F) = dF det
 template <class R> SMAC_HD void cofactor(const R* E, R* K) {
+    SMAC_PRECISE_FP
     R F[9];
     for (int i = 0; i < 9; ++i) F[i] = E[i];
     F[0] += R(1); F[4] += R(1); F[8] += R(1);
@@ -503,6 +517,7 @@ SMAC_HD double fast_sqrt(double x) { return std::sqrt(x); }
 // One Jacobi rotation on the symmetric matrix {a00,a01,a02,a11,a12,a22} in the (p,q) plane,
 // accumulated into V (columns = eigenvectors).  Written out per pair to keep everything in registers.
 template <class R> SMAC_HD void jacobi_cs(R app, R aqq, R apq, R& c, R& s, R& t) {
+    SMAC_PRECISE_FP
     if (apq == R(0)) { c = R(1); s = R(0); t = R(0); return; }
     R tau = (aqq - app) * fast_rcp(R(2) * apq);
     R at = tau < R(0) ? -tau : tau;
@@ -518,6 +533,7 @@ template <class R> SMAC_HD void jacobi_cs(R app, R aqq, R apq, R& c, R& s, R& t)
 // For det F < 0 the sign moves into the smallest singular value (ti.svd contract: U, V rotations
 // up to a common sign, which every consumer ignores).
 template <class R> SMAC_HD void svd_I_plus_E(const R* E, R* U, R* e, R* V) {
+    SMAC_PRECISE_FP
     R a00 = R(2) * E[0] + E[0] * E[0] + E[3] * E[3] + E[6] * E[6];
     R a11 = R(2) * E[4] + E[1] * E[1] + E[4] * E[4] + E[7] * E[7];
     R a22 = R(2) * E[8] + E[2] * E[2] + E[5] * E[5] + E[8] * E[8];
@@ -590,6 +606,7 @@ template <class R> struct ConstState {
 
 template <class R>
 SMAC_HD void constitutive_fwd(const Material<R>& M, const R* Et, R* En, R* stress, ConstState<R>& cs) {
+    SMAC_PRECISE_FP
     cs.Jm1 = det_minus_one(Et);                                        // :222
     const R J = R(1) + cs.Jm1;
     cs.has_svd = false;
@@ -659,6 +676,7 @@ template <class R> SMAC_HD R clamp_ref(R a) { return a >= R(0) ? max_(a, R(1e-6)
 template <class R>
 SMAC_HD void constitutive_bwd(const Material<R>& M, const R* Et, const ConstState<R>& cs,
                               const R* G, const R* gFn, R* gEt) {
+    SMAC_PRECISE_FP
     const R J = R(1) + cs.Jm1;
     R gJ = R(0);
     for (int i = 0; i < 9; ++i) gEt[i] = R(0);

@@ -159,7 +159,8 @@ template <class R> struct Sim final : ISim {
     R* dense_tmp = nullptr;
     // grid checkpoints (one slot per frame in one arena); see k_grid_save
     Vec4<R>* ck_arena = nullptr;
-    Hit* ck_hits = nullptr;          // per frame: the contact hit list of that substep (capacity Npad), with its length
+    Hit* ck_hits = nullptr;          // per frame: the contact hit list of that substep (capacity ck_hit_cap), with its length
+    int ck_hit_cap = 0;
     int* ck_nhits = nullptr;
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
@@ -236,8 +237,14 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&D.S, fs * c.max_frames));
         HIP_TRY(hipMemsetAsync(D.S, 0, fs * c.max_frames, stream));
         if (c.grad_enabled) {
-            HIP_TRY(hipMalloc((void**)&D.A, fs * c.max_frames));
-            HIP_TRY(hipMemsetAsync(D.A, 0, fs * c.max_frames, stream));
+            adj_slots = c.max_frames;
+            if (c.adjoint_frames > 0 && c.adjoint_frames < c.max_frames) adj_slots = c.adjoint_frames < 3 ? 3 : c.adjoint_frames;
+            HIP_TRY(hipMalloc((void**)&D.A, fs * adj_slots));
+            HIP_TRY(hipMemsetAsync(D.A, 0, fs * adj_slots, stream));
+            adj_slot.assign(c.max_frames, -1);
+            adj_evicted.assign(c.max_frames, 0);
+            free_slots.clear();
+            for (int i = adj_slots - 1; i >= 0; --i) free_slots.push_back(i);
         }
         HIP_TRY(hipMalloc((void**)&grid_block, 6 * D.G * sizeof(Vec4<R>)));
         HIP_TRY(hipMemsetAsync(grid_block, 0, 6 * D.G * sizeof(Vec4<R>), stream));
@@ -486,23 +493,62 @@ template <class R> struct Sim final : ISim {
         REQUIRE(D.A != nullptr, "handle created with grad_enabled = 0");
         return SMAC_OK;
     }
+    // ---- adjoint frame storage: one slot per frame (the reference's layout), or a rolling pool (smac_config.adjoint_frames)
+    int adj_slots = 0;
+    std::vector<int> adj_slot, free_slots;
+    std::vector<char> adj_evicted;
+    bool rolling() const { return adj_slots < cfg.max_frames; }
+    R* adj_ptr(int f) {                                    // nullptr: pool exhausted (rolling mode only)
+        if (!rolling()) return D.A + (size_t)f * frame_scalars();
+        if (adj_slot[f] < 0) {
+            if (free_slots.empty()) return nullptr;
+            adj_slot[f] = free_slots.back();
+            free_slots.pop_back();
+            adj_epoch[f] = -1;                              // a fresh slot is a logically-zero frame whose memory is stale
+            adj_stale[f] = 1;
+            adj_evicted[f] = 0;
+        }
+        return D.A + (size_t)adj_slot[f] * frame_scalars();
+    }
+    void adj_release(int f) {
+        if (!rolling() || f < 0 || f >= cfg.max_frames || adj_slot[f] < 0) return;
+        free_slots.push_back(adj_slot[f]);
+        adj_slot[f] = -1;
+        adj_epoch[f] = -1;
+        adj_stale[f] = 0;
+        adj_evicted[f] = 1;
+    }
+    static constexpr const char* kPoolMessage =
+        "rolling adjoint storage exhausted: smac_config.adjoint_frames must cover the frames a loss has seeded and the backward "
+        "sweep has not reached yet, plus 3";
     // clear_grads() is lazy: an adjoint frame is only physically zeroed if somebody is about to read it
     // or add to it.  A backward sweep overwrites A[f] (write mode of g2p_grad / p2g_grad), so it never is.
     int adj_make_zero(int f) {
+        R* a = adj_ptr(f);
+        REQUIRE(a, kPoolMessage);
         if (!adj_stale[f]) return SMAC_OK;
-        HIP_TRY(hipMemsetAsync(D.A + (size_t)f * frame_scalars(), 0, frame_scalars() * sizeof(R), stream));
+        HIP_TRY(hipMemsetAsync(a, 0, frame_scalars() * sizeof(R), stream));
         adj_stale[f] = 0;
         return SMAC_OK;
     }
     int get_grad(int f, double* gx, double* gv, double* gF, double* gC) override {
         int rc;
         if ((rc = need_grad()) || (rc = check_frame(f)) || (rc = check_drift())) return rc;
+        if (rolling() && adj_slot[f] < 0) {
+            REQUIRE(!adj_evicted[f], "get_grad: this adjoint frame has been released (rolling adjoint storage, smac_config.adjoint_frames)");
+            if (gx) memset(gx, 0, (size_t)D.N * 3 * sizeof(double));       // never seeded, never reached: zero
+            if (gv) memset(gv, 0, (size_t)D.N * 3 * sizeof(double));
+            if (gC) memset(gC, 0, (size_t)D.N * 9 * sizeof(double));
+            if (gF) memset(gF, 0, (size_t)D.N * 9 * sizeof(double));
+            return SMAC_OK;
+        }
         if (adj_epoch[f] < 0 && (rc = adj_make_zero(f))) return rc;
         const int e = adj_epoch[f] < 0 ? 0 : adj_epoch[f];
-        if (gx && (rc = download_comp(D.A, f, CX, 3, gx, 0, e))) return rc;
-        if (gv && (rc = download_comp(D.A, f, CV, 3, gv, 0, e))) return rc;
-        if (gC && (rc = download_comp(D.A, f, CC, 9, gC, 0, e))) return rc;
-        if (gF && (rc = download_comp(D.A, f, CF, 9, gF, 0, e))) return rc;
+        const R* base = adj_ptr(f);                              // download_comp adds f * frame size to its base: pass f = 0
+        if (gx && (rc = download_comp(base, 0, CX, 3, gx, 0, e))) return rc;
+        if (gv && (rc = download_comp(base, 0, CV, 3, gv, 0, e))) return rc;
+        if (gC && (rc = download_comp(base, 0, CC, 9, gC, 0, e))) return rc;
+        if (gF && (rc = download_comp(base, 0, CF, 9, gF, 0, e))) return rc;
         return SMAC_OK;
     }
     int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) override {
@@ -519,7 +565,7 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMemcpyAsync(d_io, src[a], (size_t)D.N * cnt[a] * sizeof(double), hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL(k_rows_add_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cnt[a],
                                e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr,
-                               D.A + (size_t)f * frame_scalars() + (size_t)c0[a] * D.Npad);
+                               adj_ptr(f) + (size_t)c0[a] * D.Npad);
             HIP_TRY(hipStreamSynchronize(stream));                            // d_io is reused by the next component
         }
         return SMAC_OK;
@@ -527,6 +573,11 @@ template <class R> struct Sim final : ISim {
     int clear_grads() override {
         if (D.A) adj_stale.assign(cfg.max_frames, 1);                              // zeroed on demand (adj_make_zero)
         adj_epoch.assign(cfg.max_frames, -1);
+        if (D.A && rolling()) {
+            for (int f = 0; f < cfg.max_frames; ++f) adj_release(f);
+            adj_evicted.assign(cfg.max_frames, 0);
+            adj_stale.assign(cfg.max_frames, 0);
+        }
         const int Pn = D.P > 0 ? D.P : 1;
         HIP_TRY(hipMemsetAsync(D.prim_grad, 0, (size_t)Pn * cfg.max_frames * 13 * sizeof(double), stream));
         HIP_TRY(hipMemsetAsync(action_buf_grad, 0, (size_t)Pn * cfg.max_frames * 6 * sizeof(double), stream));
@@ -644,10 +695,11 @@ template <class R> struct Sim final : ISim {
         } else if (adj_epoch[f] != e) {
             const R* tmp = nullptr;
             if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
-            HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(adj_ptr(f), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
         }
         adj_epoch[f] = e;
-        *Af = D.A + (size_t)f * frame_scalars();
+        *Af = adj_ptr(f);
+        REQUIRE(*Af, kPoolMessage);
         return SMAC_OK;
     }
     unsigned long long* d_best = nullptr;
@@ -874,7 +926,8 @@ template <class R> struct Sim final : ISim {
     }
     // adjoint frame f re-ordered from its own epoch into epoch `to` -> tmp_frame (returns pointer to use)
     int adjoint_in_order(int f, int to, const R** out) {
-        const R* Af = D.A + (size_t)f * frame_scalars();
+        const R* Af = adj_ptr(f);
+        REQUIRE(Af, kPoolMessage);
         const int from = adj_epoch[f];
         if (from < 0 || from == to) { *out = Af; return SMAC_OK; }   // all-zero frames have no order
         int rc;
@@ -901,7 +954,8 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h) {
             HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
-            err = kDriftMessage;
+            err = h == 2 ? "more than 1/8 of the particles were inside a contact band in one substep: its hit list does not fit the grid "
+                           "checkpoint (create the handle with flags bit 0 - recompute_backward - for such scenes)" : kDriftMessage;
             return SMAC_ERR_INVALID;
         }
         return SMAC_OK;
@@ -1000,8 +1054,11 @@ template <class R> struct Sim final : ISim {
                 ck_arena = nullptr;
                 ck_enabled = false;                        // not enough memory: substep_grad recomputes the forward grid
             }
-            // the hit lists ride along when they fit too (otherwise substep_grad repeats the band test)
-            const size_t hbytes = (size_t)cfg.max_frames * D.Npad * sizeof(Hit);
+            // the hit lists ride along when they fit too (otherwise substep_grad repeats the band test).  A slot holds the
+            // hits of 1/8 of the particles (the bench has 0.15 % of them inside a contact band); more is reported as an error
+            ck_hit_cap = D.Npad / 8 > 8192 ? D.Npad / 8 : 8192;
+            if ((size_t)ck_hit_cap > (size_t)D.Npad) ck_hit_cap = D.Npad;
+            const size_t hbytes = (size_t)cfg.max_frames * ck_hit_cap * sizeof(Hit);
             if (ck_arena && D.collision_type == CONTACT_MIXED && hipMemGetInfo(&free_b, &total_b) == hipSuccess && hbytes <= free_b / 4) {
                 if (hipMalloc((void**)&ck_hits, hbytes) != hipSuccess || hipMalloc((void**)&ck_nhits, cfg.max_frames * sizeof(int)) != hipSuccess) {
                     (void)hipGetLastError();
@@ -1039,7 +1096,7 @@ template <class R> struct Sim final : ISim {
                 prof_begin(K_CKPT);
                 const bool keep_hits = ck_hits && any_contact();
                 hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f),
-                                   keep_hits ? ck_hits + (size_t)f * D.Npad : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr);
+                                   keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr, ck_hit_cap);
                 prof_end();
                 ck_epoch[f] = e;
                 ck_gen[f] = config_gen;
@@ -1083,8 +1140,10 @@ template <class R> struct Sim final : ISim {
                 const R* tmp = nullptr;
                 REQUIRE(An != tmp_frame, "adjoint frames f and f+1 both need re-ordering (unsupported seed placement)");
                 if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
-                HIP_TRY(hipMemcpyAsync(D.A + (size_t)f * frame_scalars(), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(adj_ptr(f), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
             }
+            D.Af = adj_ptr(f);
+            REQUIRE(D.Af, kPoolMessage);
             pending_adj_zero = adj_epoch[f] < 0;                                  // A[f] is known to be all zero: write instead of +=
             adj_epoch[f] = e;
             adj_stale[f] = 0;                                                     // write mode overwrites every row
@@ -1097,7 +1156,7 @@ template <class R> struct Sim final : ISim {
                 const bool have_hits = ck_hits && D.any_contact && D.collision_type == CONTACT_MIXED;
                 vin_clean = false;
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f),
-                                   have_hits ? (const Hit*)(ck_hits + (size_t)f * D.Npad) : (const Hit*)nullptr,
+                                   have_hits ? (const Hit*)(ck_hits + (size_t)f * ck_hit_cap) : (const Hit*)nullptr,
                                    have_hits ? (const int*)(ck_nhits + f) : (const int*)nullptr);
                 if (D.any_contact && D.collision_type != CONTACT_GRID && !have_hits)
                     hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
@@ -1152,6 +1211,7 @@ template <class R> struct Sim final : ISim {
                 HIP_TRY(hipStreamSynchronize(stream));
                 for (int i = 0; i < 3 * D.n_control; ++i) action_grad_out[i] = (double)tmp[i];
             }
+            adj_release(f + 2);                    // rolling storage: the sweep has passed frame f+2 two substeps ago
         }
         return check_launch();
     }
@@ -1402,7 +1462,7 @@ template <class R> struct Sim final : ISim {
             {"grid_in", (R*)D.vin, (int64_t)(4 * D.G)}, {"grid_mixed", (R*)D.vmix, (int64_t)(4 * D.G)}, {"grid_out", (R*)D.vout, (int64_t)(4 * D.G)},
             {"grid_in.grad", (R*)D.ain, (int64_t)(4 * D.G)}, {"grid_mixed.grad", (R*)D.amix, (int64_t)(4 * D.G)},
             {"grid_out.grad", (R*)D.aout, (int64_t)(4 * D.G)},
-            {"state", D.S, (int64_t)frame_scalars() * cfg.max_frames}, {"state.grad", D.A, (int64_t)frame_scalars() * cfg.max_frames},
+            {"state", D.S, (int64_t)frame_scalars() * cfg.max_frames}, {"state.grad", D.A, (int64_t)frame_scalars() * adj_slots},
             {"slab", (R*)slab, (int64_t)(slab_chunks * TILE_WORDS * 4)}};
         for (auto& t : tab)
             if (!strcmp(t.name, field)) {

@@ -107,6 +107,7 @@ class MPMSimulator:
         c.rigid_velocity_control = 1 if rigid_velocity_control else 0
         c.sort_interval = int(getattr(cfg, "sort_interval", 0))
         c.flags = (1 if getattr(cfg, "recompute_backward", False) else 0) | int(getattr(cfg, "slab_flags", 0))
+        c.adjoint_frames = int(getattr(cfg, "adjoint_frames", 0))            # 0: one per state frame; k >= 3: rolling (long episodes)
         c.dt = self.dt
         c.mu, c.lam = self._mu, self._lam
         c.p_vol, c.p_mass = self.p_vol, self.p_mass

@@ -25,7 +25,7 @@ def test_header_and_binding_agree(hip_lib):
 def test_abi_version_and_config_layout(hip_lib):
     from softmac_amd import _ffi
     assert hip_lib.smac_abi_version() == _ffi.ABI_VERSION
-    assert ctypes.sizeof(_ffi.SmacConfig) == 16 * 4 + 10 * 8     # 16 int32 + 10 doubles, no padding surprises
+    assert ctypes.sizeof(_ffi.SmacConfig) == 18 * 4 + 10 * 8     # 18 int32 + 10 doubles, no padding surprises
 
 
 def test_no_cpu_fallback(hip_lib):

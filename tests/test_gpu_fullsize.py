@@ -31,10 +31,9 @@ def _engine(precision, max_steps=8, sort_interval=None, n=N_FULL, grid=GRID_FULL
     return cfg, env_dt, state, specs, pst, sim, prm
 
 
-@pytest.mark.parametrize("precision,tol_s,tol_g", [("float64", 1e-10, 1e-8), ("float32", 2e-3, 2e-2)])
+@pytest.mark.parametrize("precision,tol_s,tol_g", [("float64", 1e-10, 1e-8), ("float32", H.F32_TOL["state"], H.F32_TOL["gx"])])
 def test_fullsize_one_substep_vs_cpu_port(precision, tol_s, tol_g):
-    # f32: the forecast projection turns a node's position rounding (3e-8 at x ~ 0.5) into a velocity error of
-    # 3e-8 / dt = 3e-4 m/s on contact nodes - inherent to single precision, so the f32 bounds are set by contact.
+    # f32: helpers.F32_TOL (fixed-point positions and the f64 contact chain keep forecast contact inside 1e-5)
     from oracle import mpm_cpu
     cfg, env_dt, state, specs, pst, sim, prm = _engine(precision)
     P = H.oracle_params(cfg, env_dt)
@@ -60,8 +59,13 @@ def test_fullsize_one_substep_vs_cpu_port(precision, tol_s, tol_g):
     sim.add_grad(1, gx=g[0], gv=g[1], gC=g[2], gF=g[3])
     sim.substep_grad(0)
     gx, gv, gF, gC = sim.get_grad_full(0)
-    assert H.rel_err(gx, ref[0]) < tol_g and H.rel_err(gv, ref[1]) < tol_g
-    assert H.rel_err(gC, ref[2]) < tol_g and H.rel_err(gF, ref[3]) < tol_g
+    # particles inside the reference's SVD-adjoint clamp (helpers.F32_TOL "clamp") are bounded separately in f32
+    Ft = (np.eye(3)[None] + cfg.dt * C) @ F
+    s2 = np.linalg.svd(Ft, compute_uv=False) ** 2
+    zone = np.minimum(np.abs(s2[:, 0] - s2[:, 1]), np.minimum(np.abs(s2[:, 1] - s2[:, 2]), np.abs(s2[:, 0] - s2[:, 2]))) < 4e-6
+    for name, got, rf in (("gx", gx, ref[0]), ("gv", gv, ref[1]), ("gC", gC, ref[2]), ("gF", gF, ref[3])):
+        eo, ei = H.rel_err_split(got, rf, zone)
+        assert eo < tol_g and ei < (tol_g if precision == "float64" else H.F32_TOL["clamp"]), (name, eo, ei, int(zone.sum()))
     for i, m in enumerate(prm):
         scale = max(np.abs(ref[4]).max(), 1e-9)
         assert np.abs(m.get_all_states_grad(0) - ref[4][i]).max() / scale < 10 * tol_g
@@ -126,30 +130,54 @@ def test_fullsize_adjoint_dot_product_and_linearity(ptype, model, tol):
     assert H.rel_err(g3, 2.5 * g + g2) < 1e-11
 
 
-def test_fullsize_rebinning_invariance():
-    """A 20-substep S-grip rollout and its backward pass must not depend on how often the particles are
-    re-binned (sort_interval 1 / 16 / never): only the f32 summation order changes."""
-    outs = []
-    for si in (1, 16, 1000):
-        cfg, env_dt, state, specs, pst, sim, prm = _engine("float32", max_steps=24, sort_interval=si)
-        N = cfg.n_particles
-        sim.reset(state)
-        sim.run_substeps(0, 20)
-        st = sim.get_state(20)
-        rng = np.random.default_rng(3)
-        sim.clear_grads()
-        sim.add_grad(20, gx=rng.standard_normal((N, 3)), gv=rng.standard_normal((N, 3)))
-        sim.run_substeps_grad(0, 20)
-        gx, gv, gF, gC = sim.get_grad_full(0)
-        ext = np.array([m.ext_f.to_numpy() for m in prm])
-        outs.append((st, np.hstack([gx, gv]), gF, ext))
-        del sim, prm
-    # relative L2 over all particles: single-precision rollouts through contact and yield are chaotic for a handful of
-    # particles (one run in a few shows a 5 % outlier in one particle's F adjoint), which a max-norm would pick up
-    l2 = lambda a, b: float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))
+def _rebinning_outputs(precision, si, nsub=20):
+    cfg, env_dt, state, specs, pst, sim, prm = _engine(precision, max_steps=nsub + 4, sort_interval=si)
+    N = cfg.n_particles
+    sim.reset(state)
+    sim.run_substeps(0, nsub)
+    st = sim.get_state(nsub)
+    # particles that enter the reference's SVD-adjoint clamp at some frame of the window (helpers.F32_TOL "clamp")
+    zone = np.zeros(N, dtype=bool)
+    for f in range(nsub):
+        s = sim.get_state(f)
+        Ft = (np.eye(3)[None] + cfg.dt * s[:, 15:24].reshape(N, 3, 3)) @ s[:, 6:15].reshape(N, 3, 3)
+        s2 = np.linalg.svd(Ft, compute_uv=False) ** 2
+        zone |= np.minimum(np.abs(s2[:, 0] - s2[:, 1]), np.minimum(np.abs(s2[:, 1] - s2[:, 2]), np.abs(s2[:, 0] - s2[:, 2]))) < 4e-6
+    rng = np.random.default_rng(3)
+    sim.clear_grads()
+    sim.add_grad(nsub, gx=rng.standard_normal((N, 3)), gv=rng.standard_normal((N, 3)))
+    sim.run_substeps_grad(0, nsub)
+    gx, gv, gF, gC = sim.get_grad_full(0)
+    ext = np.array([m.ext_f.to_numpy() for m in prm])
+    return st, np.hstack([gx, gv]), gF, ext, zone
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_fullsize_rebinning_invariance(precision):
+    """A 20-substep S-grip rollout and its backward pass must not depend on how often the particles are re-binned
+    (sort_interval 1 / 16 / never): only the summation order changes.  Max-norm PER PARTICLE (r1's relative L2 hid a 6.7 %
+    outlier in one particle's F adjoint).  Its cause, found with tools/prec_probe.py: particles whose F_tmp has two singular
+    values within the reference's backward_svd clamp (|s_j^2 - s_i^2| < 1e-6, mpm_simulator.py:184-192), where K = 1e6
+    multiplies the difference itself - a 3e-10 change of F moves the reference's own f64 gradient of such a particle by up to
+    1e-4 per substep.  f64 rollouts agree to 1e-8 for every particle (deterministic check of the re-ordering code); in f32
+    the clamp-zone particles (~0.1 % per frame) are bounded separately, all others in max-norm."""
+    outs = [_rebinning_outputs(precision, si) for si in (1, 16, 1000)]
+    N = outs[0][0].shape[0]
+    per = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).reshape(N, -1).max(1) / np.abs(np.asarray(b)).max()
+    # f32: two 20-substep rollouts that differ only in summation order - a 1e-7 perturbation per substep, carried through
+    # plastic yield and contact - agree to 1e-5 on every particle's state; adjoints to 1e-3 outside the clamp zone
+    ts, tg, tz = (1e-9, 1e-8, 1e-8) if precision == "float64" else (1e-5, 1e-3, 1e-1)
+    zone = outs[0][4] | outs[1][4] | outs[2][4]
+    assert zone.mean() < 0.05
     for o in outs[1:]:
-        assert l2(o[0][:, :6], outs[0][0][:, :6]) < 1e-5
-        assert l2(o[0][:, 6:], outs[0][0][:, 6:]) < 1e-4
-        assert l2(o[1], outs[0][1]) < 2e-3
-        assert l2(o[2], outs[0][2]) < 2e-3
-        assert l2(o[3], outs[0][3]) < 1e-3
+        es, eg, ef = per(o[0], outs[0][0]), per(o[1], outs[0][1]), per(o[2], outs[0][2])
+        # f32: the reference's function also has KINKS - the yield clip of sigma (:226-229, its adjoint switches between ma_ii and
+        # 0), the contact branches (primitive_base.py:152, 161, 168).  Two rollouts 1e-7 apart put a handful of the 2e7
+        # particle-substeps on different sides of one (expected count N * frames * density * 1e-7 ~ 20); they are counted, not hidden.
+        kinks = int(((eg > tg) | (ef > tg))[~zone].sum())
+        print(f"[{precision}] state {es.max():.1e}  gx,gv {eg.max():.1e}  gF outside {ef[~zone].max():.1e} inside {ef[zone].max() if zone.any() else 0:.1e}"
+              f"  zone {int(zone.sum())}  kink particles {kinks}")
+        assert es.max() < ts
+        assert kinks <= (0 if precision == "float64" else 64)
+        assert eg.max() < tz and ef.max() < tz
+        assert H.rel_err(o[3], outs[0][3]) < max(100 * ts, 1e-8)

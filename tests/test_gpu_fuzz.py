@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 CASES = list(range(40))
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_random_configuration(case):
+def fuzz_case(case):
+    """the seeded configuration of one case (also used by tools/prec_probe.py --fuzz)"""
     rng = np.random.default_rng(1000 + case)
     N = int(rng.choice([1, 2, 63, 64, 65, 127, 300, 777, 1500]))
     n_grid = 32
@@ -39,8 +39,10 @@ def test_random_configuration(case):
         top = state[:, 1].max()
         for f in range(len(pstates)):
             pstates[f][0][1] = top + 0.15 - 0.004 - 2e-4 * 0.3 * f
-    tol = None
-    if precision == "float32":
-        # contact in f32 is bounded by position rounding / dt; the liquid's stiffness-free stress by J - 1
-        tol = dict(state=2e-3 if (with_prim or ptype == 2) else 2e-5, grad=2e-2 if (with_prim or ptype == 2) else 5e-4)
-    _compare_rollout(cfg, 2e-3, state, steps, specs, pstates, seed=case, tol=tol)
+    return dict(cfg=cfg, state=state, steps=steps, specs=specs, pstates=pstates, near_wall=near_wall, with_prim=with_prim)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_random_configuration(case):
+    c = fuzz_case(case)
+    _compare_rollout(c["cfg"], 2e-3, c["state"], c["steps"], c["specs"], c["pstates"], seed=case)   # tolerances: helpers.F32_TOL / 1e-9, 1e-8

@@ -11,8 +11,7 @@ from helpers import O
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"float64": dict(state=1e-9, grad=1e-8), "float32": dict(state=1e-5, grad=2e-4)}
-# NB grads in f32: 2e-4 bounds the worst field in the stiff plastic scenes; typical is ~1e-5.
+TOL = {"float64": dict(state=1e-9, grad=1e-8, gx=1e-8, clamp=1e-8), "float32": H.F32_TOL}      # see helpers.F32_TOL
 
 
 def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None, actions=None, control_idx=None,
@@ -36,7 +35,11 @@ def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None
         errs[f"F[{f}]"] = H.rel_err(st[:, 6:15], F.reshape(N, 9).numpy())
         errs[f"C[{f}]"] = H.rel_err(st[:, 15:24], C.reshape(N, 9).numpy())
     for k, e in errs.items():
-        assert e < tol["state"], (k, e, errs)
+        lim = tol["state"]
+        if k.startswith("C[") and cfg.precision == "float32":
+            f = int(k[2:-1])
+            lim = H.c_tol(lim, cfg.n_grid, orc.frames[f][1].numpy(), orc.frames[f][2].numpy())
+        assert e < lim, (k, e, lim, errs)
     if prim_specs:
         ext_ref = np.sum(np.array(orc.ext), axis=0)            # (P,6) accumulated over the window
         for i, m in enumerate(prims):
@@ -58,10 +61,13 @@ def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None
         got_ag.append(sim.substep_grad(f, None if actions is None else actions[f], ext_f_grad))
     got_ag = got_ag[::-1]
     gx, gv, gF, gC = sim.get_grad_full(0)
-    gerrs = dict(gx=H.rel_err(gx, adj[0][0].numpy()), gv=H.rel_err(gv, adj[0][1].numpy()),
-                 gC=H.rel_err(gC, adj[0][2].numpy()), gF=H.rel_err(gF, adj[0][3].numpy()))
+    zone = H.clamp_zone(orc, P, nsteps)
+    gerrs, zerrs = {}, {}
+    for k, got, ref in (("gx", gx, adj[0][0]), ("gv", gv, adj[0][1]), ("gC", gC, adj[0][2]), ("gF", gF, adj[0][3])):
+        gerrs[k], zerrs[k] = H.rel_err_split(got, ref.numpy(), zone)
     for k, e in gerrs.items():
-        assert e < tol["grad"], (k, e, gerrs)
+        assert e < tol.get(k, tol["grad"]), (k, e, gerrs)
+        assert zerrs[k] < tol.get("clamp", tol["grad"]), ("clamp zone", k, zerrs, int(zone.sum()))
     if prim_specs:
         for i, m in enumerate(prims):
             for f in range(nsteps):
@@ -127,11 +133,7 @@ def test_grip_fixture_forecast_contact(precision):
                     precision=precision)
     rng = np.random.default_rng(5)
     eg = [rng.standard_normal(6) * 1e-2]
-    tol = None
-    if precision == "float32":
-        # fp32 positions (6e-8 * 0.5) divided by dt in the forecast push-out bound contact accuracy
-        tol = dict(state=5e-4, grad=5e-3)
-    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg, tol=tol)
+    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg)
 
 
 @pytest.mark.parametrize("precision", ["float64", "float32"])
@@ -141,8 +143,7 @@ def test_backward_recompute_path(precision):
     state = d["state"]
     specs, pstates = _palm_scene(state, 4)
     cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, precision=precision, recompute_backward=True)
-    tol = None if precision == "float64" else dict(state=5e-4, grad=5e-3)
-    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, tol=tol)
+    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates)
 
 
 def test_resort_every_substep_and_long_window():
@@ -231,8 +232,12 @@ def test_against_committed_golden_vectors(name, precision):
     n = sc["nsteps"]
     sim.run_substeps(0, n)
     contact = bool(sc["specs"])
-    ts = 1e-9 if precision == "float64" else (5e-4 if contact else 1e-5)
-    tg = 1e-8 if precision == "float64" else (5e-3 if contact else 2e-4)
+    ts = 1e-9 if precision == "float64" else H.F32_TOL["state"]
+    tg = 1e-8 if precision == "float64" else H.F32_TOL["gx"]
+    zone = np.zeros(cfg.n_particles, dtype=bool)
+    if precision == "float32":                          # clamp-zone particles (helpers.F32_TOL), from the oracle's own rollout
+        P = H.oracle_params(cfg, sc["env_dt"])
+        zone = H.clamp_zone(H.OracleRollout(P, sc["state"], sc["specs"], sc["pstates"]).forward(sc["nsteps"]), P, sc["nsteps"])
     st = sim.get_state(n)
     for k, sl in (("x", slice(0, 3)), ("v", slice(3, 6)), ("F", slice(6, 15)), ("C", slice(15, 24))):
         assert H.rel_err(st[:, sl], ref[k]) < ts, (k, H.rel_err(st[:, sl], ref[k]))
@@ -245,7 +250,8 @@ def test_against_committed_golden_vectors(name, precision):
     gx, gv, gF, gC = sim.get_grad_full(0)
     N = cfg.n_particles
     for k, a in (("gx", gx), ("gv", gv), ("gC", gC.reshape(N, 9)), ("gF", gF.reshape(N, 9))):
-        assert H.rel_err(a, ref[k]) < tg, (k, H.rel_err(a, ref[k]))
+        eo, ei = H.rel_err_split(a, ref[k], zone)
+        assert eo < tg and ei < (tg if precision == "float64" else H.F32_TOL["clamp"]), (k, eo, ei)
     if contact:
         got = np.array([m.ext_f.to_numpy() for m in prims])
         assert H.rel_err(got, ref["ext_f"]) < max(ts * 50, 1e-8)
@@ -266,11 +272,10 @@ def test_particle_and_grid_contact_models(precision, collision_type):
                     collision_type=collision_type)
     rng = np.random.default_rng(6)
     eg = [rng.standard_normal(6) * 1e-2]
-    tol = None if precision == "float64" else dict(state=5e-4, grad=5e-3)
-    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg, tol=tol)
+    _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg)
     # the recompute path (no grid checkpoint) must give the same adjoints
     cfg2 = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, precision=precision, collision_type=collision_type, recompute_backward=True)
-    _compare_rollout(cfg2, 1e-3, state, 2, specs, pstates, ext_f_grad=eg, tol=tol)
+    _compare_rollout(cfg2, 1e-3, state, 2, specs, pstates, ext_f_grad=eg)
 
 
 @pytest.mark.parametrize("precision", ["float64", "float32"])

@@ -1,0 +1,59 @@
+"""BASELINE config C1 for real (VERDICT r1, next #2a): the reference's default pour scene - 5000 liquid particles inside the
+glass, glass + bowl in forecast contact - on the HIP path against the oracle, f64 and f32, forward and adjoint, with the SDF
+tables of both meshes rebuilt by the HIP voxeliser and pinned against the numpy voxeliser oracle."""
+import numpy as np
+import pytest
+
+import helpers as H
+import scenes_pour as SP
+from test_gpu_parity import _compare_rollout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tables():
+    from softmac_amd.engine.primitive import voxelize
+    _, _, glass, bowl = SP.load()
+    return [voxelize.mesh_to_sdf(*glass), voxelize.mesh_to_sdf(*bowl)]
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_rebuilt_sdf_tables_match_the_voxeliser_oracle(tables, which):
+    """glass.obj and bowl.obj are closed, consistently oriented 2-manifolds (every edge used twice), so containment is
+    unambiguous and the table is defined by geometry alone: distance / sign / closest-face normal of the HIP kernel vs the
+    brute-force oracle on 4000 random samples of the reference's sampling grid (mesh.py:170-176, 190-233)."""
+    from oracle import voxel_oracle as V
+    mesh = SP.load()[2 + which]
+    t = tables[which]
+    v, f = np.asarray(mesh[0], dtype=np.float64), np.asarray(mesh[1], dtype=np.int64)
+    res = np.asarray(t["res"]); lower = np.asarray(t["position"][0]); dx = float(t["dx"][0])
+    assert dx == pytest.approx(min(0.01, float(np.max(v.max(0) - v.min(0))) / 80))
+    rng = np.random.default_rng(5 + which)
+    ijk = np.stack([rng.integers(0, r, 4000) for r in res], 1)
+    pts = lower + ijk * dx
+    best, tid, gap = V.closest_triangle_distances(pts, v, f, chunk=500)
+    a, b, c = (v[f[:, k]][None] for k in range(3))
+    inside = np.concatenate([V._inside_by_ray(pts[s:s + 500, None, :], a, b, c, np.array([0.8017837257372732, 0.5345224838248488, 0.2672612419124244]))
+                             for s in range(0, len(pts), 500)])
+    ref = np.where(inside, -1.0, 1.0) * np.sqrt(best)
+    got = t["sdf"][ijk[:, 0], ijk[:, 1], ijk[:, 2]]
+    assert np.abs(got - ref).max() < 1e-12
+    assert (got < 0).sum() > 20                                   # samples inside the shell exist
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    uniq = gap > 1e-9                                             # closest triangle unique -> the normal is pinned
+    assert uniq.mean() > 0.5
+    assert np.abs(t["normal"][ijk[:, 0], ijk[:, 1], ijk[:, 2]] - fn[tid] / (1 + 1e-8))[uniq].max() < 1e-9
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_pour_scene_glass_and_bowl_contact(tables, precision):
+    sc = SP.build(tables, precision)
+    errs, gerrs = _compare_rollout(sc["cfg"], sc["env_dt"], sc["state"], sc["nsteps"], sc["specs"], sc["pstates"], ext_f_grad=sc["ext_f_grad"], seed=9)
+    # the scene does exercise contact: liquid against the glass wall
+    sim, prims = H.build_engine(sc["cfg"], sc["env_dt"], sc["specs"], sc["pstates"])
+    sim.reset(sc["state"])
+    sim.substep(0)
+    assert sim.contact_counts()[0] > 200
+    assert np.abs(prims[0].ext_f.to_numpy()).max() > 0

@@ -56,6 +56,6 @@ def test_two_slabs_match_single_domain_cpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-8), ("float32", 5e-4, 5e-3)])
+@pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-8), ("float32", H.F32_TOL["state"], 5e-5)])
 def test_two_slabs_match_single_domain_gpu(tmp_path, precision, ts, tg):
     _check(_run_two_ranks("hip", precision, tmp_path), ts, tg)

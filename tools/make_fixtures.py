@@ -9,6 +9,10 @@ cache is a pickle, so it is opened with a numpy-only restricted unpickler (SURVE
   pour_state_1k.npz   1000-particle subsample of softmac/envs/pour/pour_mpm_init_state_corotated.npy
   palm_sdf.npz        sdf/normal tables of softmac/assets/gripper/palm.obj (the cached 6895...c4d5 blob)
   door_sdf.npz        sdf/normal tables of softmac/assets/door/door.obj (the cached e7ab...561a blob; four touching boxes)
+  pour_scene.npz      BASELINE config C1 inputs: the full 5000-particle pour state + target, and the glass / bowl collision
+                      meshes (vertices / faces of assets/glass/glass.obj, assets/bowl/bowl.obj after trimesh's vertex merge)
+  grip_scene.npz      the full 10000-particle settled grip state (equilibrium pin, tests/test_equilibrium.py) + target, and
+                      the gripper finger mesh (assets/gripper/finger.obj)
 """
 import importlib
 import pathlib
@@ -55,6 +59,16 @@ def main():
                         lower=np.asarray(sdf["position"][0]), upper=np.asarray(sdf["position"][1]),
                         dx=float(sdf["dx"][0]), res=np.asarray(sdf["res"]),
                         vertices=blob["meshes"][0][0], faces=blob["meshes"][0][1])
+    sys.path.insert(0, str(OUT.parent.parent))
+    from softmac_amd.engine.primitive.sdf_cache import load_obj
+    from softmac_amd.engine.primitive.voxelize import merge_vertices
+    gv, gf = merge_vertices(*load_obj(REF / "assets/glass/glass.obj"))
+    bv, bf = merge_vertices(*load_obj(REF / "assets/bowl/bowl.obj"))
+    np.savez_compressed(OUT / "pour_scene.npz", state=pour, target=np.load(REF / "envs/pour/pour_mpm_target_position_corotated.npy"),
+                        glass_vertices=gv, glass_faces=gf.astype(np.int32), bowl_vertices=bv, bowl_faces=bf.astype(np.int32))
+    fv, ff = merge_vertices(*load_obj(REF / "assets/gripper/finger.obj"))
+    np.savez_compressed(OUT / "grip_scene.npz", state=grip, target=np.load(REF / "envs/grip/grip_mpm_target_position.npy"),
+                        finger_vertices=fv, finger_faces=ff.astype(np.int32))
     for p in sorted(OUT.glob("*.npz")):
         print(p.name, p.stat().st_size)
 

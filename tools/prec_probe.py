@@ -30,6 +30,10 @@ def scenes():
     sc = G.build("grip_contact")
     out.append(dict(name="grip2k_contact", cfg=sc["cfg"], env_dt=sc["env_dt"], state=sc["state"], n=3, specs=sc["specs"],
                     pst=sc["pstates"], eg=sc["ext_f_grad"]))
+    for ct in (1, 0):
+        c2 = H.sim_cfg(len(st2k), n_grid=64, dt=2e-4, ptype=0, collision_type=ct)
+        out.append(dict(name=f"grip2k_ctype{ct}", cfg=c2, env_dt=1e-3, state=st2k, n=3, specs=sc["specs"], pst=sc["pstates"],
+                        eg=[np.random.default_rng(6).standard_normal(6) * 1e-2]))
     for ptype, model in ((1, 0), (0, 0), (2, 0), (0, 1)):
         N, ng = 3000, 32
         cfg = H.sim_cfg(N, n_grid=ng, dt=2e-4, ptype=ptype, material_model=model, ground_friction=0.0, E=3e3 if ptype != 2 else 22.0)
@@ -42,14 +46,19 @@ def scenes():
 
 
 def describe(sc, orc, idx):
-    """singular values of F_tmp at frame 0 for particle idx"""
-    x, v, C, F = orc.frames[0]
+    """what is special about particle idx: smallest singular-value gap of F_tmp over the window, clip status, cell coordinates"""
     dt = sc["cfg"].dt
-    Ft = (np.eye(3) + dt * C[idx].numpy()) @ F[idx].numpy()
-    s = np.linalg.svd(Ft, compute_uv=False)
-    e = np.sort(s - 1.0)
-    gaps = np.diff(e)
-    return dict(e=[float(a) for a in e], min_gap=float(gaps.min()), clipped=bool((e < -2e-3).any() or (e > 3e-3).any()))
+    gmin, clipped = 1e30, False
+    for f in range(len(orc.frames) - 1):
+        x, v, C, F = orc.frames[f]
+        Ft = (np.eye(3) + dt * C[idx].numpy()) @ F[idx].numpy()
+        s = np.linalg.svd(Ft, compute_uv=False)
+        e = np.sort(s - 1.0)
+        gmin = min(gmin, float(np.diff(e).min()))
+        clipped |= bool((e < -2e-3).any() or (e > 3e-3).any())
+    x0 = orc.frames[0][0][idx].numpy() * sc["cfg"].n_grid
+    return dict(e=[float(a) for a in e], min_gap=gmin, clipped=clipped, cell=[round(float(a), 3) for a in x0],
+                v=[round(float(a), 3) for a in orc.frames[0][1][idx].numpy()])
 
 
 def run(sc, precision):
@@ -116,19 +125,30 @@ def main():
     ap.add_argument("--precision", default="float32")
     ap.add_argument("--out", default="")
     ap.add_argument("--only", default="")
+    ap.add_argument("--fuzz", default="", help="comma-separated case ids of tests/test_gpu_fuzz.py to probe instead of the fixed scenes")
     args = ap.parse_args()
     res = {"lib": os.environ.get("SMAC_LIB", "default"), "precision": args.precision, "scenes": {}}
-    for sc in scenes():
+    todo = scenes()
+    if args.fuzz:
+        import test_gpu_fuzz as FZ
+        todo = []
+        for c in [int(a) for a in args.fuzz.split(",")]:
+            fc = FZ.fuzz_case(c)
+            cfg = fc["cfg"]
+            print(f"fuzz {c}: N {cfg.n_particles} ptype {cfg.ptype} model {cfg.material_model} ctype {cfg.collision_type} prim {fc['with_prim']} "
+                  f"wall {fc['near_wall']} gf {cfg.ground_friction} g {cfg.gravity} steps {fc['steps']} sort {cfg.sort_interval}", flush=True)
+            todo.append(dict(name=f"fuzz{c}", cfg=cfg, env_dt=2e-3, state=fc["state"], n=fc["steps"], specs=list(fc["specs"]), pst=fc["pstates"], eg=None))
+    for sc in todo:
         if args.only and args.only not in sc["name"]:
             continue
         r = run(sc, args.precision)
         res["scenes"][sc["name"]] = r
         line = " ".join(f"{k}={v['max']:.1e}" for k, v in r.items() if isinstance(v, dict) and "max" in v)
         print(f"[{res['lib']}] {sc['name']}: {line}", flush=True)
-        for k in ("gF[0]", "gx[0]", "v[%d]" % sc["n"]):
+        for k in ("gF[0]", "gx[0]", "v[%d]" % sc["n"], "C[%d]" % sc["n"]):
             if k in r:
                 print("    ", k, "n>1e-5:", r[k]["n_over_1e5"], "l2", f"{r[k]['l2']:.1e}", "worst:",
-                      [(w["i"], f"{w['err']:.1e}", f"gap {w['min_gap']:.1e}", "clip" if w["clipped"] else "") for w in r[k]["worst"][:3]], flush=True)
+                      [(w["i"], f"{w['err']:.1e}", f"gap {w['min_gap']:.1e}", "clip" if w["clipped"] else "", w["cell"], w["v"]) for w in r[k]["worst"][:3]], flush=True)
     if args.out:
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         json.dump(res, open(args.out, "w"), indent=1)

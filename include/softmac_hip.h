@@ -105,6 +105,12 @@ int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, doub
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC); /* loss kernels' `x.grad[f,i] +=` */
 int smac_clear_grads(smac_handle h);                                          /* ti.ad.clear_all_gradients() */
 int smac_set_control_idx(smac_handle h, const int32_t* idx);                  /* set_control_idx :599-602 */
+/* Slab decomposition with particle MIGRATION (no reference counterpart): a handle is created with the CAPACITY
+ * n_particles; a rank's live particle count changes when particles are handed to a neighbouring slab.  Frames written or
+ * processed after this call hold `n_live` particles (the caller keeps frames of different segments apart: the migration point
+ * occupies two consecutive frames, one per ordering); `frame_shift` = number of such duplicate frames before the current segment,
+ * so that the substep phase `f % substeps` of the forecast contact (:425) follows the physical substep, not the frame index. */
+int smac_set_segment(smac_handle h, int n_live, int frame_shift);
 int smac_set_action(smac_handle h, const double* action);                     /* set_action :589-592: (n_control, 3); zeroes action.grad (:584-586) */
 int smac_compute_grid_m(smac_handle h, int f, double* grid_m);                /* compute_grid_m_kernel :607-617, (n,n,n) out */
 

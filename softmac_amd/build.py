@@ -77,6 +77,8 @@ def _compile(LIB, defines, report, verbose, extra=()):
         with open(out, "w") as fh:
             for r in rows:
                 name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip() or r["name"]
+                if "smac::" not in name:
+                    continue                      # (rocPRIM's scan / transform trampolines for every arch it knows)
                 fh.write(f"{name}: " + ", ".join(f"{k}={v}" for k, v in r.items() if k != "name") + "\n")
         if verbose:
             print(out.read_text())

@@ -45,6 +45,19 @@ namespace smac {
 #ifndef SMAC_OCC_P2G
 #define SMAC_OCC_P2G 6
 #endif
+#ifndef SMAC_OCC_G2P_PIPE
+#define SMAC_OCC_G2P_PIPE 3
+#endif
+// register-pressure knobs of the two gradient kernels (A/B on MI355X: tools/r02_h.sh)
+#ifndef SMAC_DW_RECOMPUTE
+#define SMAC_DW_RECOMPUTE 1      // WGrad::to_fx recomputes dw from fx instead of keeping Stencil::dw live across the gather
+#endif
+#ifndef SMAC_GFN_STASH
+#define SMAC_GFN_STASH 0         // 1: k_p2g_grad parks F.grad[f+1] in the LDS stash (48 KB per workgroup) instead of 9 registers: 100 vs 92 us
+#endif
+#ifndef SMAC_GFX_FROM_A
+#define SMAC_GFX_FROM_A 1        // k_p2g_grad: dpos adjoint from a0,a1,a2 (live anyway) instead of the 9 affine entries
+#endif
 // arithmetic type of the constitutive model (SVD, stress, their adjoint) inside the particle kernels: the storage type R,
 // or double whatever R is (SMAC_CONST_F64=1; measured for the f32 accuracy study, tools/prec_probe.py)
 #ifndef SMAC_CONST_F64
@@ -53,6 +66,7 @@ namespace smac {
 template <class R> struct const_t { typedef typename std::conditional<SMAC_CONST_F64 != 0, double, R>::type type; };
 constexpr int BLOCK = 256;
 enum { CX = 0, CV = 3, CC = 6, CF = 15, NCOMP = 24 };
+static_assert(NCOMP == NCOMP_ROWS, "frame layout helpers (smac_math.hpp) assume 24 components");
 
 template <class R> struct alignas(4 * sizeof(R)) Vec4 { R x, y, z, w; };
 struct Hit { int p, mask, block, pad; };
@@ -101,9 +115,18 @@ template <class R> struct DevSim {
     const int* block_chunk_start;   // per block: first chunk / number of chunks (dense, nb^3)
     const int* block_chunks;
     int* drift_flag;
+    int frame_shift;             // duplicate frames before this segment (smac_set_segment): physical substep = f - frame_shift
     int check_next;              // k_g2p: frame f+1 is processed with THIS binning too, so x[f+1] must still lie inside the halo
     int open_x;                  // slab decomposition: bit 0 / bit 1 = no wall at the low / high x end (neighbour slab there)
     const int* block_active;     // dense per-block flag of the current epoch (halo packing)
+    // Grid checkpoint of the frame being processed, [active slot][vin | vmix | vout][64 cells], or nullptr.
+    // Forward: k_grid_op / k_contact_hits write it directly (no copy kernel).  Backward: the kernels READ the forward grid
+    // from it (no restore kernel); the dense vin / vmix / vout arrays are then not valid for that frame.
+    Vec4<R>* ck;
+    const int* block_slot;       // dense per block: its slot in the active list of the current epoch (valid where block_active)
+    struct Hit* hit_ck;          // forward: where k_grid_op files the frame's contact hit list (with its length), or nullptr
+    int* nhit_ck;
+    int hit_cap;
 };
 
 // LDS tile: the 6x6x6 nodes a particle whose base lies in a 4x4x4 block can touch (origin = 4*block).
@@ -171,6 +194,10 @@ template <class R> __device__ __forceinline__ void atomic_add(R* p, R v) { unsaf
 template <class R> __device__ __forceinline__ Vec4<R> gld(const Vec4<R>* base, unsigned cell) {
     return *(const Vec4<R>*)((const char*)base + cell * (unsigned)sizeof(Vec4<R>));
 }
+template <class R> struct DevSim;
+// forward-grid record (field 0: {m,p}, 1: v_mixed, 2: v_out) of a dense block-major cell index: from the frame's checkpoint when
+// the backward pass runs on one, else from the dense array
+template <class R> __device__ __forceinline__ Vec4<R> gval(const DevSim<R>& D, int field, unsigned cell);
 template <class R> __device__ __forceinline__ void gatomic(Vec4<R>* base, unsigned cell, int comp, R v) {
     unsafeAtomicAdd((R*)((char*)base + cell * (unsigned)sizeof(Vec4<R>)) + comp, v);
 }
@@ -189,18 +216,20 @@ template <class R> __device__ __forceinline__ R* frame(R* base, int f, int Npad)
 }
 
 template <class R> __device__ __forceinline__ void load_vec(const R* fr, int c0, int cnt, int Npad, int p, R* out) {
+    const size_t po = poff(p);
 #pragma unroll
-    for (int i = 0; i < cnt; ++i) out[i] = fr[(size_t)(c0 + i) * Npad + p];
+    for (int i = 0; i < cnt; ++i) out[i] = fr[rowbase(c0 + i, Npad) + po];
 }
 // position rows (smac_math.hpp pos_of): doubles, or 32-bit fixed point in the float slots
 template <class R> __device__ __forceinline__ void load_pos(const R* fr, int Npad, int p, typename pos_of<R>::type* out) {
     typedef typename pos_of<R>::type P;
+    const size_t po = poff(p);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) out[i] = ((const P*)fr)[(size_t)(CX + i) * Npad + p];
+    for (int i = 0; i < 3; ++i) out[i] = ((const P*)fr)[rowbase(CX + i, Npad) + po];
 }
 template <class R> __device__ __forceinline__ void store_pos(R* fr, int Npad, int p, int i, typename pos_of<R>::type v) {
     typedef typename pos_of<R>::type P;
-    ((P*)fr)[(size_t)(CX + i) * Npad + p] = v;
+    ((P*)fr)[rowoff(CX + i, p, Npad)] = v;
 }
 template <class R, class P> __device__ __forceinline__ void pos_to(const P* x, R* out) {
 #pragma unroll
@@ -338,6 +367,14 @@ __device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, Ve
     }
 }
 
+template <class R> __device__ __forceinline__ Vec4<R> gval(const DevSim<R>& D, int field, unsigned cell) {
+    if (D.ck) {
+        const int slot = D.block_slot[cell >> 6];
+        return D.ck[(size_t)slot * 192 + field * 64 + (cell & 63)];
+    }
+    const Vec4<R>* base = field == 0 ? D.vin : (field == 1 ? D.vmix : D.vout);
+    return gld(base, cell);
+}
 // Stage the 6x6x6 node records of `field` around this chunk's block into LDS (gather tile).
 // Nodes outside the grid read as zero (they are never addressed: bases are clamped).
 template <class R>
@@ -349,6 +386,20 @@ __device__ __forceinline__ void gather_tile_load(const DevSim<R>& D, const Vec4<
         const int i = 4 * bx + li, j = 4 * by + lj, k = 4 * bz + lk;
         Vec4<R> v = {R(0), R(0), R(0), R(0)};
         if (i < D.n && j < D.n && k < D.n) v = field[cell_of(nb, i, j, k)];
+        gt[idx] = v;
+    }
+}
+
+// the same for a FORWARD-grid field (0: {m,p}, 1: v_mixed, 2: v_out) in the backward pass: from the checkpoint when there is one
+template <class R>
+__device__ __forceinline__ void gather_tile_load_fwd(const DevSim<R>& D, int field_id, int block, Vec4<R>* gt) {
+    const int nb = D.nb;
+    const int bz = block % nb, by = (block / nb) % nb, bx = block / (nb * nb);
+    for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
+        const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
+        const int i = 4 * bx + li, j = 4 * by + lj, k = 4 * bz + lk;
+        Vec4<R> v = {R(0), R(0), R(0), R(0)};
+        if (i < D.n && j < D.n && k < D.n) v = gval(D, field_id, (unsigned)cell_of(nb, i, j, k));
         gt[idx] = v;
     }
 }
@@ -383,7 +434,9 @@ template <class R> __device__ __forceinline__ void prim_state_R(const DevSim<R>&
 #pragma unroll
     for (int c = 0; c < 13; ++c) s13[c] = (R)ps[c];
 }
-template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const typename pos_of<R>::type* xp) {
+// `ps`: optional workgroup copy of the primitive states of frame f already converted to R ([prim][13], k_p2g: 13 f64 -> f32
+// conversions per primitive once per workgroup instead of once per particle)
+template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& D, int f, const typename pos_of<R>::type* xp, const R* ps = nullptr) {
     int mask = 0;
     R x[3];
     pos_to(xp, x);
@@ -391,7 +444,10 @@ template <class R> __device__ __forceinline__ int contact_mask(const DevSim<R>& 
     for (int i = 0; i < MAX_PRIMS; ++i) {
         if (i >= D.P || !D.prim[i].contact) continue;
         R st[13];
-        prim_state_R(D, i, f, st);
+        if (ps) {
+#pragma unroll
+            for (int c = 0; c < 13; ++c) st[c] = ps[13 * i + c];
+        } else prim_state_R(D, i, f, st);
         R d = prim_sdf(D.prim[i], st, x);
         if (d <= R(5e-3) + (sizeof(R) == 4 ? R(2e-5) : R(0))) mask |= 1 << i;
     }
@@ -466,11 +522,19 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <class R, bool STORE_F>
+// PCON: collision_type 1 (penalty contact inside p2g) - a separate instantiation, so that the benchmarked forecast-contact
+// kernel does not carry the f64 penalty chain in its register budget
+template <class R, bool STORE_F, bool PCON>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_p2g(DevSim<R> D, int f) {
     typedef typename ScatterTile<R>::word W;
     __shared__ double tile_raw[4 * TILE_WORDS];
     __shared__ R smax[4];
+    __shared__ R ps_wg[MAX_PRIMS * 13];
+    if (D.any_contact) {                 // (uniform) primitive states of this frame, converted once per workgroup for the band test
+        if (threadIdx.x < D.P * 13)
+            ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];
+        __syncthreads();
+    }
     SMAC_CHUNK_PROLOGUE
     W* const tile = (W*)tile_raw;
     double* const tile64 = tile_raw;
@@ -492,7 +556,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
         if (D.any_contact && D.collision_type != CONTACT_GRID) {   // contact band test (x is at hand): build the sparse contact lists
-            cmask = contact_mask(D, f, x);
+            cmask = contact_mask(D, f, x, (const R*)ps_wg);
             if (cmask) {
                 Hit h = {p, cmask, ch.block, 0};
                 D.hits[hit_slot(D.nhits)] = h;
@@ -513,22 +577,24 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         if (STORE_F) {
             R* Sn = frame(D.S, f + 1, D.Npad);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Sn[(size_t)(CF + i) * D.Npad + p] = En[i];     // :250
+            for (int i = 0; i < 9; ++i) Sn[rowoff(CF + i, p, D.Npad)] = En[i];     // :250
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
         pv[0] = D.p_mass * v[0]; pv[1] = D.p_mass * v[1]; pv[2] = D.p_mass * v[2];
-        if (D.collision_type == CONTACT_PARTICLE && cmask) {                              // :203-206 penalty contact impulse
-            R xr[3];
-            pos_to(x, xr);
+        if (PCON && cmask) {                                                              // :203-206 penalty contact impulse
+            // in f64 whatever R is: the impulse is proportional to the penetration depth c = dist - 5e-3, a small difference
+            // of the position and the table (a float x would put 3e-5 on it)
+            const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])}, v64[3] = {(double)v[0], (double)v[1], (double)v[2]};
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i) {
                 if (!((cmask >> i) & 1)) continue;
-                R s13[13], imp[3], ext[6];
-                prim_state_R(D, i, f, s13);
-                if (collide_particle(D.prim[i], s13, xr, v, D.dt, imp, ext)) {
-                    for (int c = 0; c < 3; ++c) pv[c] += imp[c];
-                    for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + i * 6 + c, (double)ext[c]);   // sparse: a few thousand particles
+                const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                double s13[13], imp[3], ext[6];
+                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+                if (collide_particle(D.prim64[i], s13, x64, v64, D.dt64, imp, ext)) {
+                    for (int c = 0; c < 3; ++c) pv[c] += (R)imp[c];
+                    for (int c = 0; c < 6; ++c) atomic_add(D.ext_f + i * 6 + c, ext[c]);   // sparse: a few thousand particles
                 }
             }
         }
@@ -628,7 +694,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
             }
         }
     }
-    if (D.any_contact && D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;   // read back by p2g.grad
+    if (PCON && D.any_contact && valid) D.pmask[p] = cmask;   // read back by p2g.grad
     __syncthreads();
     if (sparse) tile_store<R, 4>(D, tile64, R(1), R(1));
     else tile_store<R, 4>(D, tile, sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1), from_tile);
@@ -670,17 +736,33 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
+    if (D.hit_ck && phase != 1) {            // the frame's contact hit list (complete since k_p2g) goes on file with the checkpoint
+        int nh = *D.nhits;
+        if (nh > D.hit_cap) {                // more particles in contact bands than a slot holds: reported, never truncated silently
+            if (blockIdx.x == 0 && threadIdx.x == 0) *D.drift_flag = 2;
+            nh = 0;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *D.nhit_ck = nh;
+        for (int q = blockIdx.x * BLOCK + threadIdx.x; q < nh; q += gridDim.x * BLOCK) D.hit_ck[q] = D.hits[q];
+    }
     Vec4<R> acc = D.vin[cell];                                                          // drift fallback part
     if (phase != 2) {
         slab_reduce(D, b, l, acc);
-        D.vin[cell] = acc;
+        if (phase == 1 || !D.ck) D.vin[cell] = acc;
     }
     if (phase == 1) return;
+    const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+    Vec4<R>* ckp = nullptr;
+    if (D.ck) {                              // {m,p} lives in the checkpoint from here on; the dense array is left ZEROED for the next
+        ckp = D.ck + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 192 + l;           // P2G's drifted atomics (no clear pass)
+        ckp[0] = acc;
+        D.vin[cell] = z;
+    }
     const R m = acc.x;
     if (!(m > R(1e-10))) {                                                             // :286 / :399: no velocity on this node
-        const Vec4<R> z = {R(0), R(0), R(0), R(0)};                                    // (written, so the fields need no clear)
-        if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = z;
+        if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = z;                       // (written, so the fields need no clear)
         D.vout[cell] = z;
+        if (ckp) { ckp[64] = z; ckp[128] = z; }
         return;
     }
     const R inv = R(1) / m;
@@ -700,6 +782,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     const Vec4<R> o = {v[0], v[1], v[2], R(0)};
     if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = o;                            // :403
     D.vout[cell] = o;                                                                   // :404 / :297
+    if (ckp) { ckp[64] = o; ckp[128] = o; }
 }
 
 template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D, const Vec4<R>* field, const Stencil<R>& st,
@@ -730,7 +813,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
     if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
     const int nh = *D.nhits;
     const int grp = threadIdx.x >> 5, d = threadIdx.x & 31;
-    const double life = 1.0 / (double)(D.substeps - f % D.substeps);                        // :425
+    const double life = 1.0 / (double)(D.substeps - (f - D.frame_shift) % D.substeps);     // :425
     for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
         for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) ctile[i] = 0.0;
         const int wg_block = D.hits[base].block;
@@ -755,7 +838,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         bool has = false;
         if (mask && d < 27) {
             vm = gld(D.vmix, cell);
-            has = gld(D.vin, cell).x > R(1e-10);
+            has = gval(D, 0, cell).x > R(1e-10);            // ({m,p} is in the checkpoint when there is one: k_grid_op zeroed the array)
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2
 #pragma unroll
@@ -785,7 +868,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
             for (int c = 0; c < 3; ++c) {
                 const R val = -R(2) * wn * (R)((double)v_tmp[c] - v_tgt[c]);
                 if (in_tile) lds_add(ctile + tw + c * TILE_WORDS, val);
-                else gatomic(D.vout, cell, c, val);
+                else {
+                    gatomic(D.vout, cell, c, val);
+                    if (D.ck) gatomic(D.ck + (size_t)D.block_slot[cell >> 6] * 192 + 128, cell & 63u, c, val);
+                }
             }
         }
         __syncthreads();
@@ -798,6 +884,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
                     const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
                     const unsigned c2 = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
                     gatomic(D.vout, c2, 0, a0); gatomic(D.vout, c2, 1, a1); gatomic(D.vout, c2, 2, a2);
+                    if (D.ck) {                                 // the checkpoint's copy of v_out gets the same correction
+                        Vec4<R>* co = D.ck + (size_t)D.block_slot[c2 >> 6] * 192 + 128;
+                        gatomic(co, c2 & 63u, 0, a0); gatomic(co, c2 & 63u, 1, a1); gatomic(co, c2 & 63u, 2, a2);
+                    }
                 }
             }
         }
@@ -807,21 +897,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
     if (threadIdx.x < D.P * 6 && ext_acc[threadIdx.x] != 0.0) atomic_add(D.ext_f + threadIdx.x, ext_acc[threadIdx.x]);
 }
 
+// one particle of g2p :299-318: gather from the staged tile `gt` (global fallback for a lane that drifted out of it), write frame f+1
 template <class R>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_g2p(DevSim<R> D, int f) {
-    __shared__ Vec4<R> gt[TILE_WORDS];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // last kernel of the substep: hand the contact lists back empty
-        D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
-        *D.nhits = 0; *D.ncand = 0;
-    }
-    SMAC_CHUNK_PROLOGUE
-    const R* Sf = frame(D.S, f, D.Npad);
-    R* Sn = frame(D.S, f + 1, D.Npad);
-    typename pos_of<R>::type x[3];
-    load_pos(Sf, D.Npad, p, x);                     // issued before the tile load's barrier: one round trip, not two
-    gather_tile_load(D, D.vout, ch.block, gt);
-    __syncthreads();
-    if (!valid) return;
+__device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch, int p, const typename pos_of<R>::type* x, const Vec4<R>* gt, R* Sn) {
     Stencil<R> st;
     Nodes nd;
     stencil_at(D, x, st, nd, ch.block);
@@ -874,21 +952,94 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
     bool leaves = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        Sn[(size_t)(CV + c) * D.Npad + p] = nv[c];
-        typename pos_of<R>::type xn;
-        const double xd = pos_get(x[c]) + D.dt64 * (double)nv[c];                      // :318
-        pos_set(xd, xn);
+        Sn[rowoff(CV + c, p, D.Npad)] = nv[c];
+        const typename pos_of<R>::type xn = pos_advance(x[c], D.dt64, nv[c]);          // :318
         store_pos(Sn, D.Npad, p, c, xn);
         // the position just written is scattered by the NEXT substep's P2G: if that substep keeps this binning, the new
         // base must still lie in the blocks around the chunk's own (the only ones that are cleared, reduced and swept)
-        int nbase = (int)(pos_get(xn) * (double)D.n - 0.5);
+        int nbase = pos_base(xn, D.n);
         nbase = nbase < 0 ? 0 : (nbase > D.n - 3 ? D.n - 3 : nbase);
         const int cbk = c == 0 ? ch.block / (D.nb * D.nb) : (c == 1 ? (ch.block / D.nb) % D.nb : ch.block % D.nb);
         leaves |= (nbase >> 2) < cbk - 1 || (nbase >> 2) > cbk + 1;
     }
     if (leaves && D.check_next) *D.drift_flag = 1;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) Sn[(size_t)(CC + c) * D.Npad + p] = four_inv_dx * nC[c];
+    for (int c = 0; c < 9; ++c) Sn[rowoff(CC + c, p, D.Npad)] = four_inv_dx * nC[c];
+}
+
+template <class R>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_g2p(DevSim<R> D, int f) {
+    __shared__ Vec4<R> gt[TILE_WORDS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // last kernel of the substep: hand the contact lists back empty
+        D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
+        *D.nhits = 0; *D.ncand = 0;
+    }
+    SMAC_CHUNK_PROLOGUE
+    const R* Sf = frame(D.S, f, D.Npad);
+    R* Sn = frame(D.S, f + 1, D.Npad);
+    typename pos_of<R>::type x[3];
+    load_pos(Sf, D.Npad, p, x);                     // issued before the tile load's barrier: one round trip, not two
+    gather_tile_load(D, D.vout, ch.block, gt);
+    __syncthreads();
+    if (!valid) return;
+    g2p_particle(D, ch, p, x, gt, Sn);
+}
+
+// Persistent, software-pipelined form: a workgroup walks several chunks of its XCD's range; while it computes chunk k from LDS
+// buffer k & 1, the positions and the 216 tile records of chunk k+1 and the descriptor of chunk k+2 are already in flight.  The
+// per-chunk form above spends most of a wave's life in three dependent round trips (descriptor -> x / tile -> compute -> stores).
+template <class R>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P_PIPE : 2)) void k_g2p_pipe(DevSim<R> D, int f) {
+    typedef typename pos_of<R>::type PX;
+    __shared__ Vec4<R> gt[2][TILE_WORDS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
+        *D.nhits = 0; *D.ncand = 0;
+    }
+    const int t = threadIdx.x;
+    const int per = (D.nchunks + 7) >> 3;                              // the XCD-aware split of xcd_chunk()
+    const int J = (int)(gridDim.x >> 3);
+    const int lo = (int)(blockIdx.x & 7) * per;
+    const int hi = lo + per < D.nchunks ? lo + per : D.nchunks;
+    int c = lo + (int)(blockIdx.x >> 3);
+    if (c >= hi) return;
+    const R* Sf = frame(D.S, f, D.Npad);
+    R* Sn = frame(D.S, f + 1, D.Npad);
+    const int nb = D.nb;
+    auto issue = [&](const Chunk& k, PX* xo, Vec4<R>& tvo) {
+        load_pos(Sf, D.Npad, k.start + (t < k.count ? t : 0), xo);
+        if (t < TILE_WORDS) {
+            const int bz = k.block % nb, by = (k.block / nb) % nb, bx = k.block / (nb * nb);
+            const int i = 4 * bx + t / TSX, j = 4 * by + (t / TSY) % TW, kk = 4 * bz + t % TW;
+            const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+            tvo = (i < D.n && j < D.n && kk < D.n) ? D.vout[cell_of(nb, i, j, kk)] : z;
+        }
+    };
+    Chunk ch = D.chunks[c];
+    int cn = c + J;
+    Chunk chn = cn < hi ? D.chunks[cn] : ch;
+    PX x[3];
+    Vec4<R> tv = {R(0), R(0), R(0), R(0)};
+    issue(ch, x, tv);
+    int buf = 0;
+    for (;;) {
+        if (t < TILE_WORDS) gt[buf][t] = tv;
+        __syncthreads();
+        const bool more = cn < hi;
+        PX xn[3] = {x[0], x[1], x[2]};
+        Vec4<R> tvn = tv;
+        Chunk chnn = chn;
+        if (more) {
+            issue(chn, xn, tvn);
+            if (cn + J < hi) chnn = D.chunks[cn + J];
+        }
+        if (t < ch.count) g2p_particle(D, ch, ch.start + t, x, gt[buf], Sn);
+        if (!more) break;
+        ch = chn; chn = chnn; cn += J;
+        x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
+        tv = tvn;
+        buf ^= 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -909,8 +1060,17 @@ template <class R> struct WGrad {
         g[k][2] += gw * st.w[i][0] * st.w[j][1];
     }
     __device__ __forceinline__ void to_fx(const Stencil<R>& st, R* gfx) const {
+#if SMAC_DW_RECOMPUTE
+        // the weight derivatives are recomputed from fx here (mpm_simulator.py:217) instead of being kept live across the gather
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const R fx = st.fx[d];
+            gfx[d] += g[0][d] * (fx - R(1.5)) + g[1][d] * (R(-2) * (fx - R(1))) + g[2][d] * (fx - R(0.5));
+        }
+#else
 #pragma unroll
         for (int d = 0; d < 3; ++d) gfx[d] += g[0][d] * st.dw[0][d] + g[1][d] * st.dw[1][d] + g[2][d] * st.dw[2][d];
+#endif
     }
 };
 
@@ -926,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;       // f64 words instead of fixed point (see SPARSE_MAX)
     if (sparse) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
     else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
-    gather_tile_load(D, D.vout, ch.block, gt);      // (its barrier is the one inside tile_scale below: the particle loads
+    gather_tile_load_fwd(D, 2, ch.block, gt);       // (its barrier is the one inside tile_scale below: the particle loads
                                                     //  that follow are then in flight together with the tile's)
     typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
     R gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
@@ -998,7 +1158,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
                             const bool in = !MIXED || (okxi & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
                             const unsigned cell = (unsigned)(cxi + nd.cy[j] + nd.cz[k]);
                             Vec4<R> g = gt[in ? tw : 0];                 // unconditional LDS read (see k_g2p)
-                            if (MIXED && !in) g = gld(D.vout, cell);
+                            if (MIXED && !in) g = gval(D, 2, cell);
                             const R tk[3] = {tj[0] + R(k) * gC1[2], tj[1] + R(k) * gC1[5], tj[2] + R(k) * gC1[8]};
                             const R w = wij * st.w[k][2];
                             if (in) {
@@ -1035,8 +1195,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const R g = gx1[d] + D.inv_dx * gfx[d];
-            if (ACC_X) Af[(size_t)(CX + d) * D.Npad + p] += g;
-            else Af[(size_t)(CX + d) * D.Npad + p] = g;
+            if (ACC_X) Af[rowoff(CX + d, p, D.Npad)] += g;
+            else Af[rowoff(CX + d, p, D.Npad)] = g;
         }
     }
     __syncthreads();
@@ -1083,7 +1243,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, h.block);
-        const double life = 1.0 / (double)(D.substeps - f % D.substeps);
+        const double life = 1.0 / (double)(D.substeps - (f - D.frame_shift) % D.substeps);
         const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])};
         const double pm64 = (double)D.p_mass;
         // this lane's stencil node (lanes 27..31 idle in the node-parallel parts)
@@ -1099,9 +1259,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         Vec4<R> vm = {R(0), R(0), R(0), R(0)}, G = {R(0), R(0), R(0), R(0)};
         R has = R(0);
         if (mask && d < 27) {
-            vm = gld(D.vmix, cell);
+            vm = gval(D, 1, cell);
             G = gld(D.aout, cell);
-            has = gld(D.vin, cell).x > R(1e-10) ? R(1) : R(0);
+            has = gval(D, 0, cell).x > R(1e-10) ? R(1) : R(0);
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2 forward
         R gd[3] = {-R(2) * wn * has * G.x, -R(2) * wn * has * G.y, -R(2) * wn * has * G.z};   // mixed4.grad: d/d(v_tmp - v_tgt)
@@ -1204,7 +1364,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                 R* Af = D.Af;
                 const double gp = d == 0 ? gpos[0] : (d == 1 ? gpos[1] : gpos[2]);
                 const R gf = d == 0 ? gfx[0] : (d == 1 ? gfx[1] : gfx[2]);
-                Af[(size_t)(CX + d) * D.Npad + p] += (R)(gp + (double)(D.inv_dx * gf));
+                Af[rowoff(CX + d, p, D.Npad)] += (R)(gp + (double)(D.inv_dx * gf));
             }
         }
         __syncthreads();
@@ -1245,12 +1405,12 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
         if (hi < nh) h = D.hits[hi];
         const int mask = h.mask, p = h.p;
         typename pos_of<R>::type xp[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
-        R x[3], v[3] = {R(0), R(0), R(0)};
+        R v[3] = {R(0), R(0), R(0)};
         if (mask) {
             load_pos(frame(D.S, f, D.Npad), D.Npad, p, xp);
             load_vec(frame(D.S, f, D.Npad), CV, 3, D.Npad, p, v);
         }
-        pos_to(xp, x);
+        const double x64[3] = {pos_get(xp[0]), pos_get(xp[1]), pos_get(xp[2])};
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, xp, st, nd, h.block);
@@ -1273,26 +1433,25 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
         for (int i = 0; i < D.P; ++i) {
             const bool act = (mask >> i) & 1;
             if (!__ballot(act)) continue;
-            R out = R(0);
-            if (act && d < 19) {
-                R ps[13];
-                prim_state_R(D, i, f, ps);
-                Dual<R> xs[3], vs[3], ss[13], im[3], es[6];
-                for (int c = 0; c < 3; ++c) { xs[c] = Dual<R>(x[c], d == c ? R(1) : R(0)); vs[c] = Dual<R>(v[c], d == 3 + c ? R(1) : R(0)); }
-                for (int c = 0; c < 13; ++c) ss[c] = Dual<R>(ps[c], d == 6 + c ? R(1) : R(0));
-                if (collide_particle(D.prim[i], ss, xs, vs, D.dt, im, es)) {
-                    for (int c = 0; c < 3; ++c) out += gi[c] * im[c].d;
-                    for (int c = 0; c < 6; ++c) out += (R)D.ext_f_grad[i * 6 + c] * es[c].d;
+            double out = 0.0;
+            if (act && d < 19) {                                   // f64 duals (see k_p2g: the impulse scales with a small penetration depth)
+                const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                Dual<double> xs[3], vs[3], ss[13], im[3], es[6];
+                for (int c = 0; c < 3; ++c) { xs[c] = Dual<double>(x64[c], d == c ? 1.0 : 0.0); vs[c] = Dual<double>((double)v[c], d == 3 + c ? 1.0 : 0.0); }
+                for (int c = 0; c < 13; ++c) ss[c] = Dual<double>(ps[c], d == 6 + c ? 1.0 : 0.0);
+                if (collide_particle(D.prim64[i], ss, xs, vs, D.dt64, im, es)) {
+                    for (int c = 0; c < 3; ++c) out += (double)gi[c] * im[c].d;
+                    for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * es[c].d;
                 }
             }
             if (act && d < 6) {
                 R* Af = D.Af;
-                Af[(size_t)((d < 3 ? CX : CV - 3) + d) * D.Npad + p] += out;
+                Af[rowoff((d < 3 ? CX : CV - 3) + d, p, D.Npad)] += (R)out;
             }
-            R sg = (act && d >= 6 && d < 19) ? out : R(0);
+            double sg = (act && d >= 6 && d < 19) ? out : 0.0;
             sg += __shfl_xor(sg, 32, 64);
-            if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != R(0))
-                __hip_atomic_fetch_add(pg_acc + i * 13 + (d - 6), (double)sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != 0.0)
+                __hip_atomic_fetch_add(pg_acc + i * 13 + (d - 6), sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             (void)lane0;
         }
     }
@@ -1308,17 +1467,23 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    const Vec4<R> in = D.vin[cell];
+    const Vec4<R> in = D.ck ? D.ck[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 192 + l] : D.vin[cell];
+    const Vec4<R> go = D.aout[cell];
+    const Vec4<R> zero4 = {R(0), R(0), R(0), R(0)};
+    Vec4<R> gm_ = zero4;
+    if (D.collision_type == CONTACT_MIXED) gm_ = D.amix[cell];
+    if (D.ck) {          // last readers of grid_v_out.grad / grid_v_mixed.grad in this substep: hand them back zeroed to the next one
+        D.aout[cell] = zero4;                                                          // (there is no restore kernel to do it)
+        if (D.collision_type == CONTACT_MIXED) D.amix[cell] = zero4;
+    }
     const R m = in.x;
-    if (!(m > R(1e-10))) return;
+    if (!(m > R(1e-10))) {
+        if (D.ck) D.ain[cell] = zero4;                                                 // k_p2g_grad gathers every node of its tile
+        return;
+    }
     const R inv = R(1) / m;
     const R vin[3] = {in.y, in.z, in.w};
-    const Vec4<R> go = D.aout[cell];
-    R g[3] = {go.x, go.y, go.z};
-    if (D.collision_type == CONTACT_MIXED) {                                           // grid_v_out += grid_v_mixed
-        const Vec4<R> gm_ = D.amix[cell];
-        g[0] += gm_.x; g[1] += gm_.y; g[2] += gm_.z;
-    }
+    R g[3] = {go.x + gm_.x, go.y + gm_.y, go.z + gm_.z};                               // grid_v_out += grid_v_mixed
     R v[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) v[d] = inv * vin[d] + D.dt * D.g[d];
@@ -1381,13 +1546,14 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
 // 128 VGPRs together, and at 1 wave/SIMD the kernel is latency-bound.  The SVD factors (kept for the
 // constitutive adjoint) are parked in LDS across the gather loop, and the loop is fenced per x-plane so
 // that at most 9 nodes of loads are in flight: 4 waves/SIMD instead of 1.
-constexpr int STASH = 34;   // U9 V9 e3 ep3 Et9 Jm1 (+ C9 E9 in f32 mode; f64 reloads them to keep two workgroups per CU)
+constexpr int STASH = SMAC_GFN_STASH ? 43 : 34;   // U9 V9 e3 ep3 Et9 Jm1 (gFn9): parked in LDS across the gather loop
 template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SMAC_OCC_P2GG : 2; };   // waves/SIMD asked of the register allocator
-template <class R, bool ACC_VCF>
+template <class R, bool ACC_VCF, bool PCON>
 __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
     constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
     typedef typename const_t<R>::type CT;
     __shared__ CT stash[(STASH + (STASH_CE ? 18 : 0)) * BLOCK];
+    static_assert(!STASH_CE || !SMAC_GFN_STASH, "the C / E stash slots would collide with gFn's");
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     gather_tile_load(D, D.ain, ch.block, gt);
@@ -1399,7 +1565,10 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     // every global load of the kernel is issued here, in one batch (one memory round trip instead of four);
     // C, E and the SVD factors wait in LDS until the constitutive adjoint needs them
     typename pos_of<R>::type x[3];
-    R v[3], aff[9], gFn[9];
+    R v[3], aff[9];
+#if !SMAC_GFN_STASH
+    R gFn[9];
+#endif
     {
         R C[9], E[9];
         CT Et[9], En[9], stress[9];
@@ -1407,7 +1576,10 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         load_vec(Sf, CF, 9, D.Npad, p, E);
         load_pos(Sf, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
-        load_vec(An, CF, 9, D.Npad, p, gFn);
+#if SMAC_GFN_STASH
+        R gFn[9];
+#endif
+        load_vec(An, CF, 9, D.Npad, p, gFn);            // F.grad[f+1]: fetched with the rest (parked in LDS until the constitutive adjoint)
         ConstState<CT> cs;
         {
             CT Cc[9], Ec[9];
@@ -1429,6 +1601,10 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
 #pragma unroll
         for (int i = 0; i < 3; ++i) { stash[(18 + i) * BLOCK + t] = cs.e[i]; stash[(21 + i) * BLOCK + t] = cs.ep[i]; }
         stash[33 * BLOCK + t] = cs.Jm1;
+#if SMAC_GFN_STASH
+#pragma unroll
+        for (int i = 0; i < 9; ++i) stash[(34 + i) * BLOCK + t] = (CT)gFn[i];
+#endif
     }
     R imp[3] = {R(0), R(0), R(0)};
     int ci = -1;
@@ -1437,18 +1613,20 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         if (ci >= 0)
             for (int d = 0; d < 3; ++d) imp[d] = R(6e-4) * D.action[3 * ci + d] * D.dt;
     }
-    if (D.collision_type == CONTACT_PARTICLE && D.any_contact) {      // the contact impulse is part of the scattered momentum
+    // (PCON is a template parameter for k_p2g only.  Here the instantiation WITH the penalty chain compiled in gets the better
+    //  register allocation - 145 VGPRs instead of 168 + spills, 20 us at 1M particles - so every launch uses it and the test is dynamic.)
+    if (PCON && D.collision_type == CONTACT_PARTICLE && D.any_contact) {      // the contact impulse is part of the scattered momentum
         const int cm = D.pmask[p];
         if (cm) {
-            R xr[3];
-            pos_to(x, xr);
+            const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])}, v64[3] = {(double)v[0], (double)v[1], (double)v[2]};
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i) {
                 if (!((cm >> i) & 1)) continue;
-                R s13[13], im[3], ex[6];
-                prim_state_R(D, i, f, s13);
-                if (collide_particle(D.prim[i], s13, xr, v, D.dt, im, ex))
-                    for (int c = 0; c < 3; ++c) imp[c] += im[c];
+                const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                double s13[13], im[3], ex[6];
+                for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+                if (collide_particle(D.prim64[i], s13, x64, v64, D.dt64, im, ex))
+                    for (int c = 0; c < 3; ++c) imp[c] += (R)im[c];
             }
         }
     }
@@ -1520,18 +1698,24 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         gaff[3 * c + 1] = D.dx * (My[c] - st.fx[1] * M0[c]);
         gaff[3 * c + 2] = D.dx * (Mz[c] - st.fx[2] * M0[c]);
     }
+#if SMAC_GFX_FROM_A
+    gfx[0] -= a0[0] * M0[0] + a0[1] * M0[1] + a0[2] * M0[2];                             // dpos = (offset - fx) dx ; a_d = dx affine[:, d]
+    gfx[1] -= a1[0] * M0[0] + a1[1] * M0[1] + a1[2] * M0[2];
+    gfx[2] -= a2[0] * M0[0] + a2[1] * M0[1] + a2[2] * M0[2];
+#else
 #pragma unroll
     for (int d = 0; d < 3; ++d) gfx[d] -= D.dx * (aff[d] * M0[0] + aff[3 + d] * M0[1] + aff[6 + d] * M0[2]);   // dpos = (offset - fx) dx
+#endif
     wg.to_fx(st, gfx);
     // impulse adjoint = sum_nodes w gv = gvp  -> action.grad
     if (ci >= 0)
         for (int d = 0; d < 3; ++d) atomic_add(D.action_grad + 3 * ci + d, R(6e-4) * D.dt * gvp[d]);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        Af[(size_t)(CX + d) * D.Npad + p] += D.inv_dx * gfx[d];
+        Af[rowoff(CX + d, p, D.Npad)] += D.inv_dx * gfx[d];
         const R gvv = D.p_mass * gvp[d];
-        if (ACC_VCF) Af[(size_t)(CV + d) * D.Npad + p] += gvv;
-        else Af[(size_t)(CV + d) * D.Npad + p] = gvv;
+        if (ACC_VCF) Af[rowoff(CV + d, p, D.Npad)] += gvv;
+        else Af[rowoff(CV + d, p, D.Npad)] = gvv;
     }
     // constitutive adjoint
     R gEt[9];
@@ -1549,7 +1733,11 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         cs.Jm1 = stash[33 * BLOCK + t];
         cs.has_svd = true;
 #pragma unroll
+#if SMAC_GFN_STASH
+        for (int i = 0; i < 9; ++i) { G[i] = (CT)(D.stress_scale * gaff[i]); gFc[i] = stash[(34 + i) * BLOCK + t]; }
+#else
         for (int i = 0; i < 9; ++i) { G[i] = (CT)(D.stress_scale * gaff[i]); gFc[i] = (CT)gFn[i]; }
+#endif
         const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam};
         constitutive_bwd(mat, Et, cs, G, gFc, gEc);
 #pragma unroll
@@ -1574,11 +1762,11 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     for (int i = 0; i < 9; ++i) {
         const R gc = D.dt * gC[i] + D.p_mass * gaff[i];
         if (ACC_VCF) {
-            Af[(size_t)(CC + i) * D.Npad + p] += gc;
-            Af[(size_t)(CF + i) * D.Npad + p] += gE[i];
+            Af[rowoff(CC + i, p, D.Npad)] += gc;
+            Af[rowoff(CF + i, p, D.Npad)] += gE[i];
         } else {
-            Af[(size_t)(CC + i) * D.Npad + p] = gc;
-            Af[(size_t)(CF + i) * D.Npad + p] = gE[i];
+            Af[rowoff(CC + i, p, D.Npad)] = gc;
+            Af[rowoff(CF + i, p, D.Npad)] = gE[i];
         }
     }
 }
@@ -1623,7 +1811,8 @@ __global__ void k_grid_m_only(const R* x0, const R* x1, const R* x2, int N, int 
     const int p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= N) return;
     typedef typename pos_of<R>::type PX;
-    const PX x[3] = {((const PX*)x0)[p], ((const PX*)x1)[p], ((const PX*)x2)[p]};
+    const size_t po = poff(p);
+    const PX x[3] = {((const PX*)x0)[po], ((const PX*)x1)[po], ((const PX*)x2)[po]};
     Stencil<R> st;
     make_stencil_pos(x, n, st);
     (void)inv_dx;

@@ -20,7 +20,7 @@ namespace smac {
 
 // position rows of a frame (pos_of<R>: doubles, or 32-bit fixed point in f32 mode)
 template <class R> __device__ __forceinline__ double rd_pos(const R* row, int p) {
-    return pos_get(((const typename pos_of<R>::type*)row)[p]);
+    return pos_get(((const typename pos_of<R>::type*)row)[poff(p)]);         // `row` = frame + rowbase(c): see smac_math.hpp "Frame layout"
 }
 
 struct PointIndex {
@@ -145,9 +145,9 @@ __global__ void k_chamfer_cur_to_target(int N, const R* x0, const R* x1, const R
         if (b.slot >= 0) {
             d2 = b.d2;
             if (add_grad) {
-                g0[p] += (R)(2.0 * weight * (q[0] - b.p[0]));
-                g1[p] += (R)(2.0 * weight * (q[1] - b.p[1]));
-                g2[p] += (R)(2.0 * weight * (q[2] - b.p[2]));
+                g0[poff(p)] += (R)(2.0 * weight * (q[0] - b.p[0]));
+                g1[poff(p)] += (R)(2.0 * weight * (q[1] - b.p[1]));
+                g2[poff(p)] += (R)(2.0 * weight * (q[2] - b.p[2]));
             }
         }
     }
@@ -167,9 +167,9 @@ __global__ void k_chamfer_target_to_cur(int M, const double* target, PointIndex 
         if (b.slot >= 0) {
             d2 = b.d2;
             if (add_grad) {
-                atomicAdd(g0 + b.slot, (R)(2.0 * weight * (b.p[0] - q[0])));
-                atomicAdd(g1 + b.slot, (R)(2.0 * weight * (b.p[1] - q[1])));
-                atomicAdd(g2 + b.slot, (R)(2.0 * weight * (b.p[2] - q[2])));
+                atomicAdd(g0 + poff(b.slot), (R)(2.0 * weight * (b.p[0] - q[0])));
+                atomicAdd(g1 + poff(b.slot), (R)(2.0 * weight * (b.p[1] - q[1])));
+                atomicAdd(g2 + poff(b.slot), (R)(2.0 * weight * (b.p[2] - q[2])));
             }
         }
     }
@@ -215,7 +215,7 @@ __global__ void k_min_dist_finish(const R* x0, const R* x1, const R* x2, const u
     if (v > 0.0) {                                   // d(weight v^2)/dx = 2 weight v * 2 (x - c);  -that for the centre
         const double k = 4.0 * weight * v;
         out[1] = -k * dx; out[2] = -k * dy; out[3] = -k * dz;
-        if (add_grad) { g0[p] += (R)(k * dx); g1[p] += (R)(k * dy); g2[p] += (R)(k * dz); }
+        if (add_grad) { g0[poff(p)] += (R)(k * dx); g1[poff(p)] += (R)(k * dy); g2[poff(p)] += (R)(k * dz); }
     }
 }
 

@@ -23,15 +23,16 @@
 #define SMAC_HD inline
 #endif
 
-// The SVD, the constitutive update and its adjoint are compiled with PRECISE floating-point semantics even though the
-// library is built with -ffast-math: for the few particles inside the reference's backward_svd clamp the adjoint is
-// ill-conditioned (K up to 1e6 on a singular-value difference), and there fast-math's reassociation / approximate
-// division cost a factor 4 in accuracy (4.5e-5 -> 9e-6 on the grip fixture, tools/prec_probe.py) for 3 % of the time.
-#if defined(__clang__)
-#define SMAC_PRECISE_FP _Pragma("float_control(precise, on)")
+// SMAC_PRECISE=1: the SVD, the constitutive update and its adjoint keep their operation order and exact reciprocals inside the
+// -ffast-math build (`#pragma clang fp`; `#pragma float_control` is not supported on amdgcn).  Measured (tools/prec_probe.py):
+// it only matters for particles inside the reference's backward_svd clamp, whose gradient is ill-conditioned in any case
+// (DESIGN 3), and costs 11 % more instructions in k_p2g_grad - off by default.
+#if defined(__clang__) && defined(SMAC_PRECISE) && SMAC_PRECISE
+#define SMAC_PRECISE_FP _Pragma("clang fp reassociate(off) reciprocal(off)")
 #else
 #define SMAC_PRECISE_FP
 #endif
+
 namespace smac {
 
 enum : int { MODEL_COROTATED = 0, MODEL_NEOHOOKEAN = 1 };
@@ -413,6 +414,24 @@ template <class R> SMAC_HD void make_stencil(const R* x, R inv_dx, Stencil<R>& s
 // forecast push-out (sdf / dt) n (primitive_base.py:170) divides a position error of 1e-10, not 3e-8, by dt.
 // The reference keeps particles inside [3 dx, 1 - 3 dx] (boundary_condition :268-281); anything outside [0, 1) saturates.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Frame layout.  A frame holds NCOMP_ROWS components per particle.  SMAC_TILE_P = 0: SoA rows, S[c][p] (rows Npad apart).
+// SMAC_TILE_P = T (a power of two): AoSoA tiles of T particles, S[p / T][c][p % T] - the 15 output streams of k_g2p then
+// stay within a few DRAM pages (tools/microbench/frame_layout.hip: the 3-read / 15-write pattern streams at 2.1 TB/s from SoA
+// rows and 3.4 TB/s from 1024-particle tiles; read-heavy patterns are unchanged or better).
+//     element (c, p) of a frame = frame[rowbase(c, Npad) + poff(p)]
+// ------------------------------------------------------------------------------------------
+#ifndef SMAC_TILE_P
+#define SMAC_TILE_P 0
+#endif
+constexpr int NCOMP_ROWS = 24;
+SMAC_HD size_t rowbase(int c, int Npad) { return SMAC_TILE_P ? (size_t)c * (size_t)SMAC_TILE_P : (size_t)c * (size_t)Npad; }
+SMAC_HD size_t poff(int p) {
+    constexpr int T = SMAC_TILE_P ? SMAC_TILE_P : 1;
+    return SMAC_TILE_P ? (size_t)(p / T) * (size_t)(NCOMP_ROWS * T) + (size_t)(p % T) : (size_t)p;
+}
+SMAC_HD size_t rowoff(int c, int p, int Npad) { return rowbase(c, Npad) + poff(p); }
+
 template <class R> struct pos_of { typedef R type; };
 template <> struct pos_of<float> { typedef uint32_t type; };
 SMAC_HD double pos_get(double x) { return x; }
@@ -422,12 +441,48 @@ SMAC_HD void pos_set(double v, uint32_t& o) {
     const double s = v * 4294967296.0 + 0.5;
     o = !(s > 0.0) ? 0u : (s >= 4294967295.0 ? 4294967295u : (uint32_t)s);          // NaN -> 0
 }
+// base = int(x n - 0.5) (truncation, :215) and fx = x n - base of a stored position
+SMAC_HD void pos_base_fx(double x, int n, int& b, double& fx) {
+    const double xs = x * (double)n;
+    b = (int)(xs - 0.5);
+    fx = xs - (double)b;
+}
+#ifndef SMAC_POS_INT
+#define SMAC_POS_INT 1
+#endif
+SMAC_HD void pos_base_fx(uint32_t x, int n, int& b, float& fx) {
+#if !SMAC_POS_INT
+    const double xs = pos_get(x) * (double)n;
+    b = (int)(xs - 0.5);
+    fx = (float)(xs - (double)b);
+    return;
+#endif
+    // fixed point: x n is a 64-bit integer with 32 fraction bits - exact, and no f64 instruction
+    const uint64_t prod = (uint64_t)x * (uint64_t)(uint32_t)n;
+    if (prod < 0x80000000ull) { b = 0; fx = (float)(uint32_t)prod * 2.3283064365386963e-10f; return; }    // x n < 0.5
+    const uint64_t q = prod - 0x80000000ull;
+    b = (int)(q >> 32);
+    fx = (float)(uint32_t)q * 2.3283064365386963e-10f + 0.5f;
+}
+SMAC_HD int pos_base(double x, int n) { return (int)(x * (double)n - 0.5); }
+SMAC_HD int pos_base(uint32_t x, int n) {
+    const uint64_t prod = (uint64_t)x * (uint64_t)(uint32_t)n;
+    return prod < 0x80000000ull ? 0 : (int)((prod - 0x80000000ull) >> 32);
+}
+// x + dt v of g2p (:318)
+SMAC_HD double pos_advance(double x, double dt, double v) { return x + dt * v; }
+SMAC_HD uint32_t pos_advance(uint32_t x, double dt, float v) {
+    // the increment in fixed-point units (|dt v| < 2^-8 of the box for any admissible step); saturating add
+    const float d = (float)(dt * 4294967296.0) * v;
+    const long long y = (long long)x + (long long)(d < 0.f ? d - 0.5f : d + 0.5f);
+    return y <= 0 ? 0u : (y >= 4294967295ll ? 4294967295u : (uint32_t)y);
+}
 // the stencil of mpm_simulator.py:215-217 from a stored position (n = n_grid = inv_dx)
 template <class R, class P> SMAC_HD void make_stencil_pos(const P* x, int n, Stencil<R>& s) {
     for (int d = 0; d < 3; ++d) {
-        const double xs = pos_get(x[d]) * (double)n;
-        const int b = (int)(xs - 0.5);                 // .cast(int): truncation
-        const R fx = (R)(xs - (double)b);
+        int b;
+        R fx;
+        pos_base_fx(x[d], n, b, fx);
         s.base[d] = b; s.fx[d] = fx;
         s.w[0][d] = R(0.5) * (R(1.5) - fx) * (R(1.5) - fx);
         s.w[1][d] = R(0.75) - (fx - R(1)) * (fx - R(1));

@@ -39,7 +39,8 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, 
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     float vm = 0.f;
     if (p < N) {
-        const float a = fabsf((float)v0[p]), b = fabsf((float)v1[p]), c = fabsf((float)v2[p]);
+        const size_t po = poff(p);
+        const float a = fabsf((float)v0[po]), b = fabsf((float)v1[po]), c = fabsf((float)v2[po]);
         vm = fmaxf(a, fmaxf(b, c));
     }
     for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o, 64));
@@ -54,11 +55,11 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, 
     }
     if (p >= N) return;
     typedef typename pos_of<R>::type PX;                 // position rows: smac_math.hpp pos_of
-    const PX x[3] = {((const PX*)x0)[p], ((const PX*)x1)[p], ((const PX*)x2)[p]};
+    const PX x[3] = {((const PX*)x0)[poff(p)], ((const PX*)x1)[poff(p)], ((const PX*)x2)[poff(p)]};
     (void)inv_dx;
     int b[3];
     for (int d = 0; d < 3; ++d) {
-        int v = (int)(pos_get(x[d]) * (double)n - 0.5);  // the base of make_stencil_pos
+        int v = pos_base(x[d], n);                       // the base of make_stencil_pos
         b[d] = v < 0 ? 0 : (v > n - 3 ? n - 3 : v);
     }
     const size_t cell = cell_of(nb, b[0], b[1], b[2]);
@@ -133,13 +134,13 @@ __global__ void k_rows_from_aos(int N, int Npad, const double* src, int stride, 
         for (int c = 0; c < cnt; ++c) {
             PX v;
             pos_set(q < N ? src[id * stride + offset + c] : 0.5, v);
-            ((PX*)rows)[(size_t)c * Npad + q] = v;
+            ((PX*)rows)[rowoff(c, q, Npad)] = v;
         }
         return;
     }
     for (int c = 0; c < cnt; ++c) {
         const double sub = (ident && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
-        rows[(size_t)c * Npad + q] = q < N ? (R)(src[id * stride + offset + c] - sub) : R(0);
+        rows[rowoff(c, q, Npad)] = q < N ? (R)(src[id * stride + offset + c] - sub) : R(0);
     }
 }
 template <class R>
@@ -147,7 +148,7 @@ __global__ void k_rows_add_aos(int N, int Npad, const double* src, int cnt, cons
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= N) return;
     const size_t id = (size_t)(orig ? orig[q] : q);
-    for (int c = 0; c < cnt; ++c) rows[(size_t)c * Npad + q] += (R)src[id * cnt + c];
+    for (int c = 0; c < cnt; ++c) rows[rowoff(c, q, Npad)] += (R)src[id * cnt + c];
 }
 template <class R>
 __global__ void k_rows_to_aos(int N, int Npad, const R* rows, int cnt, const int* orig, int ident, double* dst, int stride, int offset) {
@@ -156,12 +157,12 @@ __global__ void k_rows_to_aos(int N, int Npad, const R* rows, int cnt, const int
     const size_t id = (size_t)(orig ? orig[q] : q);
     if (ident == 2) {
         typedef typename pos_of<R>::type PX;
-        for (int c = 0; c < cnt; ++c) dst[id * stride + offset + c] = pos_get(((const PX*)rows)[(size_t)c * Npad + q]);
+        for (int c = 0; c < cnt; ++c) dst[id * stride + offset + c] = pos_get(((const PX*)rows)[rowoff(c, q, Npad)]);
         return;
     }
     for (int c = 0; c < cnt; ++c) {
         const double add = (ident && (c == 0 || c == 4 || c == 8)) ? 1.0 : 0.0;
-        dst[id * stride + offset + c] = (double)rows[(size_t)c * Npad + q] + add;
+        dst[id * stride + offset + c] = (double)rows[rowoff(c, q, Npad)] + add;
     }
 }
 
@@ -171,7 +172,8 @@ __global__ void k_sort_move(int N, const int* dest, const R* src, R* dst, int Np
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     const int q = dest[p];
-    for (int c = 0; c < ncomp; ++c) dst[(size_t)c * Npad + q] = src[(size_t)c * Npad + p];
+    const size_t pq = poff(q), pp = poff(p);
+    for (int c = 0; c < ncomp; ++c) dst[rowbase(c, Npad) + pq] = src[rowbase(c, Npad) + pp];
 }
 
 // gather form, used to bring an adjoint frame from one epoch's order into another's:
@@ -181,7 +183,8 @@ __global__ void k_gather_rows(int N, const int* map, const R* src, R* dst, int N
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= N) return;
     const int p = map[q];
-    for (int c = 0; c < ncomp; ++c) dst[(size_t)c * Npad + q] = src[(size_t)c * Npad + p];
+    const size_t pq = poff(q), pp = poff(p);
+    for (int c = 0; c < ncomp; ++c) dst[rowbase(c, Npad) + pq] = src[rowbase(c, Npad) + pp];
 }
 
 // inverse[orig[q]] = q

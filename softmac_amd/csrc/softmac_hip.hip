@@ -58,6 +58,7 @@ struct ISim {
     virtual int clear_grads() = 0;
     virtual int set_control_idx(const int32_t* idx) = 0;
     virtual int set_action_v(const double* action) = 0;
+    virtual int set_segment(int n_live, int frame_shift) = 0;
     virtual int compute_grid_m(int f, double* out) = 0;
     virtual int substep(int f, const double* action) = 0;
     virtual int substep_grad(int f, const double* action, const double* ext_f_grad, double* action_grad_out) = 0;
@@ -125,6 +126,7 @@ template <class R> struct Sim final : ISim {
         int* block_chunk_start = nullptr;
         int* block_chunks = nullptr;
         int* block_active = nullptr;
+        int* block_slot = nullptr;    // dense per block: slot in the active list (exclusive scan of the active flags)
         int frame = 0;              // frame at which the sort happened
         int interval = 1;           // substeps this binning is used for (<= sort_interval, shortened for fast particles)
         bool live = false;
@@ -165,7 +167,16 @@ template <class R> struct Sim final : ISim {
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
     bool vin_clean = false;          // {m,p} of every active block is zero (saves the clear pass before P2G)
+    bool adj_grid_clean = true;      // grid_v_out.grad / grid_v_mixed.grad of every active block are zero (direct-checkpoint backward)
+    // grid checkpoint traffic.  0 (default): copy kernels both ways (k_grid_save / k_grid_restore, 10 us each at 1M particles).
+    // 1: k_grid_op / k_contact_hits write the checkpoint and the backward kernels read it in place (gval / gather_tile_load_fwd);
+    // 2: written in place by the forward pass, restored by k_grid_restore.  Measured (tools/r02_h.sh, r02_i.sh: 3 interleaved runs,
+    // per-kernel minima): mode 1 costs k_g2p_grad a dependent slot lookup per tile record (+13 us) and the contact kernels +3 us
+    // each - 369 vs 364 us per substep pair; mode 2 equals mode 0 (363 vs 364).  Kept selectable, not a win.
+    int ck_mode = getenv("SMAC_CK_MODE") ? atoi(getenv("SMAC_CK_MODE")) : 0;
+    int g2p_pipe = getenv("SMAC_G2P_PIPE") ? atoi(getenv("SMAC_G2P_PIPE")) : 0;   // > 0: persistent pipelined k_g2p, this many workgroups per XCD
     std::vector<int> ck_epoch;       // epoch the slot of frame f was saved in (-1: invalid)
+    std::vector<char> ck_has_hits;   // the frame's contact hit list is on file too
     std::vector<long long> ck_gen;   // configuration generation at save time
     long long config_gen = 0;        // bumped whenever something the forward grid depends on may have changed
 
@@ -217,6 +228,7 @@ template <class R> struct Sim final : ISim {
             const int skew = sk ? atoi(sk) : 4160;
             if (D.Npad >= 65536) D.Npad += (skew / 64) * 64;
         }
+        if (SMAC_TILE_P) D.Npad = (c.n_particles + SMAC_TILE_P - 1) / SMAC_TILE_P * SMAC_TILE_P;       // AoSoA tiles (smac_math.hpp "Frame layout")
         D.n = c.n_grid;
         D.G = (size_t)c.n_grid * c.n_grid * c.n_grid;
         D.P = c.n_primitives;
@@ -314,6 +326,7 @@ template <class R> struct Sim final : ISim {
         adj_epoch.assign(c.max_frames, -1);
         adj_stale.assign(c.max_frames, 0);
         ck_epoch.assign(c.max_frames, -1);
+        ck_has_hits.assign(c.max_frames, 0);
         ck_gen.assign(c.max_frames, -1);
         ck_enabled = c.grad_enabled && !(getenv("SMAC_NO_CHECKPOINT") && atoi(getenv("SMAC_NO_CHECKPOINT")));
         if (c.flags & 1) ck_enabled = false;                    // bit 0 of flags: recompute in substep_grad like the reference
@@ -384,7 +397,7 @@ template <class R> struct Sim final : ISim {
         int rc;
         if ((rc = io_buffer((size_t)D.N * cnt))) return rc;
         HIP_TRY(hipMemcpyAsync(d_io, src, (size_t)D.N * cnt * sizeof(double), hipMemcpyHostToDevice, stream));
-        R* d = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
+        R* d = base + (size_t)f * frame_scalars() + rowbase(c0, D.Npad);
         hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cnt, 0, cnt,
                            e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, kind, d);
         HIP_TRY(hipStreamSynchronize(stream));
@@ -393,7 +406,7 @@ template <class R> struct Sim final : ISim {
     int download_comp(const R* base, int f, int c0, int cnt, double* dst, int kind, int e) {
         int rc;
         if ((rc = io_buffer((size_t)D.N * cnt))) return rc;
-        const R* s = base + (size_t)f * frame_scalars() + (size_t)c0 * D.Npad;
+        const R* s = base + (size_t)f * frame_scalars() + rowbase(c0, D.Npad);
         hipLaunchKernelGGL(k_rows_to_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, s, cnt,
                            e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, kind, d_io, cnt, 0);
         HIP_TRY(hipMemcpyAsync(dst, d_io, (size_t)D.N * cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -409,6 +422,7 @@ template <class R> struct Sim final : ISim {
         int rc = check_frame(f);
         if (rc) return rc;
         if (frame_epoch[f] < 0) frame_epoch[f] = 0;          // first write: identity order
+        if (x && v && F && C) frame_epoch[f] = 0;            // a full overwrite needs no old order (and the particle SET may be new: migration)
         ck_epoch[f] = -1;                                    // the saved forward grid of this frame is stale
         const int e = frame_epoch[f];
         if (x && (rc = upload_comp(D.S, f, CX, 3, x, 2, e))) return rc;
@@ -426,7 +440,7 @@ template <class R> struct Sim final : ISim {
         const R* fr = D.S + (size_t)f * frame_scalars();
         const int* orig = e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr;
         auto rows = [&](int c0, int cnt, int offset, int ident) {
-            hipLaunchKernelGGL(k_rows_to_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, fr + (size_t)c0 * D.Npad, cnt, orig, ident,
+            hipLaunchKernelGGL(k_rows_to_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, fr + rowbase(c0, D.Npad), cnt, orig, ident,
                                d_io, 24, offset);
         };
         rows(CX, 3, 0, 2); rows(CV, 3, 3, 0); rows(CF, 9, 6, 1); rows(CC, 9, 15, 0);
@@ -455,15 +469,14 @@ template <class R> struct Sim final : ISim {
         R* fr = D.S;
         auto rows = [&](int c0, int cnt, int offset, int ident) {
             hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cols, offset,
-                               cnt, (const int*)nullptr, ident, fr + (size_t)c0 * D.Npad);
+                               cnt, (const int*)nullptr, ident, fr + rowbase(c0, D.Npad));
         };
+        if (cols != 24) HIP_TRY(hipMemsetAsync(fr, 0, frame_scalars() * sizeof(R), stream));   // v = 0, C = 0, F = I (stored as E = 0)
         rows(CX, 3, 0, 2);
         if (cols == 24) {
             rows(CV, 3, 3, 0);
             rows(CF, 9, 6, 1);
             rows(CC, 9, 15, 0);
-        } else {                                                              // v = 0, C = 0, F = I (stored as E = 0)
-            HIP_TRY(hipMemsetAsync(fr + (size_t)CV * D.Npad, 0, (size_t)(NCOMP - CV) * D.Npad * sizeof(R), stream));
         }
         HIP_TRY(hipStreamSynchronize(stream));
         return check_launch();
@@ -565,7 +578,7 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMemcpyAsync(d_io, src[a], (size_t)D.N * cnt[a] * sizeof(double), hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL(k_rows_add_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, (const double*)d_io, cnt[a],
                                e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr,
-                               adj_ptr(f) + (size_t)c0[a] * D.Npad);
+                               adj_ptr(f) + rowbase(c0[a], D.Npad));
             HIP_TRY(hipStreamSynchronize(stream));                            // d_io is reused by the next component
         }
         return SMAC_OK;
@@ -598,7 +611,7 @@ template <class R> struct Sim final : ISim {
         if (!dense_tmp) HIP_TRY(hipMalloc((void**)&dense_tmp, D.G * sizeof(R)));
         HIP_TRY(hipMemsetAsync(dense_tmp, 0, D.G * sizeof(R), stream));
         const R* Sf = D.S + (size_t)f * frame_scalars();
-        hipLaunchKernelGGL(k_grid_m_only<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad, D.N,
+        hipLaunchKernelGGL(k_grid_m_only<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, Sf, Sf + rowbase(1, D.Npad), Sf + rowbase(2, D.Npad), D.N,
                            D.n, D.inv_dx, D.p_mass, dense_tmp);
         return check_launch();
     }
@@ -669,14 +682,14 @@ template <class R> struct Sim final : ISim {
         REQUIRE(frame_epoch[f] >= 0, "loss_chamfer: frame holds no state");
         const int e = frame_epoch[f];
         const R* Sf = D.S + (size_t)f * frame_scalars();
-        if ((rc = pi_build(pi_cur, D.N, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad, nullptr, e > 0 ? (const int*)epochs[e].orig : nullptr))) return rc;
+        if ((rc = pi_build(pi_cur, D.N, Sf, Sf + rowbase(1, D.Npad), Sf + rowbase(2, D.Npad), nullptr, e > 0 ? (const int*)epochs[e].orig : nullptr))) return rc;
         R* Af = nullptr;
         if (add_grad && (rc = adjoint_frame_for_seeding(f, &Af))) return rc;
         if (!d_loss) HIP_TRY(hipMalloc((void**)&d_loss, sizeof(double)));
         HIP_TRY(hipMemsetAsync(d_loss, 0, sizeof(double), stream));
-        R* g0 = Af; R* g1 = Af ? Af + D.Npad : nullptr; R* g2 = Af ? Af + 2 * (size_t)D.Npad : nullptr;
-        hipLaunchKernelGGL(k_chamfer_cur_to_target<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, Sf, Sf + D.Npad,
-                           Sf + 2 * (size_t)D.Npad, pi_view(pi_target), weight, add_grad ? 1 : 0, g0, g1, g2, d_loss);
+        R* g0 = Af; R* g1 = Af ? Af + rowbase(1, D.Npad) : nullptr; R* g2 = Af ? Af + rowbase(2, D.Npad) : nullptr;
+        hipLaunchKernelGGL(k_chamfer_cur_to_target<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, Sf, Sf + rowbase(1, D.Npad),
+                           Sf + rowbase(2, D.Npad), pi_view(pi_target), weight, add_grad ? 1 : 0, g0, g1, g2, d_loss);
         hipLaunchKernelGGL(k_chamfer_target_to_cur<R>, dim3(nblk(n_target)), dim3(BLOCK), 0, stream, n_target, (const double*)d_target,
                            pi_view(pi_cur), weight, add_grad ? 1 : 0, g0, g1, g2, d_loss);
         double h = 0;
@@ -719,11 +732,11 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMalloc((void**)&d_md_out, 4 * sizeof(double)));
         }
         HIP_TRY(hipMemsetAsync(d_best, 0xff, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(k_min_dist<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad,
+        hipLaunchKernelGGL(k_min_dist<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, Sf, Sf + rowbase(1, D.Npad), Sf + rowbase(2, D.Npad),
                            e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, id0, id1, c3[0], c3[1], c3[2], offset, d_best);
-        hipLaunchKernelGGL(k_min_dist_finish<R>, dim3(1), dim3(64), 0, stream, Sf, Sf + D.Npad, Sf + 2 * (size_t)D.Npad,
+        hipLaunchKernelGGL(k_min_dist_finish<R>, dim3(1), dim3(64), 0, stream, Sf, Sf + rowbase(1, D.Npad), Sf + rowbase(2, D.Npad),
                            (const unsigned long long*)d_best, c3[0], c3[1], c3[2], offset, weight, add_grad ? 1 : 0, Af,
-                           Af ? Af + D.Npad : (R*)nullptr, Af ? Af + 2 * (size_t)D.Npad : (R*)nullptr, d_md_out);
+                           Af ? Af + rowbase(1, D.Npad) : (R*)nullptr, Af ? Af + rowbase(2, D.Npad) : (R*)nullptr, d_md_out);
         HIP_TRY(hipMemcpyAsync(out4, d_md_out, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return check_launch();
@@ -754,7 +767,8 @@ template <class R> struct Sim final : ISim {
     // ---- epochs / sorting ------------------------------------------------------------------
     static void free_epoch(Epoch& e) {
         hipFree(e.orig); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
-        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = nullptr;
+        hipFree(e.block_slot);
+        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
         e.chunks = nullptr;
         e.live = false;
     }
@@ -763,19 +777,21 @@ template <class R> struct Sim final : ISim {
         Epoch b;
         b.orig = e.orig; b.inv = e.inv; b.chunks = e.chunks; b.active = e.active;
         b.block_chunk_start = e.block_chunk_start; b.block_chunks = e.block_chunks; b.block_active = e.block_active;
+        b.block_slot = e.block_slot;
         epoch_pool.push_back(std::move(b));
-        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = nullptr;
+        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
         e.chunks = nullptr;
         e.inv_valid = false;
         e.live = false;
     }
-    size_t chunk_capacity() const { return (size_t)D.N / 256 + (size_t)(nblocks < D.N ? nblocks : D.N) + 8; }
+    size_t chunk_capacity() const { const int n = cfg.n_particles; return (size_t)n / 256 + (size_t)(nblocks < n ? nblocks : n) + 8; }
     int epoch_buffers(Epoch& ep) {
         if (!epoch_pool.empty()) {
             Epoch b = std::move(epoch_pool.back());
             epoch_pool.pop_back();
             ep.orig = b.orig; ep.inv = b.inv; ep.chunks = b.chunks; ep.active = b.active;
             ep.block_chunk_start = b.block_chunk_start; ep.block_chunks = b.block_chunks; ep.block_active = b.block_active;
+            ep.block_slot = b.block_slot;
             ep.inv_valid = false;
             return SMAC_OK;
         }
@@ -785,6 +801,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&ep.block_chunk_start, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.block_chunks, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.block_active, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.block_slot, (nblocks + 1) * sizeof(int)));
         return SMAC_OK;
     }
     void gc_epochs() {                                   // drop epochs no frame refers to any more
@@ -823,9 +840,9 @@ template <class R> struct Sim final : ISim {
         R* Sf = D.S + (size_t)f * frame_scalars();
         HIP_TRY(hipMemsetAsync(d_cell_count, 0, D.G * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_bin + nbins, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + D.Npad),
-                           (const R*)(Sf + 2 * (size_t)D.Npad), (const R*)(Sf + 3 * (size_t)D.Npad), (const R*)(Sf + 4 * (size_t)D.Npad),
-                           (const R*)(Sf + 5 * (size_t)D.Npad), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax_part);
+        hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + rowbase(1, D.Npad)),
+                           (const R*)(Sf + rowbase(2, D.Npad)), (const R*)(Sf + rowbase(3, D.Npad)), (const R*)(Sf + rowbase(4, D.Npad)),
+                           (const R*)(Sf + rowbase(5, D.Npad)), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax_part);
         hipLaunchKernelGGL(k_bin_masks, dim3((nblocks + 3) / 4), dim3(BLOCK), 0, stream, nblocks, (const int*)d_cell_count, d_bin,
                            d_bin_mask, d_over_prefix, (const float*)d_vmax_part, nblk(D.N), (float*)d_vmax);
         int rc = scan(d_bin, d_bin_start, nbins + 1);
@@ -879,6 +896,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemcpyAsync(ep.block_chunk_start, d_chunk_start, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipMemcpyAsync(ep.block_chunks, d_block_chunks, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipMemcpyAsync(ep.block_active, d_active_flag, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(ep.block_slot, d_active_start, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         prof_end();
         ep.frame = f;
         ep.live = true;
@@ -905,12 +923,13 @@ template <class R> struct Sim final : ISim {
             Do.nactive = epochs[grid_epoch].nactive;
             hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 6);
         }
-        if (e != grid_epoch) vin_clean = false;
+        if (e != grid_epoch) { vin_clean = false; adj_grid_clean = true; }   // (the old epoch's blocks were zeroed just above; the rest always is)
         grid_epoch = e;
         const Epoch& ep = epochs[e];
         D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
         D.orig_id = ep.orig; D.block_chunk_start = ep.block_chunk_start; D.block_chunks = ep.block_chunks;
         D.block_active = ep.block_active;
+        D.block_slot = ep.block_slot;
         D.slab = slab;
         D.cand = d_cand;
         return check_launch();
@@ -967,6 +986,13 @@ template <class R> struct Sim final : ISim {
             if (D.prim[i].contact) return true;
         return false;
     }
+    int set_segment(int n_live, int frame_shift) override {
+        REQUIRE(n_live >= 1 && n_live <= cfg.n_particles, "set_segment: n_live must be in [1, n_particles (the handle's capacity)]");
+        REQUIRE(frame_shift >= 0, "set_segment: negative frame_shift");
+        D.N = n_live;
+        D.frame_shift = frame_shift;
+        return SMAC_OK;
+    }
     int set_action_v(const double* action) override {
         REQUIRE(action, "null action");
         return set_action(action);
@@ -1019,8 +1045,14 @@ template <class R> struct Sim final : ISim {
             }
             vin_clean = false;
             prof_begin(K_P2G);
-            if (store_F) hipLaunchKernelGGL((k_p2g<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
-            else hipLaunchKernelGGL((k_p2g<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+            const bool pcon = D.collision_type == CONTACT_PARTICLE && D.any_contact;
+            if (pcon) {
+                if (store_F) hipLaunchKernelGGL((k_p2g<R, true, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+                else hipLaunchKernelGGL((k_p2g<R, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+            } else {
+                if (store_F) hipLaunchKernelGGL((k_p2g<R, true, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+                else hipLaunchKernelGGL((k_p2g<R, false, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+            }
             prof_end();
             if (!is_recompute && cfg.rigid_velocity_control) {                    // :329-331
                 for (int i = 0; i < D.P; ++i)
@@ -1087,14 +1119,33 @@ template <class R> struct Sim final : ISim {
             }
             if ((rc = bind_epoch(e))) return rc;
             ck_epoch[f] = -1;
-            if ((rc = forward_grid(f, true, false, phase < 0 ? 0 : 1))) return rc;
+            // whole substep on one GPU: k_grid_op / k_contact_hits file the forward grid in the frame's checkpoint slot themselves
+            // (the slab decomposition exchanges halo planes of the dense arrays in between and keeps the copy kernel)
+            const bool direct = ck_mode != 0 && phase < 0 && D.nchunks > 0 && D.n_control == 0 && ck_prepare();
+            if (direct) {
+                const bool keep_hits = ck_hits && any_contact() && D.collision_type == CONTACT_MIXED;
+                D.ck = ck_slot(f);
+                D.hit_ck = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
+                D.nhit_ck = keep_hits ? ck_nhits + f : (int*)nullptr;
+                D.hit_cap = ck_hit_cap;
+            }
+            rc = forward_grid(f, true, false, phase < 0 ? 0 : 1);
+            D.ck = nullptr; D.hit_ck = nullptr; D.nhit_ck = nullptr;
+            if (rc) return rc;
+            if (direct) {
+                ck_epoch[f] = e;
+                ck_gen[f] = config_gen;
+                ck_has_hits[f] = (ck_hits && any_contact() && D.collision_type == CONTACT_MIXED) ? 1 : 0;
+                vin_clean = true;
+            }
         }
         if (phase == 1 && (rc = forward_grid(f, true, false, 2))) return rc;
         if (phase < 0 || phase == 2) {
             const int e = frame_epoch[f];
-            if (D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {              // keep the forward grid for substep_grad
+            if (ck_epoch[f] != e && D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {   // (slab phases) keep the forward grid for substep_grad
                 prof_begin(K_CKPT);
                 const bool keep_hits = ck_hits && any_contact();
+                ck_has_hits[f] = keep_hits ? 1 : 0;
                 hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f),
                                    keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr, ck_hit_cap);
                 prof_end();
@@ -1105,7 +1156,11 @@ template <class R> struct Sim final : ISim {
             if (D.nchunks > 0) {
                 prof_begin(K_G2P);
                 D.check_next = (f + 1 - epochs[e].frame < epochs[e].interval) ? 1 : 0;     // else substep(f+1) re-bins first
-                hipLaunchKernelGGL(k_g2p<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                if (g2p_pipe) {
+                    const int per = (D.nchunks + 7) / 8, J = per < g2p_pipe ? per : g2p_pipe;
+                    hipLaunchKernelGGL(k_g2p_pipe<R>, dim3(8 * J), dim3(BLOCK), 0, stream, D, f);
+                } else
+                    hipLaunchKernelGGL(k_g2p<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
             }
             frame_epoch[f + 1] = e;
@@ -1118,6 +1173,7 @@ template <class R> struct Sim final : ISim {
     // 1: contact adjoint; 2: grid_op.grad, kinematics adjoint, p2g.grad.  Halo sums of grid_v_out.grad follow phase 0,
     // of grid_v_mixed.grad phase 1.
     bool pending_adj_zero = false;
+    bool direct_bwd = false;
     int substep_grad_phase(int f, const double* action, const double* ext_f_grad, double* action_grad_out, int phase) {
         int rc;
         if ((rc = need_grad())) return rc;
@@ -1148,12 +1204,34 @@ template <class R> struct Sim final : ISim {
             adj_epoch[f] = e;
             adj_stale[f] = 0;                                                     // write mode overwrites every row
             D.An = An;
-            if (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0) {
+            const bool ck_ok = ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0;
+            if (ck_ok && ck_mode == 1 && phase < 0) {
+                // forward grid of this frame is on file and the kernels read it THERE (gval / gather_tile_load_fwd): no restore
+                // kernel.  The grid adjoints start from zero because k_grid_op_grad hands them back zeroed.
+                D.any_contact = any_contact() ? 1 : 0;
+                D.cur_frame = f;
+                if (!adj_grid_clean) {
+                    prof_begin(K_CLEAR);
+                    hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block + 3 * D.G, 3);
+                    prof_end();
+                }
+                D.ck = ck_slot(f);
+                const bool have_hits = ck_has_hits[f] && D.any_contact && D.collision_type == CONTACT_MIXED;
+                if (have_hits) {
+                    D.hits = ck_hits + (size_t)f * ck_hit_cap;                    // the contact adjoint walks the filed list in place
+                    D.nhits = ck_nhits + f;
+                } else if (D.any_contact && D.collision_type != CONTACT_GRID) {
+                    HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
+                    hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                }
+                direct_bwd = true;
+            } else if (ck_ok) {
                 // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing
                 D.any_contact = any_contact() ? 1 : 0;
                 D.cur_frame = f;
+                adj_grid_clean = false;
                 prof_begin(K_CKPT);
-                const bool have_hits = ck_hits && D.any_contact && D.collision_type == CONTACT_MIXED;
+                const bool have_hits = ck_has_hits[f] && D.any_contact && D.collision_type == CONTACT_MIXED;
                 vin_clean = false;
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f),
                                    have_hits ? (const Hit*)(ck_hits + (size_t)f * ck_hit_cap) : (const Hit*)nullptr,
@@ -1164,6 +1242,7 @@ template <class R> struct Sim final : ISim {
             } else {
                 REQUIRE(phase < 0, "slab-decomposed substep_grad needs the forward-grid checkpoint of this frame "
                                    "(recomputing it would need the forward halo exchanges again)");
+                adj_grid_clean = false;
                 if ((rc = forward_grid(f, false, true))) return rc;               // :347-359 (clears values + adjoints, recomputes)
             }
             if (D.nchunks > 0) {
@@ -1195,8 +1274,8 @@ template <class R> struct Sim final : ISim {
                     if ((rc = prim_fk_grad(i, f))) return rc;
             if (D.nchunks > 0) {
                 prof_begin(K_P2G_GRAD);
-                if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);   // :371-374
-                else hipLaunchKernelGGL((k_p2g_grad<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);   // :371-374
+                else hipLaunchKernelGGL((k_p2g_grad<R, true, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
                 if (D.collision_type == CONTACT_PARTICLE && any_contact()) {      // adjoint of p2g's contact impulse (:203-206)
                     prof_begin(K_CONTACT_GRAD);
@@ -1212,6 +1291,11 @@ template <class R> struct Sim final : ISim {
                 for (int i = 0; i < 3 * D.n_control; ++i) action_grad_out[i] = (double)tmp[i];
             }
             adj_release(f + 2);                    // rolling storage: the sweep has passed frame f+2 two substeps ago
+            if (direct_bwd) {
+                D.ck = nullptr; D.hits = d_hits; D.nhits = d_nhits;
+                direct_bwd = false;
+                adj_grid_clean = true;             // k_grid_op_grad zeroed what it read
+            }
         }
         return check_launch();
     }
@@ -1567,6 +1651,7 @@ int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, cons
 int smac_clear_grads(smac_handle h) { return FWD(clear_grads()); }
 int smac_set_control_idx(smac_handle h, const int32_t* idx) { return FWD(set_control_idx(idx)); }
 int smac_set_action(smac_handle h, const double* action) { return FWD(set_action_v(action)); }
+int smac_set_segment(smac_handle h, int n_live, int frame_shift) { return FWD(set_segment(n_live, frame_shift)); }
 int smac_compute_grid_m(smac_handle h, int f, double* grid_m) { return FWD(compute_grid_m(f, grid_m)); }
 int smac_substep(smac_handle h, int f, const double* action) { return FWD(substep(f, action)); }
 int smac_substep_grad(smac_handle h, int f, const double* action, const double* ext_f_grad, double* action_grad_out) {

@@ -57,6 +57,7 @@ class MPMSimulator:
 
         quality = cfg.quality * 0.5                         # :26-30
         n_particles = self.n_particles = int(cfg.n_particles)
+        self.capacity = n_particles                         # slab migration changes n_particles within this capacity (set_segment)
         n_grid = self.n_grid = int(128 * quality)
         if getattr(cfg, "n_grid", None):                    # extension: explicit grid size (128^3 / 256^3 runs)
             n_grid = self.n_grid = int(cfg.n_grid)
@@ -149,6 +150,12 @@ class MPMSimulator:
 
     def sync(self):
         self._h.call("smac_sync")
+
+    def set_segment(self, n_live, frame_shift=0):
+        """Slab migration (softmac_amd/parallel.py): from now on frames hold `n_live` <= capacity particles; `frame_shift` duplicate
+        frames precede the current segment (keeps the substep phase of the forecast contact on the physical substep)."""
+        self._h.call("smac_set_segment", int(n_live), int(frame_shift))
+        self.n_particles = int(n_live)
 
     # ------------------------------------------------------------------ hot path (:320-378)
     def substep(self, s, action=None):

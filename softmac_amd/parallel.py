@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -65,15 +66,40 @@ class HipSlabEngine:
     def halo_unpack_add(self, field, plane0, nplanes, buf):
         self.sim._h.call("smac_halo_unpack_add", field.encode(), int(plane0), int(nplanes), C.c_void_p(buf.data_ptr()))
 
+    # ---- migration (rows = x3 v3 F9 C9, the layout of get_state)
+    def set_segment(self, n_live, shift):
+        self.sim.set_segment(n_live, shift)
+
+    def get_state(self, f):
+        return self.sim.get_state(f)
+
+    def set_state(self, f, st):
+        n = len(st)
+        self.sim.set_state(f, (st[:, 0:3], st[:, 3:6], st[:, 6:15].reshape(n, 3, 3), st[:, 15:24].reshape(n, 3, 3)))
+
+    def get_grad_rows(self, f):
+        gx, gv, gF, gC = self.sim.get_grad_full(f)
+        n = len(gx)
+        return np.hstack([gx, gv, gF.reshape(n, 9), gC.reshape(n, 9)])
+
+    def add_grad_rows(self, f, g):
+        n = len(g)
+        self.sim.add_grad(f, gx=g[:, 0:3], gv=g[:, 3:6], gF=g[:, 6:15].reshape(n, 3, 3), gC=g[:, 15:24].reshape(n, 3, 3))
+
 
 class SlabRunner:
     """Drives one rank's engine and its halo exchanges.
 
     left_plane0 / right_plane0: first shared plane (in THIS rank's grid indexing) with the left / right
     neighbour; the neighbour indexes the same physical planes from its own right_plane0 / left_plane0.
-    """
 
-    def __init__(self, engine, rank, world, left_plane0, right_plane0, nplanes=2, has_contact=True, group=None):
+    Particle MIGRATION: `own=(lo, hi)` is the range of stencil bases this rank owns and `ids` the global ids of its
+    particles.  `migrate(f)` - called by the driver at a re-sort / env-step boundary, never inside a substep - hands the
+    particles whose base left [lo, hi) to the neighbour (neighbour-only variable-size send/recv) and starts a new SEGMENT at
+    handle frame f+1 with the new particle set; the tape keeps both orderings of the migration point (frames f and f+1), and
+    `migrate_grad()` carries the adjoint of frame f+1 back across the slab boundary in the backward sweep."""
+
+    def __init__(self, engine, rank, world, left_plane0, right_plane0, nplanes=2, has_contact=True, group=None, own=None, ids=None):
         self.e, self.rank, self.world = engine, rank, world
         self.left0, self.right0, self.np = int(left_plane0), int(right_plane0), int(nplanes)
         self.has_contact = bool(has_contact)
@@ -83,6 +109,10 @@ class SlabRunner:
         self._buf = {}
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.stage_on_host = backend == "gloo"       # gloo moves host memory: stage device buffers through the CPU
+        self.own = None if own is None else (int(own[0]), int(own[1]))
+        self.ids = None if ids is None else np.asarray(ids, dtype=np.int64).copy()
+        self.shift = 0                               # duplicate (migration) frames before the current segment
+        self.migrations = []
 
     def _buffers(self, side):
         if side not in self._buf:
@@ -138,6 +168,75 @@ class SlabRunner:
     def run_substeps_grad(self, f0, count, ext_f_grad=None):
         for f in range(f0 + count - 1, f0 - 1, -1):
             self.substep_grad(f, ext_f_grad)
+
+    # ---- migration ------------------------------------------------------------------------------------------
+    def _exchange_rows(self, to_left, to_right):
+        """variable-size neighbour exchange of (k, c) float64 rows: returns (rows from the left, rows from the right)"""
+        cols = to_left.shape[1]
+        dev = "cpu" if (self.stage_on_host or not dist.is_initialized()) else "cuda"
+        peers = [(self.left, to_left), (self.right, to_right)]
+        cnt_out = [torch.tensor([len(r)], dtype=torch.int64, device=dev) for _, r in peers]
+        cnt_in = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in peers]
+        ops = []
+        for (peer, _), co, ci in zip(peers, cnt_out, cnt_in):
+            if peer is not None:
+                ops += [dist.P2POp(dist.isend, co, peer, self.group), dist.P2POp(dist.irecv, ci, peer, self.group)]
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        bufs_in = [torch.empty((int(ci.item()), cols), dtype=torch.float64, device=dev) for ci in cnt_in]
+        ops, keep = [], []
+        for (peer, rows), bi in zip(peers, bufs_in):
+            if peer is None:
+                continue
+            if len(rows):
+                t = torch.as_tensor(np.ascontiguousarray(rows), dtype=torch.float64).to(dev)
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, peer, self.group))
+            if len(bi):
+                ops.append(dist.P2POp(dist.irecv, bi, peer, self.group))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        return bufs_in[0].cpu().numpy(), bufs_in[1].cpu().numpy()
+
+    def migrate(self, f):
+        """Hand over the particles of frame f whose stencil base (mpm_simulator.py:215) left this rank's range.  The next
+        segment starts at handle frame f + 1 (returned) and holds the kept particles followed by the arrivals."""
+        assert self.own is not None and self.ids is not None, "SlabRunner(own=..., ids=...) is needed for migration"
+        st = self.e.get_state(f)
+        base = np.floor(st[:, 0] * self.e.n - 0.5).astype(np.int64)
+        to_l = (base < self.own[0]) if self.left is not None else np.zeros(len(st), dtype=bool)
+        to_r = (base >= self.own[1]) if self.right is not None else np.zeros(len(st), dtype=bool)
+        keep = ~(to_l | to_r)
+        pack = lambda m: np.hstack([st[m], self.ids[m, None].astype(np.float64)])
+        from_l, from_r = self._exchange_rows(pack(to_l), pack(to_r))
+        new = np.vstack([st[keep], from_l[:, :24], from_r[:, :24]])
+        new_ids = np.concatenate([self.ids[keep], from_l[:, 24].astype(np.int64), from_r[:, 24].astype(np.int64)])
+        assert len(new) >= 1, "a slab lost all its particles"
+        self.migrations.append(dict(frame=f, n_old=len(st), keep=np.nonzero(keep)[0], sl=np.nonzero(to_l)[0], sr=np.nonzero(to_r)[0],
+                                    nl=len(from_l), nr=len(from_r), ids_old=self.ids))
+        self.shift += 1
+        self.e.set_segment(len(new), self.shift)
+        self.e.set_state(f + 1, new)
+        self.ids = new_ids
+        return f + 1
+
+    def migrate_grad(self):
+        """Backward of the most recent `migrate`: the adjoint of the later segment's first frame goes back to the frame it was
+        copied from - across the slab boundary for the particles that crossed it."""
+        rec = self.migrations.pop()
+        f = rec["frame"]
+        g = self.e.get_grad_rows(f + 1)
+        nk = len(rec["keep"])
+        back_l, back_r = self._exchange_rows(g[nk:nk + rec["nl"]], g[nk + rec["nl"]:])
+        old = np.zeros((rec["n_old"], 24))
+        old[rec["keep"]] = g[:nk]
+        old[rec["sl"]] = back_l
+        old[rec["sr"]] = back_r
+        self.shift -= 1
+        self.e.set_segment(rec["n_old"], self.shift)
+        self.e.add_grad_rows(f, old)
+        self.ids = rec["ids_old"]
+        return f
 
 
 class _DevArray:

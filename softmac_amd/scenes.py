@@ -174,3 +174,24 @@ def s_grip_strong(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, p
     cfg.slab_flags = (2 if rank > 0 else 0) | (4 if rank < world - 1 else 0)      # smac_config.flags bits 1,2: open x ends
     nplanes = 2 + 2 * drift_tol
     return cfg, env_dt, state[own], specs, s13, (max(lo - drift_tol, 0), min(hi - drift_tol, n_grid - nplanes), nplanes), own
+
+
+def s_pour(n_particles=1 << 22, n_grid=256, max_steps=16, precision="float32", device=0, seed=2, bowl_table=None):
+    """S-pour (BASELINE config C4): a column of liquid (ptype 2, E 22) at 8 particles per cell on a 256^3 grid just above /
+    inside a bowl SDF; dt = 2.5e-4 (the reference's 1e-3 at dx = 1/64 scaled by the CFL ratio).  `bowl_table`: the voxelised
+    bowl (dict with sdf, normal, position, dx, res as the voxeliser returns it); None -> no primitive."""
+    side_cells = (n_particles / 8) ** (1.0 / 3.0)
+    center = (0.5, 0.5, 0.5)
+    state, lo, side = block_cloud(n_particles, n_grid, center, ppc=8, seed=seed, v_std=0.05, C_std=0.5, F_std=0.0)
+    state[:, 6:15] = (np.eye(3) * 0.99).reshape(1, 9)                     # slightly compressed liquid, like the reference's pour fixture (F = 0.98 I)
+    state[:, 4] -= 0.5                                                    # falling
+    cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=2.5e-4, max_steps=max_steps, precision=precision, device=device,
+                        ptype=2, E=22.0, ground_friction=0.0)
+    specs, s13 = [], []
+    if bowl_table is not None:
+        t = bowl_table
+        specs = [dict(sdf=t["sdf"], normal=t["normal"], lower=np.asarray(t["position"][0]), upper=np.asarray(t["position"][1]),
+                      dx=float(np.asarray(t["dx"]).reshape(-1)[0]), res=np.asarray(t["res"]), friction=1.0, softness=666.0, contact=True)]
+        # bowl rim (0.067 above its origin) 2 mm inside the bottom of the column
+        s13 = [np.array([0.5, lo[1] - 0.0668 + 0.002, 0.5, 1.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0], dtype=np.float64)]
+    return cfg, 1e-3, state, specs, s13

@@ -73,7 +73,7 @@ F32_TOL = dict(state=1e-5, grad=1e-5, gx=1e-5, clamp=5e-3)
 def c_tol(tol_state, n_grid, v, C):
     """tolerance for the affine field C in float32 mode (see F32_TOL)"""
     vmax, cmax = float(np.abs(np.asarray(v)).max()), float(np.abs(np.asarray(C)).max())
-    return max(tol_state, 1.2e-7 * 4.0 * n_grid * vmax / max(cmax, 1e-300))
+    return max(tol_state, 2e-7 * 4.0 * n_grid * vmax / max(cmax, 1e-300))
 
 
 def clamp_zone(orc, P, nsteps, width=4e-6):

@@ -35,3 +35,24 @@ def seeds(sc):
     n = sc["nsteps"]
     return {n: (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), 0.01 * rng.standard_normal((N, 3, 3)),
                 0.01 * rng.standard_normal((N, 3, 3))), 1: (rng.standard_normal((N, 3)), None, None, None)}
+
+
+def build_moving(precision="float64", world=2):
+    """Migration scene: an elastic cloud flying in +x at 20 m/s (0.128 cells per substep at n_grid 32): within the 8-substep
+    window every slab boundary is crossed by particles, so ownership must change hands (SlabRunner.migrate every 4 substeps)."""
+    n_grid, N = 32, 2400
+    state = H.make_cloud(N, n_grid, seed=33, lo=(0.2, 0.3, 0.36), hi=(0.72, 0.5, 0.64), v_std=0.3, F_std=5e-3)
+    state[:, 3] += 20.0
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, material_model=0, ground_friction=0.0, precision=precision, max_steps=16,
+                    gravity=(0.0, -9.8, 0.0), sort_interval=4)
+    base = (state[:, 0] * n_grid - 0.5).astype(int)
+    from softmac_amd.scenes import balanced_slab_bounds
+    bounds = balanced_slab_bounds(base, world, n_grid, min_width=4)
+    return dict(cfg=cfg, env_dt=1e-3, state=state, nsteps=8, migrate_every=4, specs=[], pstates=None, ext_f_grad=None, n_grid=n_grid,
+                bounds=bounds, drift_tol=1)
+
+
+def owned_range(sc, rank):
+    base = (sc["state"][:, 0] * sc["n_grid"] - 0.5).astype(int)
+    lo, hi = sc["bounds"][rank], sc["bounds"][rank + 1]
+    return np.nonzero((base >= lo) & (base < hi))[0]

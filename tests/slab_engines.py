@@ -23,6 +23,7 @@ class OracleSlabEngine:
         self.ext = [torch.zeros(6, dtype=O.DT) for _ in self.specs]
         self.pgrad = {}
         self.newF = None
+        self.shift = 0                                # migration: duplicate frames before the current segment
 
     # ---- helpers
     def prims_at(self, f, leaves=False):
@@ -38,9 +39,9 @@ class OracleSlabEngine:
                                    float(s.get("friction", 0.9)), float(s.get("softness", 666.0)), bool(s.get("contact", True))))
         return out, lv
 
-    def get_adj(self, f):
+    def get_adj(self, f, n=None):
         if f not in self.adj:
-            N = self.frames[0][0].shape[0]
+            N = n if n is not None else self.frames[f][0].shape[0]
             self.adj[f] = [torch.zeros(N, 3, dtype=O.DT), torch.zeros(N, 3, dtype=O.DT), torch.zeros(N, 3, 3, dtype=O.DT),
                            torch.zeros(N, 3, 3, dtype=O.DT)]
         return self.adj[f]
@@ -57,8 +58,38 @@ class OracleSlabEngine:
     def halo_unpack_add(self, field, plane0, nplanes, buf):
         self.fields[field][plane0:plane0 + nplanes] += buf
 
+    # ---- migration interface (rows = x3 v3 F9 C9 / gx3 gv3 gF9 gC9), same as HipSlabEngine
+    def set_segment(self, n_live, shift):
+        self.shift = int(shift)
+
+    def get_state(self, f):
+        x, v, C, F = self.frames[f]
+        n = x.shape[0]
+        return np.hstack([x.numpy(), v.numpy(), F.reshape(n, 9).numpy(), C.reshape(n, 9).numpy()])
+
+    def set_state(self, f, st):
+        fr = O.state24_split(st)
+        while len(self.frames) <= f:
+            self.frames.append(None)
+        self.frames[f] = fr
+
+    def get_grad_rows(self, f):
+        gx, gv, gC, gF = self.get_adj(f)
+        n = gx.shape[0]
+        return np.hstack([gx.numpy(), gv.numpy(), gF.reshape(n, 9).numpy(), gC.reshape(n, 9).numpy()])
+
+    def add_grad_rows(self, f, g):
+        n = len(g)
+        self.adj.pop(f, None) if (f in self.adj and self.adj[f][0].shape[0] != n) else None
+        self.frames_n = n
+        a = self.get_adj(f, n)
+        t = lambda b, shp: torch.as_tensor(np.ascontiguousarray(b), dtype=O.DT).reshape(shp)
+        a[0] = a[0] + t(g[:, 0:3], (n, 3)); a[1] = a[1] + t(g[:, 3:6], (n, 3))
+        a[3] = a[3] + t(g[:, 6:15], (n, 3, 3)); a[2] = a[2] + t(g[:, 15:24], (n, 3, 3))
+
     def _contact(self, x, vmix, gm, prims, f):
         """correction added to grid_v_out by mixed2-4, and the per-primitive wrench"""
+        f = f - self.shift                            # the substep phase of `life` follows the physical substep (smac_set_segment)
         v_tmp = O.grid_op_mixed2(x, vmix, self.P)
         v_tgt, ext = O.grid_op_mixed3(x, v_tmp, prims, self.P, f)
         corr = O.grid_op_mixed4(x, v_tmp, v_tgt, gm, torch.zeros_like(vmix), self.P)

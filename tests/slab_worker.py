@@ -21,9 +21,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--engine", default="oracle"); ap.add_argument("--rank", type=int); ap.add_argument("--world", type=int)
     ap.add_argument("--port", type=int); ap.add_argument("--out"); ap.add_argument("--precision", default="float64")
+    ap.add_argument("--scene", default="static")
     a = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port))
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+    if a.scene == "moving":
+        return moving(a)
     sc = S.build(a.precision)
     idx = S.owned(sc, a.rank, a.world)
     state = sc["state"][idx]
@@ -65,6 +68,59 @@ def main():
                    ext=np.array([m.ext_f.to_numpy() for m in prims]) if sc["specs"] else np.zeros((0, 6)),
                    pgrad=np.array([[m.get_all_states_grad(f) for m in prims] for f in range(nsteps)]))
     np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=idx, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def moving(a):
+    """migration test: segments of `migrate_every` substeps, SlabRunner.migrate between them, migrate_grad on the way back"""
+    sc = S.build_moving(a.precision, a.world)
+    ids0 = S.owned_range(sc, a.rank)
+    state = sc["state"][ids0]
+    n, M, tol = sc["nsteps"], sc["migrate_every"], sc["drift_tol"]
+    lo, hi = sc["bounds"][a.rank], sc["bounds"][a.rank + 1]
+    npl = 2 + 2 * tol
+    left0, right0 = max(lo - tol, 0), min(hi - tol, sc["n_grid"] - npl)
+    if a.engine == "oracle":
+        import slab_engines as E
+        eng = E.OracleSlabEngine(H.oracle_params(sc["cfg"], sc["env_dt"]), state)
+        sim = None
+    else:
+        from softmac_amd.parallel import HipSlabEngine
+        cfg = sc["cfg"]
+        cfg.n_particles = len(sc["state"])                     # capacity: any rank may end up with many more particles
+        cfg.slab_flags = (2 if a.rank > 0 else 0) | (4 if a.rank < a.world - 1 else 0)
+        sim, prims = H.build_engine(cfg, sc["env_dt"])
+        sim.set_segment(len(state), 0)
+        sim.reset(state)
+        eng = HipSlabEngine(sim, use_torch_stream=True)
+    run = SlabRunner(eng, a.rank, a.world, left0, right0, npl, has_contact=False, own=(lo, hi), ids=ids0)
+    f, starts = 0, []
+    for seg in range(n // M):
+        starts.append(f)
+        run.run_substeps(f, M)
+        f += M
+        if seg < n // M - 1:
+            f = run.migrate(f)
+    ids_end = run.ids.copy()
+    st_end = eng.get_state(f)
+    rng = np.random.default_rng(77)
+    N = len(sc["state"])
+    seed_end = np.hstack([rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), 0.01 * rng.standard_normal((N, 9)), 0.01 * rng.standard_normal((N, 9))])
+    seed_1 = np.hstack([rng.standard_normal((N, 3)), np.zeros((N, 21))])
+    if sim is not None:
+        sim.clear_grads()
+    eng.add_grad_rows(f, seed_end[ids_end])
+    for seg in range(n // M - 1, -1, -1):
+        if seg == 0:                                           # a seed inside the first segment (frame 1), in that segment's ordering
+            eng.add_grad_rows(1, seed_1[ids0])
+        run.run_substeps_grad(starts[seg], M)
+        if seg > 0:
+            run.migrate_grad()
+    assert (run.ids == ids0).all()
+    g0 = eng.get_grad_rows(0)
+    moved = int(len(np.setdiff1d(ids_end, ids0)))
+    np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", ids0=ids0, ids_end=ids_end, st_end=st_end, g0=g0, moved=moved)
     dist.barrier()
     dist.destroy_process_group()
 

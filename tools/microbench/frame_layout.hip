@@ -10,6 +10,8 @@ constexpr int NC = 24;
 template <int TILED> __device__ __forceinline__ size_t at(int c, int p, int Npad) {
     if (TILED == 1) return (size_t)(p >> 6) * (NC * 64) + (size_t)c * 64 + (p & 63);
     if (TILED == 2) return (size_t)(p >> 12) * (NC * 4096) + (size_t)c * 4096 + (p & 4095);
+    if (TILED == 3) return (size_t)(p >> 8) * (NC * 256) + (size_t)c * 256 + (p & 255);
+    if (TILED == 4) return (size_t)(p >> 10) * (NC * 1024) + (size_t)c * 1024 + (p & 1023);
     return (size_t)c * Npad + p;
 }
 template <int TILED, int NR, int NW>
@@ -88,6 +90,14 @@ int main(int argc, char** argv) {
     }
     run<1, 3, 15>("AoSoA 64   (g2p-like)", a, b, N, N, 256);
     run<2, 3, 15>("AoSoA 4096 (g2p-like)", a, b, N, N, 256);
+    run<3, 3, 15>("AoSoA 256  (g2p-like)", a, b, N, N, 256);
+    run<4, 3, 15>("AoSoA 1024 (g2p-like)", a, b, N, N, 256);
+    run<0, 24, 9>("SoA        (p2g-like)", a, b, N, N + 4160, 512);
+    run<2, 24, 9>("AoSoA 4096 (p2g-like)", a, b, N, N, 512);
+    run<4, 24, 9>("AoSoA 1024 (p2g-like)", a, b, N, N, 512);
+    run<0, 18, 3>("SoA        (g2p_grad-like)", a, b, N, N + 4160, 256);
+    run<2, 18, 3>("AoSoA 4096 (g2p_grad-like)", a, b, N, N, 256);
+    run<4, 18, 3>("AoSoA 1024 (g2p_grad-like)", a, b, N, N, 256);
     run_staged<3, 15>("SoA staged 1 KB runs (g2p-like)", a, b, N, N + 4160, 256);
     run_staged<21, 21>("SoA staged 1 KB runs (p2g_grad)", a, b, N, N + 4160, 256);
     for (int skew : {0, 4160, 4128, 32 * 33}) {
@@ -97,5 +107,7 @@ int main(int argc, char** argv) {
     }
     run<1, 21, 21>("AoSoA 64   (p2g_grad-like)", a, b, N, N, 256);
     run<2, 21, 21>("AoSoA 4096 (p2g_grad-like)", a, b, N, N, 256);
+    run<3, 21, 21>("AoSoA 256  (p2g_grad-like)", a, b, N, N, 256);
+    run<4, 21, 21>("AoSoA 1024 (p2g_grad-like)", a, b, N, N, 256);
     return 0;
 }

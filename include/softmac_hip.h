@@ -161,6 +161,35 @@ int smac_loss_min_dist(smac_handle h, int f, int id_begin, int id_end, const dou
                        double out4[4]);
 int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /* particles inside a contact band after the last forward substep (nchunks_hit: retired, 0) */
 
+/* ---- material options of the soft_cloth variant of the simulator (soft_cloth/engine/mpm_simulator.py) ----
+ * "plasticity": 0 = singular values clipped to [1-2e-3, 1+3e-3] (softmac mpm_simulator.py:226-229, default),
+ *               1 = von-Mises return mapping (soft_cloth mpm_simulator.py:172-188, :232);
+ * "yield_ratio": yield_stress / (2 mu) of that return mapping (:182);
+ * "mass_eps":   a grid node has a velocity when its mass exceeds this (1e-10, mpm_simulator.py:286/399; the Python mirror rescales
+ *               it by mpm_scale^-2 because the particle kernels work on the unit domain) */
+int smac_set_param(smac_handle h, const char* name, double value);
+
+/* ---- cloth primitive: replaces soft_cloth/engine/primitive/primitive_cloth.py (Primitive_Cloth) and the contact bookkeeping of
+ * soft_cloth/engine/mpm_simulator.py:447-561.  One per handle, instead of SDF primitives.  Vertex positions / velocities /
+ * ext_f and their adjoints are float64 (n_vertices, 3) arrays in PHYSICAL units (the domain [0, mpm_scale)^3); the sheet moves
+ * kinematically (set per frame by the caller, as cloth_simulator.py:80-81 does with DiffClothAI's result). ---- */
+int smac_cloth_create(smac_handle h, int n_vertices, int n_faces, const int32_t* faces /* (n_faces,3) */, int n_neighbors,
+                      const int32_t* neighbor_faces /* (n_faces,n_neighbors), process_faces.py */, const int8_t* neighbor_dir,
+                      double friction, double softness, double cloth_force_scale, int sticky, double mpm_scale);   /* :30-69, initialize :367-376 */
+int smac_cloth_set_state(smac_handle h, int f_begin, int f_end, const double* pos, const double* vel);   /* set_all_states :348-354 for frames [f_begin, f_end) */
+int smac_cloth_get_state(smac_handle h, int f, double* pos, double* vel);                                /* get_all_states :320-324 */
+int smac_cloth_get_state_grad(smac_handle h, int f, double* pos_grad, double* vel_grad);                 /* get_all_states_grad :334-338 */
+int smac_cloth_get_ext_f(smac_handle h, double* ext_f);                                                  /* ext_f.to_numpy() */
+int smac_cloth_clear_ext_f(smac_handle h);                                                               /* clear_ext_f :285-290 (value and grad) */
+int smac_cloth_set_ext_f_grad(smac_handle h, const double* ext_f_grad);                                  /* set_ext_f_grad :292-296 */
+int smac_cloth_contact_pair(smac_handle h, int f);                 /* get_contact_pair, mpm_simulator.py:447-469 */
+int smac_cloth_backup_contact_pair(smac_handle h, int f);          /* backup_contact_pair :471-482 */
+int smac_cloth_trace_penetration(smac_handle h, int f, int after_cloth);   /* trace_penetration_after_mpm :484-518 (0) / _after_cloth :520-553 (1) */
+int smac_cloth_get_contact(smac_handle h, int f, int32_t* contact_id, int8_t* penetration);   /* the two extra columns of readframe :567-578; either may be NULL */
+int smac_cloth_set_contact(smac_handle h, int f, const int32_t* contact_id, const int8_t* penetration);   /* reset_all_kernel :642-643 / reset_kernel :629 */
+int smac_cloth_check_penetration(smac_handle h, int f, int32_t* total, int32_t* warnings);   /* check_penetration :555-561; warnings (may be NULL): particles the
+                                                                                                 tracing skipped because their previous face was not a listed neighbour (:509, :544) */
+
 /* ---- raw device views for the multi-GPU halo exchange (softmac_amd/parallel.py wraps them as
  * torch tensors for torch.distributed/RCCL; no reference counterpart - SURVEY 8e). */
 int smac_grid_device_ptr(smac_handle h, const char* field, void** dev_ptr, int64_t* n_scalars, int32_t* scalar_bytes);

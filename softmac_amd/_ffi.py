@@ -18,6 +18,7 @@ MAX_PRIMS = 4
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
+c_int8_p = C.POINTER(C.c_int8)
 
 
 class SmacConfig(C.Structure):
@@ -82,6 +83,21 @@ SIGNATURES = {
     "smac_profile_get": (C.c_int, [H, C.c_int, C.c_char_p, C.c_int, c_double_p, C.POINTER(C.c_int64)]),
     "smac_count_active_cells": (C.c_int, [H, C.c_int, C.POINTER(C.c_int64)]),
     "smac_contact_counts": (C.c_int, [H, c_int32_p, c_int32_p]),
+    "smac_set_param": (C.c_int, [H, C.c_char_p, C.c_double]),
+    "smac_cloth_create": (C.c_int, [H, C.c_int, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int8_p, C.c_double, C.c_double, C.c_double, C.c_int,
+                                    C.c_double]),
+    "smac_cloth_set_state": (C.c_int, [H, C.c_int, C.c_int, c_double_p, c_double_p]),
+    "smac_cloth_get_state": (C.c_int, [H, C.c_int, c_double_p, c_double_p]),
+    "smac_cloth_get_state_grad": (C.c_int, [H, C.c_int, c_double_p, c_double_p]),
+    "smac_cloth_get_ext_f": (C.c_int, [H, c_double_p]),
+    "smac_cloth_clear_ext_f": (C.c_int, [H]),
+    "smac_cloth_set_ext_f_grad": (C.c_int, [H, c_double_p]),
+    "smac_cloth_contact_pair": (C.c_int, [H, C.c_int]),
+    "smac_cloth_backup_contact_pair": (C.c_int, [H, C.c_int]),
+    "smac_cloth_trace_penetration": (C.c_int, [H, C.c_int, C.c_int]),
+    "smac_cloth_get_contact": (C.c_int, [H, C.c_int, c_int32_p, c_int8_p]),
+    "smac_cloth_set_contact": (C.c_int, [H, C.c_int, c_int32_p, c_int8_p]),
+    "smac_cloth_check_penetration": (C.c_int, [H, C.c_int, c_int32_p, c_int32_p]),
     "smac_loss_set_target": (C.c_int, [H, c_double_p, C.c_int]),
     "smac_loss_chamfer": (C.c_int, [H, C.c_int, C.c_double, C.c_int, c_double_p]),
     "smac_loss_min_dist": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_double_p, C.c_double, C.c_double, C.c_int, c_double_p]),

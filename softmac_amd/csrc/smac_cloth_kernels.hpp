@@ -1,0 +1,126 @@
+// Kernels of the soft <-> cloth contact that are not part of the substep itself: contact-face search, penetration tracing, hit list.
+// (The contact model runs inside k_contact_hits / k_contact_grad, CLOTH instantiation.)  Integer outputs, no gradient
+// (soft_cloth/engine/mpm_simulator.py:463-469, 512-518, 547-553 replace the adjoints by no-ops).
+#pragma once
+#include "smac_kernels.hpp"
+
+namespace smac {
+
+constexpr int CLOTH_FACE_BATCH = 256;      // faces staged in LDS per pass: 256 x 9 doubles = 18 KB
+
+// particle position of slot p in physical units (the particle kernels work on the unit domain; the cloth lives in [0, mpm_scale))
+template <class R> __device__ __forceinline__ void cloth_particle_pos(const DevSim<R>& D, const R* Sf, int p, double* x) {
+    typename pos_of<R>::type xp[3];
+    load_pos(Sf, D.Npad, p, xp);
+    for (int c = 0; c < 3; ++c) x[c] = pos_get(xp[c]) * D.cloth.par.scale;
+}
+
+// get_contact_pair_kernel :447-461: per particle the face with the smallest distance among the faces whose padded bounding box
+// holds it (every face for a particle that was penetrated at the previous frame); the first minimum wins, -1 without candidate.
+// One thread per particle slot; the faces' vertices are staged through LDS in batches, in face order.
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_cloth_pairs(DevSim<R> D, int f, const R* Sf, const int* orig) {
+    __shared__ double fv[CLOTH_FACE_BATCH][9];
+    const ClothDev& Cl = D.cloth;
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = p < D.N;
+    double px[3] = {0, 0, 0};
+    int id = 0, pen = 0;
+    if (valid) {
+        cloth_particle_pos(D, Sf, p, px);
+        id = orig ? orig[p] : p;
+        if (f > 0) pen = Cl.penetration[(size_t)(f - 1) * Cl.n_ids + id];
+    }
+    const double threshold = 1e-2 * Cl.par.scale;
+    double dmin = 1e10;
+    int best = -1;
+    const double* vpos = Cl.pos + (size_t)f * Cl.V * 3;
+    for (int base = 0; base < Cl.Fc; base += CLOTH_FACE_BATCH) {
+        const int nb = min(CLOTH_FACE_BATCH, Cl.Fc - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * 9; i += BLOCK) {
+            const int q = i / 9, k = i % 9;
+            fv[q][k] = vpos[(size_t)Cl.faces[3 * (base + q) + k / 3] * 3 + k % 3];
+        }
+        __syncthreads();
+        if (valid)
+            for (int q = 0; q < nb; ++q)
+                if (pen || cl_in_bbox(px, fv[q], fv[q] + 3, fv[q] + 6, threshold)) {
+                    const double d = cl_distance(px, fv[q], fv[q] + 3, fv[q] + 6);
+                    if (d < dmin) { dmin = d; best = base + q; }
+                }
+    }
+    if (valid) Cl.contact_id[(size_t)f * Cl.n_ids + id] = best;
+}
+
+// trace_penetration_after_mpm_kernel :484-510 (after_cloth = 0) / trace_penetration_after_cloth_kernel :520-545 (1).
+// One thread per ORIGINAL particle id; inv_cur / inv_prev map ids to slots of frames f / f-1 (nullptr: identity order).
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_cloth_trace(DevSim<R> D, int f, int after_cloth, const R* S_cur, const R* S_prev, const int* inv_cur,
+                                                       const int* inv_prev, int* warn) {
+    const ClothDev& Cl = D.cloth;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= D.N) return;
+    const size_t cur = (size_t)f * Cl.n_ids + i, prev = (size_t)(f - 1) * Cl.n_ids + i;
+    int pen = after_cloth ? Cl.penetration[cur] : Cl.penetration[prev];
+    const int fc = Cl.contact_id[cur], fp = after_cloth ? Cl.contact_before[i] : Cl.contact_id[prev];
+    if (fc == -1 || fp == -1) pen = 0;
+    else {
+        int inverse = 0;
+        bool neighbouring = false;
+        if (fc != fp) {
+            for (int j = 0; j < Cl.n_neighbors; ++j)
+                if (Cl.nbr[(size_t)fc * Cl.n_neighbors + j] == fp) {
+                    neighbouring = true;
+                    inverse = Cl.nbr_dir[(size_t)fc * Cl.n_neighbors + j];
+                    break;
+                }
+        } else neighbouring = true;
+        if (neighbouring) {
+            double pc[3], pp[3];
+            cloth_particle_pos(D, S_cur, inv_cur ? inv_cur[i] : i, pc);
+            if (after_cloth) { pp[0] = pc[0]; pp[1] = pc[1]; pp[2] = pc[2]; }
+            else cloth_particle_pos(D, S_prev, inv_prev ? inv_prev[i] : i, pp);
+            const double* vc = Cl.pos + (size_t)f * Cl.V * 3;
+            const double* vp = Cl.pos + (size_t)(f - 1) * Cl.V * 3;
+            const int* a = Cl.faces + 3 * fc;
+            const int* b = Cl.faces + 3 * fp;
+            const bool side_cur = cl_check_side(pc, vc + 3 * a[0], vc + 3 * a[1], vc + 3 * a[2]);
+            const bool side_prev = cl_check_side(pp, vp + 3 * b[0], vp + 3 * b[1], vp + 3 * b[2]);
+            if ((side_cur == side_prev) == (inverse != 0)) pen = 1 - pen;
+        } else atomicAdd(warn, 1);                 // the reference prints "not neighboring faces ... please expand searching region"
+    }
+    Cl.penetration[cur] = (signed char)pen;
+}
+
+// backup_contact_pair_kernel :471-474 and the per-frame copies of copyframe :597-598
+__global__ void k_cloth_copy_ids(int N, const int* src_id, int* dst_id, const signed char* src_pen, signed char* dst_pen) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    dst_id[i] = src_id[i];
+    if (src_pen) dst_pen[i] = src_pen[i];
+}
+// check_penetration :555-561
+__global__ void k_cloth_count_pen(int N, const signed char* pen, int* total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = (i < N && pen[i] == 1) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
+}
+
+// The particles grid_op_mixed3 :419-428 acts on (contact_id[f, p] >= 0) as the hit list the contact kernels walk:
+// Hit = {slot, 1 | penetration << 1, block, face}
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_cloth_hit_list(DevSim<R> D, int f) {
+    SMAC_CHUNK_PROLOGUE
+    if (!valid) return;
+    const ClothDev& Cl = D.cloth;
+    const size_t at = (size_t)f * Cl.n_ids + D.orig_id[p];
+    const int face = Cl.contact_id[at];
+    if (face >= 0) {
+        Hit h = {p, 1 | ((Cl.penetration[at] == 1 ? 1 : 0) << 1), ch.block, face};
+        D.hits[hit_slot(D.nhits)] = h;
+    }
+}
+
+}  // namespace smac

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "smac_math.hpp"
+#include "smac_cloth.hpp"
 #include "smac_sort.hpp"
 
 namespace smac {
@@ -74,6 +75,7 @@ struct Hit { int p, mask, block, pad; };
 template <class R> struct DevSim {
     int N, Npad, n, P, n_control, substeps, collision_type, sticky, max_frames;
     R dt, inv_dx, dx, p_mass, stress_scale;
+    R m_eps;                     // a grid node carries a velocity when its mass exceeds this (1e-10, mpm_simulator.py:286; rescaled with mpm_scale^-2)
     R g[3];
     Material<R> mat;
     R* S;
@@ -127,6 +129,7 @@ template <class R> struct DevSim {
     struct Hit* hit_ck;          // forward: where k_grid_op files the frame's contact hit list (with its length), or nullptr
     int* nhit_ck;
     int hit_cap;
+    ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
 };
 
 // LDS tile: the 6x6x6 nodes a particle whose base lies in a 4x4x4 block can touch (origin = 4*block).
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, H
     D.vin[cell] = z;
 }
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<R>* ck, const Hit* hit_ck, const int* nhit_ck) {
+__global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<R>* ck, const Hit* hit_ck, const int* nhit_ck, int zero_all) {
     if (hit_ck) {
         const int nh = *nhit_ck;
         if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = nh; *D.ncand = 0; }
@@ -516,7 +519,8 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
     const Vec4<R>* src = ck + (size_t)a * 192 + l;
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
     D.vin[cell] = src[0]; D.vmix[cell] = src[64]; D.vout[cell] = src[128];
-    D.ain[cell] = z; D.amix[cell] = z; D.aout[cell] = z;
+    D.aout[cell] = z;                                // g2p.grad's drifted lanes add to it
+    if (zero_all) { D.ain[cell] = z; D.amix[cell] = z; }   // (the fused backward grid pass writes every grid_v_in.grad and never reads grid_v_mixed.grad)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -714,6 +718,31 @@ template <class R> __device__ __forceinline__ int boundary(const DevSim<R>& D, i
     return mask;
 }
 
+// Adjoint of grid_op :283-297 / grid_op_mixed1 :396-404 at ONE node (no grid-node contact): `in` = forward {m, p}, `g` = adjoint of
+// the node's output velocity (zeroed here where the boundary condition zeroed the velocity); returns {grid_m.grad, grid_v_in.grad}.
+// Linear in g, which lets the contact adjoint push each of its sparse contributions through it separately (k_contact_grad).
+template <class R> __device__ __forceinline__ Vec4<R> grid_op_node_adjoint(const DevSim<R>& D, const Vec4<R>& in, int i, int j, int k, R* g) {
+    const Vec4<R> zero4 = {R(0), R(0), R(0), R(0)};
+    const R m = in.x;
+    if (!(m > D.m_eps)) return zero4;
+    const R inv = R(1) / m;
+    R v[3] = {inv * in.y + D.dt * D.g[0], inv * in.z + D.dt * D.g[1], inv * in.w + D.dt * D.g[2]};
+    const int mask = boundary(D, i, j, k, v);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (mask & (1 << d)) g[d] = R(0);
+    const R gm = -(in.y * g[0] + in.z * g[1] + in.w * g[2]);
+    const Vec4<R> o = {gm * inv * inv, g[0] * inv, g[1] * inv, g[2] * inv};
+    return o;
+}
+// grid coordinates of a block-major cell index
+__device__ __forceinline__ void cell_ijk(int nb, unsigned cell, int& i, int& j, int& k) {
+    const int b = (int)(cell >> 6), l = (int)(cell & 63u);
+    i = 4 * (b / (nb * nb)) + (l >> 4);
+    j = 4 * ((b / nb) % nb) + ((l >> 2) & 3);
+    k = 4 * (b % nb) + (l & 3);
+}
+
 // one thread per cell of an active block; returns false past the end
 template <class R> __device__ __forceinline__ bool active_cell(const DevSim<R>& D, int& b, int& l, size_t& cell, int& i, int& j, int& k) {
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -759,7 +788,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
         D.vin[cell] = z;
     }
     const R m = acc.x;
-    if (!(m > R(1e-10))) {                                                             // :286 / :399: no velocity on this node
+    if (!(m > D.m_eps)) {                                                             // :286 / :399: no velocity on this node
         if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = z;                       // (written, so the fields need no clear)
         D.vout[cell] = z;
         if (ckp) { ckp[64] = z; ckp[128] = z; }
@@ -805,7 +834,9 @@ template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D
 // collide_mixed chain, 8 hits per workgroup share an LDS tile over the block of the first one.  (A per-chunk
 // form walking a candidate-chunk list and a per-particle mask took 24 instead of 17 us: three more dependent loads and
 // half as many busy workgroups.)
-template <class R>
+// CLOTH: the hit list names the particles with a contact face (k_cloth_hit_list) and mixed3 is the cloth primitive's collide_mixed
+// (soft_cloth/engine/primitive/primitive_cloth.py:233-280) in physical units, its force splat onto the face's three vertices
+template <class R, bool CLOTH>
 __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
     typedef typename pos_of<R>::type PX;
     __shared__ tile_t ctile[3 * TILE_WORDS];
@@ -838,7 +869,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         bool has = false;
         if (mask && d < 27) {
             vm = gld(D.vmix, cell);
-            has = gval(D, 0, cell).x > R(1e-10);            // ({m,p} is in the checkpoint when there is one: k_grid_op zeroed the array)
+            has = gval(D, 0, cell).x > D.m_eps;            // ({m,p} is in the checkpoint when there is one: k_grid_op zeroed the array)
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2
 #pragma unroll
@@ -848,8 +879,29 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         // mixed3 in double whatever R is: the push-out divides a signed distance by dt
         const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])};
         double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
+        if (CLOTH && mask) {                                                                // mixed3, soft_cloth :419-428
+            const ClothDev& Cl = D.cloth;
+            const double sc = Cl.par.scale;
+            const int* vid = Cl.faces + 3 * h.pad;
+            double xv[3][3], vv[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 3; ++c) {
+                    xv[i][c] = Cl.pos[((size_t)f * Cl.V + vid[i]) * 3 + c];
+                    vv[i][c] = Cl.vel[((size_t)f * Cl.V + vid[i]) * 3 + c];
+                }
+            const double pp[3] = {sc * x64[0], sc * x64[1], sc * x64[2]};
+            double vio[3] = {sc * v_tgt[0], sc * v_tgt[1], sc * v_tgt[2]}, cf[3], wb[3];
+            if (cloth_collide_mixed<double>(Cl.par, xv, vv, pp, vio, (double)D.p_mass * sc * sc, D.dt64, life, (mask >> 1) & 1, cf, wb)) {
+                for (int c = 0; c < 3; ++c) v_tgt[c] = vio[c] / sc;
+                if (d < 9) {                                                                // :276-278, lane d adds component d % 3 of vertex d / 3
+                    const int vi = d / 3, c = d % 3;
+                    const double wv = vi == 0 ? wb[0] : (vi == 1 ? wb[1] : wb[2]), cc = c == 0 ? cf[0] : (c == 1 ? cf[1] : cf[2]);
+                    atomic_add(Cl.ext_f + (size_t)(vi == 0 ? vid[0] : (vi == 1 ? vid[1] : vid[2])) * 3 + c, cc * wv);
+                }
+            }
+        }
 #pragma unroll 1
-        for (int i = 0; i < D.P; ++i) {                                                     // mixed3
+        for (int i = 0; i < (CLOTH ? 0 : D.P); ++i) {                                       // mixed3
             if (!((mask >> i) & 1)) continue;
             const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
             double s13[13], ext[6] = {0, 0, 0, 0, 0, 0};
@@ -1215,11 +1267,30 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_aout(DevSim<R> D) {
     D.aout[cell] = acc;
 }
 
+// k_reduce_aout + the adjoint of grid_op / grid_op_mixed1 in one pass over the active cells (whole-substep path without grid-node
+// contact).  grid_op_mixed1's adjoint is linear in grid_v_mixed.grad, so it does not have to wait for the contact adjoint: this
+// kernel sends grid_v_out.grad through it, and k_contact_grad<DIRECT> sends each of its own sparse grid_v_mixed.grad contributions
+// through the same node map and adds them to grid_v_in.grad / grid_m.grad (one kernel and the dense grid_v_mixed.grad field less).
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad(DevSim<R> D) {
+    int b, l, i, j, k;
+    size_t cell;
+    if (!active_cell(D, b, l, cell, i, j, k)) return;
+    Vec4<R> acc = D.aout[cell];
+    const Vec4<R> in = D.vin[cell];
+    slab_reduce(D, b, l, acc);
+    if (D.any_contact) D.aout[cell] = acc;           // the contact adjoint gathers grid_v_out.grad at the nodes of its hits
+    R g[3] = {acc.x, acc.y, acc.z};
+    D.ain[cell] = grid_op_node_adjoint(D, in, i, j, k, g);
+}
+
 // Adjoint of grid_op_mixed4 / mixed3 / mixed2 for the listed particles.  One hit = one group of 32 lanes:
 // every lane of the group recomputes the (cheap) shared forward quantities, and the 19 forward-mode
 // directions of collide_mixed's adjoint (p_pos3, p_v3, state13) run in 19 different lanes instead of 19
 // times in one lane.  Lane n < 27 then owns stencil node n for the mixed2 scatter and the weight adjoints.
-template <class R>
+// DIRECT: grid_v_mixed.grad contributions go through grid_op_mixed1's node adjoint into grid_v_in.grad (see k_reduce_grid_grad)
+// CLOTH: 24 forward-mode directions of the cloth primitive's collide_mixed (p_pos3, p_v3, the face's vertex positions 9 and velocities 9)
+template <class R, bool DIRECT, bool CLOTH>
 __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
     __shared__ double pg_acc[MAX_PRIMS * 13];         // primitive-state adjoints of this workgroup's hits (see k_contact)
     if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
@@ -1256,12 +1327,13 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         const unsigned cell = (unsigned)((ni == 0 ? nd.cx[0] : (ni == 1 ? nd.cx[1] : nd.cx[2])) + (nj == 0 ? nd.cy[0] : (nj == 1 ? nd.cy[1] : nd.cy[2])) +
                                          (nk == 0 ? nd.cz[0] : (nk == 1 ? nd.cz[1] : nd.cz[2])));
         // node-parallel gathers, group-reduced (xor shuffles stay inside the 32-lane group)
-        Vec4<R> vm = {R(0), R(0), R(0), R(0)}, G = {R(0), R(0), R(0), R(0)};
+        Vec4<R> vm = {R(0), R(0), R(0), R(0)}, G = {R(0), R(0), R(0), R(0)}, vin_n = {R(0), R(0), R(0), R(0)};
         R has = R(0);
         if (mask && d < 27) {
             vm = gval(D, 1, cell);
             G = gld(D.aout, cell);
-            has = gval(D, 0, cell).x > R(1e-10) ? R(1) : R(0);
+            vin_n = gval(D, 0, cell);
+            has = vin_n.x > D.m_eps ? R(1) : R(0);
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2 forward
         R gd[3] = {-R(2) * wn * has * G.x, -R(2) * wn * has * G.y, -R(2) * wn * has * G.z};   // mixed4.grad: d/d(v_tmp - v_tgt)
@@ -1275,7 +1347,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         double dummy[6];
         // One primitive in range (the usual case): the value part of the dual pass below IS the forward result,
         // so the separate forward evaluation - a second chain of dependent SDF lookups - is skipped.
-        const bool single = mask != 0 && (mask & (mask - 1)) == 0;
+        const bool single = CLOTH || (mask != 0 && (mask & (mask - 1)) == 0);
         if (!single) {
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i)
@@ -1288,8 +1360,46 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         }
         double g[3] = {-(double)gd[0], -(double)gd[1], -(double)gd[2]};             // adjoint of v_tgt
         double gpos[3] = {0.0, 0.0, 0.0};
+        if (CLOTH) {
+            const ClothDev& Cl = D.cloth;
+            const double sc = Cl.par.scale;
+            const bool act = mask != 0;
+            const int* vid = Cl.faces + 3 * (act ? h.pad : 0);
+            double out = 0.0, vfwd[3] = {0.0, 0.0, 0.0};
+            if (act && d < 24) {
+                // particle position / velocity are unit-domain variables (x = sc * u), the vertices physical
+                Dual<double> pos[3], v[3], xv[3][3], vv[3][3], cf[3], wb[3];
+                for (int c = 0; c < 3; ++c) {
+                    pos[c] = Dual<double>(sc * x64[c], d == c ? sc : 0.0);
+                    v[c] = Dual<double>(sc * (double)v_tmp[c], d == 3 + c ? sc : 0.0);
+                }
+                for (int i = 0; i < 3; ++i)
+                    for (int c = 0; c < 3; ++c) {
+                        xv[i][c] = Dual<double>(Cl.pos[((size_t)f * Cl.V + vid[i]) * 3 + c], d == 6 + 3 * i + c ? 1.0 : 0.0);
+                        vv[i][c] = Dual<double>(Cl.vel[((size_t)f * Cl.V + vid[i]) * 3 + c], d == 15 + 3 * i + c ? 1.0 : 0.0);
+                    }
+                const bool in_band = cloth_collide_mixed<Dual<double>>(Cl.par, xv, vv, pos, v, pm64 * sc * sc, D.dt64, life, (mask >> 1) & 1, cf, wb);
+                for (int c = 0; c < 3; ++c) { out += g[c] * v[c].d / sc; vfwd[c] = v[c].v / sc; }      // (outside the band v is untouched: identity)
+                if (in_band)
+                    for (int i = 0; i < 3; ++i)
+                        for (int c = 0; c < 3; ++c) out += Cl.ext_f_grad[(size_t)vid[i] * 3 + c] * (cf[c] * wb[i]).d;
+            }
+            const double f0 = __shfl(vfwd[0], lane0, 64), f1 = __shfl(vfwd[1], lane0, 64), f2 = __shfl(vfwd[2], lane0, 64);
+            if (act) { v_tgt[0] = f0; v_tgt[1] = f1; v_tgt[2] = f2; }
+            const double o0 = __shfl(out, lane0 + 0, 64), o1 = __shfl(out, lane0 + 1, 64), o2 = __shfl(out, lane0 + 2, 64);
+            const double o3 = __shfl(out, lane0 + 3, 64), o4 = __shfl(out, lane0 + 4, 64), o5 = __shfl(out, lane0 + 5, 64);
+            if (act) {
+                gpos[0] += o0; gpos[1] += o1; gpos[2] += o2;
+                g[0] = o3; g[1] = o4; g[2] = o5;
+                if (d >= 6 && d < 24 && out != 0.0 && Cl.pos_grad) {                // position.grad[f, vertex] / velocity.grad[f, vertex]
+                    const int q = d < 15 ? d - 6 : d - 15, vi = q / 3, c = q % 3;
+                    double* dst = (d < 15 ? Cl.pos_grad : Cl.vel_grad) + ((size_t)f * Cl.V + (vi == 0 ? vid[0] : (vi == 1 ? vid[1] : vid[2]))) * 3 + c;
+                    atomic_add(dst, out);
+                }
+            }
+        }
 #pragma unroll 1
-        for (int i = D.P - 1; i >= 0; --i) {
+        for (int i = (CLOTH ? 0 : D.P) - 1; i >= 0; --i) {
             const bool act = (mask >> i) & 1;
             if (!__ballot(act)) continue;
             double out = 0.0;
@@ -1342,10 +1452,18 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                 const bool in_tile = h.block == wg_block && ((nd.okx >> ni) & (nd.oky >> nj) & (nd.okz >> nk) & 1) != 0;
                 const int tw = (ni == 0 ? nd.tx[0] : (ni == 1 ? nd.tx[1] : nd.tx[2])) + (nj == 0 ? nd.ty[0] : (nj == 1 ? nd.ty[1] : nd.ty[2])) +
                                (nk == 0 ? nd.tz[0] : (nk == 1 ? nd.tz[1] : nd.tz[2]));
+                if (DIRECT && !in_tile) {
+                    int ci, cj, ck;
+                    cell_ijk(D.nb, cell, ci, cj, ck);
+                    R gn[3] = {wn * gvt[0], wn * gvt[1], wn * gvt[2]};
+                    const Vec4<R> o = grid_op_node_adjoint(D, vin_n, ci, cj, ck, gn);
+                    if (has != R(0)) { gatomic(D.ain, cell, 0, o.x); gatomic(D.ain, cell, 1, o.y); gatomic(D.ain, cell, 2, o.z); gatomic(D.ain, cell, 3, o.w); }
+                } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (in_tile) lds_add(atile + tw + c * TILE_WORDS, wn * gvt[c]);
-                    else gatomic(D.amix, cell, c, wn * gvt[c]);
+                    for (int c = 0; c < 3; ++c) {
+                        if (in_tile) lds_add(atile + tw + c * TILE_WORDS, wn * gvt[c]);
+                        else gatomic(D.amix, cell, c, wn * gvt[c]);
+                    }
                 }
                 gw = vm.x * gvt[0] + vm.y * gvt[1] + vm.z * gvt[2]                           // mixed2: d/dw
                      - R(2) * has * (diff[0] * G.x + diff[1] * G.y + diff[2] * G.z);        // mixed4: d/dw
@@ -1376,7 +1494,15 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                 if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
                     const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
                     const unsigned cell = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
-                    gatomic(D.amix, cell, 0, a0); gatomic(D.amix, cell, 1, a1); gatomic(D.amix, cell, 2, a2);
+                    if (DIRECT) {
+                        R gn[3] = {a0, a1, a2};
+                        const Vec4<R> o = grid_op_node_adjoint(D, gval(D, 0, cell), 4 * bx + li, 4 * by + lj, 4 * bz + lk, gn);
+                        if (o.x != R(0) || o.y != R(0) || o.z != R(0) || o.w != R(0)) {
+                            gatomic(D.ain, cell, 0, o.x); gatomic(D.ain, cell, 1, o.y); gatomic(D.ain, cell, 2, o.z); gatomic(D.ain, cell, 3, o.w);
+                        }
+                    } else {
+                        gatomic(D.amix, cell, 0, a0); gatomic(D.amix, cell, 1, a1); gatomic(D.amix, cell, 2, a2);
+                    }
                 }
             }
         }
@@ -1477,7 +1603,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
         if (D.collision_type == CONTACT_MIXED) D.amix[cell] = zero4;
     }
     const R m = in.x;
-    if (!(m > R(1e-10))) {
+    if (!(m > D.m_eps)) {
         if (D.ck) D.ain[cell] = zero4;                                                 // k_p2g_grad gathers every node of its tile
         return;
     }

@@ -650,10 +650,30 @@ template <class R> SMAC_HD void svd_I_plus_E(const R* E, R* U, R* e, R* V) {
 //   out: En = new_F - I, stress (un-scaled, reference line 235-236 / 244-245)
 //   kept for the adjoint: U, e, V, ep (clipped e), Jm1 = J - 1
 // ------------------------------------------------------------------------------------------
+// plast: how the plastic material (ptype 0) returns to the yield surface.  PLAST_CLIP: the singular values are clipped to
+// [1 - 2e-3, 1 + 3e-3] (softmac mpm_simulator.py:226-229).  PLAST_VON_MISES: soft_cloth's compute_von_mises
+// (soft_cloth/engine/mpm_simulator.py:172-188) with yield_c = yield_stress / (2 mu).
+enum { PLAST_CLIP = 0, PLAST_VON_MISES = 1 };
 template <class R> struct Material {
     int ptype, model;
     R mu, lam;
+    int plast;
+    R yield_c;
 };
+// von-Mises return mapping on e = sigma - 1 (log strains eps = log(max(sigma, 0.05)), deviator eh, |eh| with the reference's 1e-8):
+// returns whether the particle yields; ep = sigma' - 1
+template <class R> SMAC_HD bool von_mises(const R* e, R yield_c, R* ep, R* eh, R& nrm) {
+    R eps[3];
+    for (int i = 0; i < 3; ++i) eps[i] = std::log1p(max_(e[i], R(0.05 - 1.0)));           // :175, 177-179
+    const R m = (eps[0] + eps[1] + eps[2]) / R(3);
+    for (int i = 0; i < 3; ++i) eh[i] = eps[i] - m;                                         // :180
+    nrm = std::sqrt(eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2] + R(1e-8));               // :181, 200-202
+    const R dg = nrm - yield_c;                                                             // :182
+    for (int i = 0; i < 3; ++i) ep[i] = e[i];
+    if (!(dg > R(0))) return false;
+    for (int i = 0; i < 3; ++i) ep[i] = std::expm1(eps[i] - (dg / nrm) * eh[i]);            // :185-186
+    return true;
+}
 template <class R> struct ConstState {
     R U[9], V[9], e[3], ep[3], Jm1;
     bool has_svd;
@@ -685,8 +705,12 @@ SMAC_HD void constitutive_fwd(const Material<R>& M, const R* Et, R* En, R* stres
             cs.has_svd = true;
             for (int i = 0; i < 3; ++i) {
                 cs.ep[i] = cs.e[i];
-                if (M.ptype == MAT_PLASTIC)                            // :226-229
+                if (M.ptype == MAT_PLASTIC && M.plast == PLAST_CLIP)   // :226-229
                     cs.ep[i] = min_(max_(cs.e[i], R(-2e-3)), R(3e-3));
+            }
+            if (M.ptype == MAT_PLASTIC && M.plast == PLAST_VON_MISES) {
+                R eh[3], nrm;
+                von_mises(cs.e, M.yield_c, cs.ep, eh, nrm);
             }
             // (new_F - R) new_F^T = U diag(e'(1+e')) U^T              (:234-235)
             R d[3] = {cs.ep[0] * (R(1) + cs.ep[0]), cs.ep[1] * (R(1) + cs.ep[1]), cs.ep[2] * (R(1) + cs.ep[2])};
@@ -785,7 +809,7 @@ SMAC_HD void constitutive_bwd(const Material<R>& M, const R* Et, const ConstStat
                     R ma_ji = plastic ? MAs[3 * j + i] + N[3 * j + i] : R(0);
                     if (i == j) {
                         bool inside = (e[i] > R(-2e-3)) && (e[i] < R(3e-3));     // clip passes the gradient
-                        T[3 * i + j] = (plastic && inside) ? ma_ij : R(0);
+                        T[3 * i + j] = (plastic && (inside || M.plast != PLAST_CLIP)) ? ma_ij : R(0);   // (von Mises: adjoint of sigma'_i, mapped below)
                     } else {
                         // reference: K (ma_ij (a_j - a_i) + ma_ji b + (MB_ij - MB_ji) ds) with a = s s' - 1, b = s_i s'_j - s'_i s_j.
                         // Written on the differences ds = e_j - e_i, ds' = e'_j - e'_i:
@@ -799,6 +823,20 @@ SMAC_HD void constitutive_bwd(const Material<R>& M, const R* Et, const ConstStat
                     }
                     if (!plastic) T[3 * i + j] += MAs[3 * i + j];      // elastic: new_F = F_tmp directly
                 }
+            if (plastic && M.plast == PLAST_VON_MISES) {
+                // the diagonal of T holds the adjoints of sigma'_k; sigma' = exp(eps'), eps' = mean(eps) + (c / |eh|) eh, eps = log(max(sigma, 0.05)):
+                //   d eps'_k / d eps_i = 1/3 + (c / |eh|) (delta_ki - 1/3) - c eh_k eh_i / |eh|^3        (sum eh = 0)
+                R ep2[3], eh[3], nrm;
+                if (von_mises(e, M.yield_c, ep2, eh, nrm)) {             // (not yielding: new_F = F_tmp, the adjoint passes unchanged)
+                    const R c = M.yield_c;
+                    R gep[3] = {T[0] * (R(1) + ep[0]), T[4] * (R(1) + ep[1]), T[8] * (R(1) + ep[2])};
+                    const R gm = (gep[0] + gep[1] + gep[2]) / R(3), dot = gep[0] * eh[0] + gep[1] * eh[1] + gep[2] * eh[2];
+                    for (int i = 0; i < 3; ++i) {
+                        const R ge = gm + (c / nrm) * (gep[i] - gm) - c * dot * eh[i] / (nrm * nrm * nrm);
+                        T[4 * i] = (R(1) + e[i] > R(0.05)) ? ge / (R(1) + e[i]) : R(0);
+                    }
+                }
+            }
             mm(cs.U, T, t); mmt(t, cs.V, gEt);
             if (!plastic) for (int i = 0; i < 9; ++i) gEt[i] += gFn[i];
         }

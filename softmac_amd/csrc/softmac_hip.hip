@@ -10,6 +10,7 @@
 
 #include "../../include/softmac_hip.h"
 #include "smac_kernels.hpp"
+#include "smac_cloth_kernels.hpp"
 #include "smac_voxel.hpp"
 #include "smac_loss.hpp"
 
@@ -93,6 +94,16 @@ struct ISim {
     virtual int halo_unpack_add(const char* field, int plane0, int np, const void* dev_in) = 0;
     virtual int set_stream(void* s) = 0;
     virtual int stream_handle(void** s) = 0;
+    virtual int set_param(const char* name, double value) = 0;
+    virtual int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction,
+                             double softness, double force_scale, int sticky, double scale) = 0;
+    virtual int cloth_set_state(int f0, int f1, const double* pos, const double* vel) = 0;
+    virtual int cloth_get_state(int f, double* pos, double* vel, int grad) = 0;
+    virtual int cloth_ext_f(int op, double* buf) = 0;
+    virtual int cloth_contact(int op, int f) = 0;
+    virtual int cloth_get_contact(int f, int32_t* ids, int8_t* pen) = 0;
+    virtual int cloth_set_contact(int f, const int32_t* ids, const int8_t* pen) = 0;
+    virtual int cloth_check_penetration(int f, int32_t* total, int32_t* warnings) = 0;
 };
 
 template <class R> struct Sim final : ISim {
@@ -193,6 +204,9 @@ template <class R> struct Sim final : ISim {
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
         hipFree(d_io);
+        hipFree(d_cloth_faces); hipFree(d_cloth_nbr); hipFree(d_cloth_nbr_dir); hipFree(d_cloth_warn); hipFree(d_cloth_ext_scratch);
+        hipFree(D.cloth.pos); hipFree(D.cloth.vel); hipFree(D.cloth.pos_grad); hipFree(D.cloth.vel_grad); hipFree(D.cloth.ext_f);
+        hipFree(D.cloth.ext_f_grad); hipFree(D.cloth.contact_id); hipFree(D.cloth.penetration); hipFree(D.cloth.contact_before);
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
         hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
@@ -245,6 +259,7 @@ template <class R> struct Sim final : ISim {
         D.stress_scale = (R)(-c.dt * c.p_vol * 4.0 * (double)c.n_grid * (double)c.n_grid);    // mpm_simulator.py:247
         for (int d = 0; d < 3; ++d) D.g[d] = (R)c.gravity[d];
         D.mat.ptype = c.ptype; D.mat.model = c.material_model; D.mat.mu = (R)c.mu; D.mat.lam = (R)c.lam;
+        D.mat.plast = PLAST_CLIP; D.mat.yield_c = R(0); D.m_eps = R(1e-10);
         const size_t fs = frame_scalars() * sizeof(R);
         HIP_TRY(hipMalloc((void**)&D.S, fs * c.max_frames));
         HIP_TRY(hipMemsetAsync(D.S, 0, fs * c.max_frames, stream));
@@ -500,6 +515,18 @@ template <class R> struct Sim final : ISim {
                 HIP_TRY(hipMemcpyAsync(ab + (size_t)(dst + j) * 6, ab + (size_t)(src + j) * 6, 6 * sizeof(double),
                                        hipMemcpyDeviceToDevice, stream));
             }
+        if (D.cloth.present) {                               // soft_cloth copyframe :597-602: contact face, penetration flag, the sheet's frames
+            const ClothDev& C = D.cloth;
+            hipLaunchKernelGGL(k_cloth_copy_ids, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)(C.contact_id + (size_t)src * C.n_ids),
+                               C.contact_id + (size_t)dst * C.n_ids, (const signed char*)(C.penetration + (size_t)src * C.n_ids),
+                               C.penetration + (size_t)dst * C.n_ids);
+            const size_t b = (size_t)C.V * 3;
+            for (int j = 0; j < cfg.substeps; ++j) {
+                if (src + j >= cfg.max_frames || dst + j >= cfg.max_frames) break;
+                HIP_TRY(hipMemcpyAsync(C.pos + (dst + j) * b, C.pos + (src + j) * b, b * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(C.vel + (dst + j) * b, C.vel + (src + j) * b, b * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            }
+        }
         return SMAC_OK;
     }
     int need_grad() {
@@ -597,6 +624,12 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(D.ext_f_grad, 0, Pn * 6 * sizeof(double), stream));
         HIP_TRY(hipMemsetAsync(D.action_grad, 0, (D.n_control > 0 ? D.n_control : 1) * 3 * sizeof(R), stream));
         HIP_TRY(hipMemsetAsync(grid_block + 3 * D.G, 0, 3 * D.G * sizeof(Vec4<R>), stream));
+        if (D.cloth.present && D.cloth.pos_grad) {
+            const size_t vs = (size_t)cfg.max_frames * D.cloth.V * 3 * sizeof(double);
+            HIP_TRY(hipMemsetAsync(D.cloth.pos_grad, 0, vs, stream));
+            HIP_TRY(hipMemsetAsync(D.cloth.vel_grad, 0, vs, stream));
+            HIP_TRY(hipMemsetAsync(D.cloth.ext_f_grad, 0, (size_t)D.cloth.V * 3 * sizeof(double), stream));
+        }
         return SMAC_OK;
     }
     int set_control_idx(const int32_t* idx) override {
@@ -982,9 +1015,180 @@ template <class R> struct Sim final : ISim {
 
     // ---- hot path -----------------------------------------------------------------------
     bool any_contact() const {
+        if (D.cloth.present) return true;
         for (int i = 0; i < D.P; ++i)
             if (D.prim[i].contact) return true;
         return false;
+    }
+
+    // ---- soft <-> cloth contact (soft_cloth/engine/primitive/primitive_cloth.py, soft_cloth/engine/mpm_simulator.py:447-561) ----
+    int* d_cloth_faces = nullptr; int* d_cloth_nbr = nullptr; signed char* d_cloth_nbr_dir = nullptr;
+    int* d_cloth_warn = nullptr;
+    double* d_cloth_ext_scratch = nullptr;
+    int set_param(const char* name, double value) override {
+        REQUIRE(name, "set_param: null name");
+        if (!strcmp(name, "plasticity")) {
+            REQUIRE(value == 0.0 || value == 1.0, "set_param(plasticity): 0 = clipped singular values (softmac), 1 = von Mises (soft_cloth)");
+            D.mat.plast = (int)value;
+        } else if (!strcmp(name, "yield_ratio")) {
+            REQUIRE(value > 0.0, "set_param(yield_ratio): yield_stress / (2 mu) must be positive");
+            D.mat.yield_c = (R)value;
+        } else if (!strcmp(name, "mass_eps")) {
+            REQUIRE(value >= 0.0, "set_param(mass_eps): negative");
+            D.m_eps = (R)value;
+        } else REQUIRE(false, "set_param: unknown parameter (plasticity | yield_ratio | mass_eps)");
+        ++config_gen;                                   // the forward grids on file were made with the old value
+        return SMAC_OK;
+    }
+    int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,
+                     double force_scale, int sticky, double scale) override {
+        REQUIRE(!D.cloth.present, "cloth_create: this handle already has a cloth primitive");
+        REQUIRE(D.P == 0, "cloth_create: a handle holds either SDF primitives or the cloth primitive (as the reference's two simulators do)");
+        REQUIRE(nv > 0 && nf > 0 && faces && nn >= 0 && (nn == 0 || (nbr && nbr_dir)) && scale > 0.0, "cloth_create: bad mesh arguments");
+        REQUIRE(cfg.collision_type != CONTACT_PARTICLE, "cloth_create: collision_type 1 (penalty contact) is not built for the cloth primitive; use 2 (forecast) or 0");
+        for (int i = 0; i < 3 * nf; ++i) REQUIRE(faces[i] >= 0 && faces[i] < nv, "cloth_create: face index out of range");
+        for (size_t i = 0; i < (size_t)nf * nn; ++i) REQUIRE(nbr[i] >= 0 && nbr[i] < nf, "cloth_create: neighbour face index out of range");
+        ClothDev& C = D.cloth;
+        const size_t vs = (size_t)cfg.max_frames * nv * 3 * sizeof(double), ns = (size_t)cfg.max_frames * cfg.n_particles;
+        HIP_TRY(hipMalloc((void**)&d_cloth_faces, (size_t)nf * 3 * sizeof(int)));
+        HIP_TRY(hipMemcpy(d_cloth_faces, faces, (size_t)nf * 3 * sizeof(int), hipMemcpyHostToDevice));
+        if (nn > 0) {
+            HIP_TRY(hipMalloc((void**)&d_cloth_nbr, (size_t)nf * nn * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&d_cloth_nbr_dir, (size_t)nf * nn));
+            HIP_TRY(hipMemcpy(d_cloth_nbr, nbr, (size_t)nf * nn * sizeof(int), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_cloth_nbr_dir, nbr_dir, (size_t)nf * nn, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMalloc((void**)&C.pos, vs)); HIP_TRY(hipMalloc((void**)&C.vel, vs));
+        HIP_TRY(hipMemset(C.pos, 0, vs)); HIP_TRY(hipMemset(C.vel, 0, vs));
+        if (cfg.grad_enabled) {
+            HIP_TRY(hipMalloc((void**)&C.pos_grad, vs)); HIP_TRY(hipMalloc((void**)&C.vel_grad, vs));
+            HIP_TRY(hipMemset(C.pos_grad, 0, vs)); HIP_TRY(hipMemset(C.vel_grad, 0, vs));
+        }
+        HIP_TRY(hipMalloc((void**)&C.ext_f, (size_t)nv * 3 * sizeof(double))); HIP_TRY(hipMalloc((void**)&C.ext_f_grad, (size_t)nv * 3 * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&d_cloth_ext_scratch, (size_t)nv * 3 * sizeof(double)));
+        HIP_TRY(hipMemset(C.ext_f, 0, (size_t)nv * 3 * sizeof(double))); HIP_TRY(hipMemset(C.ext_f_grad, 0, (size_t)nv * 3 * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&C.contact_id, ns * sizeof(int))); HIP_TRY(hipMalloc((void**)&C.penetration, ns));
+        HIP_TRY(hipMalloc((void**)&C.contact_before, (size_t)cfg.n_particles * sizeof(int)));
+        HIP_TRY(hipMemset(C.contact_id, 0xff, ns * sizeof(int))); HIP_TRY(hipMemset(C.penetration, 0, ns));
+        HIP_TRY(hipMemset(C.contact_before, 0xff, (size_t)cfg.n_particles * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_cloth_warn, 2 * sizeof(int))); HIP_TRY(hipMemset(d_cloth_warn, 0, 2 * sizeof(int)));
+        C.V = nv; C.Fc = nf; C.n_neighbors = nn; C.faces = d_cloth_faces; C.nbr = d_cloth_nbr; C.nbr_dir = d_cloth_nbr_dir;
+        C.n_ids = cfg.n_particles;
+        C.par.friction = friction; C.par.softness = softness; C.par.force_scale = force_scale; C.par.scale = scale; C.par.sticky = sticky ? 1 : 0;
+        C.present = 1;
+        ++config_gen;
+        return SMAC_OK;
+    }
+    int cloth_need() { REQUIRE(D.cloth.present, "this handle has no cloth primitive (smac_cloth_create)"); return SMAC_OK; }
+    int cloth_set_state(int f0, int f1, const double* pos, const double* vel) override {            // set_all_states :348-354, frames [f0, f1)
+        int rc;
+        if ((rc = cloth_need())) return rc;
+        REQUIRE(pos && vel && f0 >= 0 && f0 < f1 && f1 <= cfg.max_frames, "cloth_set_state: bad frame range / null argument");
+        const size_t b = (size_t)D.cloth.V * 3 * sizeof(double);
+        for (int f = f0; f < f1; ++f) {
+            HIP_TRY(hipMemcpyAsync(D.cloth.pos + (size_t)f * D.cloth.V * 3, pos, b, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(D.cloth.vel + (size_t)f * D.cloth.V * 3, vel, b, hipMemcpyHostToDevice, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        ++config_gen;
+        return SMAC_OK;
+    }
+    int cloth_get_state(int f, double* pos, double* vel, int grad) override {                         // get_all_states :320-324 / get_all_states_grad :334-338
+        int rc;
+        if ((rc = cloth_need()) || (rc = check_frame(f))) return rc;
+        REQUIRE(pos && vel, "null argument");
+        REQUIRE(!grad || D.cloth.pos_grad, "the handle was created without gradients");
+        const size_t b = (size_t)D.cloth.V * 3 * sizeof(double), at = (size_t)f * D.cloth.V * 3;
+        HIP_TRY(hipMemcpyAsync(pos, (grad ? D.cloth.pos_grad : D.cloth.pos) + at, b, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(vel, (grad ? D.cloth.vel_grad : D.cloth.vel) + at, b, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int cloth_ext_f(int op, double* buf) override {        // 0: ext_f.to_numpy(); 1: clear_ext_f :285-290; 2: set_ext_f_grad :292-296
+        int rc;
+        if ((rc = cloth_need())) return rc;
+        const size_t b = (size_t)D.cloth.V * 3 * sizeof(double);
+        if (op == 0) {
+            REQUIRE(buf, "null argument");
+            HIP_TRY(hipMemcpyAsync(buf, D.cloth.ext_f, b, hipMemcpyDeviceToHost, stream));
+        } else if (op == 1) {
+            HIP_TRY(hipMemsetAsync(D.cloth.ext_f, 0, b, stream));
+            HIP_TRY(hipMemsetAsync(D.cloth.ext_f_grad, 0, b, stream));
+        } else if (op == 2) {
+            REQUIRE(buf, "null argument");
+            HIP_TRY(hipMemcpyAsync(D.cloth.ext_f_grad, buf, b, hipMemcpyHostToDevice, stream));
+        } else REQUIRE(false, "cloth_ext_f: unknown op");
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    // id -> slot table of frame f (nullptr: the frame is in identity order)
+    int frame_inverse(int f, const int** out) {
+        const int e = frame_epoch[f];
+        *out = nullptr;
+        if (e <= 0) return SMAC_OK;
+        int rc;
+        if ((rc = ensure_inverse(e))) return rc;
+        *out = epochs[e].inv;
+        return SMAC_OK;
+    }
+    // 0: get_contact_pair :447-469; 1: backup_contact_pair :471-482; 2: trace_penetration_after_mpm :484-518; 3: ..._after_cloth :520-553
+    int cloth_contact(int op, int f) override {
+        int rc;
+        if ((rc = cloth_need()) || (rc = check_frame(f)) || (rc = check_drift())) return rc;
+        REQUIRE(frame_epoch[f] >= 0, "cloth contact: frame holds no particle state");
+        const ClothDev& C = D.cloth;
+        const size_t at = (size_t)f * C.n_ids;
+        const R* Sf = D.S + (size_t)f * frame_scalars();
+        if (op == 0) {
+            const int e = frame_epoch[f];
+            hipLaunchKernelGGL(k_cloth_pairs<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f, Sf, e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr);
+        } else if (op == 1) {
+            hipLaunchKernelGGL(k_cloth_copy_ids, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)(C.contact_id + at), C.contact_before,
+                               (const signed char*)nullptr, (signed char*)nullptr);
+        } else if (op == 2 || op == 3) {
+            REQUIRE(f >= 1 && frame_epoch[f - 1] >= 0, "trace_penetration: needs frame f-1");
+            const int *ic = nullptr, *ip = nullptr;
+            if ((rc = frame_inverse(f, &ic)) || (rc = frame_inverse(f - 1, &ip))) return rc;
+            hipLaunchKernelGGL(k_cloth_trace<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f, op == 3 ? 1 : 0, Sf, Sf - frame_scalars(), ic, ip, d_cloth_warn);
+        } else REQUIRE(false, "cloth_contact: unknown op");
+        ++config_gen;                                   // the contact faces are inputs of the forward grid
+        return check_launch();
+    }
+    int cloth_get_contact(int f, int32_t* ids, int8_t* pen) override {
+        int rc;
+        if ((rc = cloth_need()) || (rc = check_frame(f))) return rc;
+        const size_t at = (size_t)f * D.cloth.n_ids;
+        if (ids) HIP_TRY(hipMemcpyAsync(ids, D.cloth.contact_id + at, (size_t)D.N * sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (pen) HIP_TRY(hipMemcpyAsync(pen, D.cloth.penetration + at, (size_t)D.N, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int cloth_set_contact(int f, const int32_t* ids, const int8_t* pen) override {            // reset_all_kernel :642-643; reset_kernel :629
+        int rc;
+        if ((rc = cloth_need()) || (rc = check_frame(f))) return rc;
+        const size_t at = (size_t)f * D.cloth.n_ids;
+        if (ids) {
+            for (int i = 0; i < D.N; ++i) REQUIRE(ids[i] >= -1 && ids[i] < D.cloth.Fc, "cloth_set_contact: face id out of range");
+            HIP_TRY(hipMemcpyAsync(D.cloth.contact_id + at, ids, (size_t)D.N * sizeof(int), hipMemcpyHostToDevice, stream));
+        }
+        if (pen) HIP_TRY(hipMemcpyAsync(D.cloth.penetration + at, pen, (size_t)D.N, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        ++config_gen;
+        return SMAC_OK;
+    }
+    int cloth_check_penetration(int f, int32_t* total, int32_t* warnings) override {           // check_penetration :555-561
+        int rc;
+        if ((rc = cloth_need()) || (rc = check_frame(f))) return rc;
+        REQUIRE(total, "null argument");
+        HIP_TRY(hipMemsetAsync(d_cloth_warn + 1, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_cloth_count_pen, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const signed char*)(D.cloth.penetration + (size_t)f * D.cloth.n_ids),
+                           d_cloth_warn + 1);
+        int h[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(h, d_cloth_warn, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *total = h[1];
+        if (warnings) *warnings = h[0];               // particles whose previous contact face was not among the neighbours (tracing skipped them)
+        return check_launch();
     }
     int set_segment(int n_live, int frame_shift) override {
         REQUIRE(n_live >= 1 && n_live <= cfg.n_particles, "set_segment: n_live must be in [1, n_particles (the handle's capacity)]");
@@ -1067,7 +1271,12 @@ template <class R> struct Sim final : ISim {
         prof_end();
         if (stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED) {
             prof_begin(K_CONTACT);
-            hipLaunchKernelGGL(k_contact_hits<R>, dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+            if (D.cloth.present) {
+                if (is_recompute) Dc.cloth.ext_f = d_cloth_ext_scratch;          // (recompute pass: do not count the force twice)
+                hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+                hipLaunchKernelGGL((k_contact_hits<R, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+            } else
+                hipLaunchKernelGGL((k_contact_hits<R, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
         }
         return check_launch();
@@ -1174,6 +1383,12 @@ template <class R> struct Sim final : ISim {
     // of grid_v_mixed.grad phase 1.
     bool pending_adj_zero = false;
     bool direct_bwd = false;
+    // whole-substep backward without grid-node contact: k_reduce_grid_grad does k_reduce_aout's and k_grid_op_grad's work in one pass
+    // (SMAC_FUSED_GRID_BWD=0 keeps the three-kernel sequence the slab phases use)
+    int fused_bwd_env = getenv("SMAC_FUSED_GRID_BWD") ? atoi(getenv("SMAC_FUSED_GRID_BWD")) : 1;
+    bool fused_grid_bwd(int phase) const {
+        return fused_bwd_env && phase < 0 && ck_mode != 1 && !(D.collision_type == CONTACT_GRID && any_contact());
+    }
     int substep_grad_phase(int f, const double* action, const double* ext_f_grad, double* action_grad_out, int phase) {
         int rc;
         if ((rc = need_grad())) return rc;
@@ -1222,7 +1437,8 @@ template <class R> struct Sim final : ISim {
                     D.nhits = ck_nhits + f;
                 } else if (D.any_contact && D.collision_type != CONTACT_GRID) {
                     HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
-                    hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                    if (D.cloth.present) hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                    else hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 }
                 direct_bwd = true;
             } else if (ck_ok) {
@@ -1235,9 +1451,11 @@ template <class R> struct Sim final : ISim {
                 vin_clean = false;
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f),
                                    have_hits ? (const Hit*)(ck_hits + (size_t)f * ck_hit_cap) : (const Hit*)nullptr,
-                                   have_hits ? (const int*)(ck_nhits + f) : (const int*)nullptr);
-                if (D.any_contact && D.collision_type != CONTACT_GRID && !have_hits)
-                    hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                                   have_hits ? (const int*)(ck_nhits + f) : (const int*)nullptr, fused_grid_bwd(phase) ? 0 : 1);
+                if (D.any_contact && D.collision_type != CONTACT_GRID && !have_hits) {
+                    if (D.cloth.present) hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                    else hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                }
                 prof_end();
             } else {
                 REQUIRE(phase < 0, "slab-decomposed substep_grad needs the forward-grid checkpoint of this frame "
@@ -1251,17 +1469,22 @@ template <class R> struct Sim final : ISim {
                 else hipLaunchKernelGGL((k_g2p_grad<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
                 prof_begin(K_REDUCE);
-                hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+                if (fused_grid_bwd(phase)) hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+                else hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
             }
         }
         if ((phase < 0 || phase == 1) && D.nchunks > 0 && D.collision_type == CONTACT_MIXED && any_contact()) {   // :362-363, 389-393
             prof_begin(K_CONTACT_GRAD);
-            hipLaunchKernelGGL(k_contact_grad<R>, dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
+            if (D.cloth.present) {
+                if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
+                else hipLaunchKernelGGL((k_contact_grad<R, false, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
+            } else if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
+            else hipLaunchKernelGGL((k_contact_grad<R, false, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
             prof_end();
         }
         if (phase < 0 || phase == 2) {
-            if (D.nchunks > 0) {
+            if (D.nchunks > 0 && !fused_grid_bwd(phase)) {
                 prof_begin(K_GRID_OP_GRAD);
                 if (D.collision_type == CONTACT_GRID && any_contact())
                     hipLaunchKernelGGL((k_grid_op_grad<R, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);   // :394 / :365
@@ -1701,6 +1924,23 @@ int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* tot
 }
 int smac_count_active_cells(smac_handle h, int f, int64_t* cells) { return FWD(count_active_cells(f, cells)); }
 int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit) { return FWD(contact_counts(nhits, nchunks_hit)); }
+int smac_set_param(smac_handle h, const char* name, double value) { return FWD(set_param(name, value)); }
+int smac_cloth_create(smac_handle h, int n_vertices, int n_faces, const int32_t* faces, int n_neighbors, const int32_t* neighbor_faces,
+                      const int8_t* neighbor_dir, double friction, double softness, double cloth_force_scale, int sticky, double mpm_scale) {
+    return FWD(cloth_create(n_vertices, n_faces, faces, n_neighbors, neighbor_faces, neighbor_dir, friction, softness, cloth_force_scale, sticky, mpm_scale));
+}
+int smac_cloth_set_state(smac_handle h, int f_begin, int f_end, const double* pos, const double* vel) { return FWD(cloth_set_state(f_begin, f_end, pos, vel)); }
+int smac_cloth_get_state(smac_handle h, int f, double* pos, double* vel) { return FWD(cloth_get_state(f, pos, vel, 0)); }
+int smac_cloth_get_state_grad(smac_handle h, int f, double* pos_grad, double* vel_grad) { return FWD(cloth_get_state(f, pos_grad, vel_grad, 1)); }
+int smac_cloth_get_ext_f(smac_handle h, double* ext_f) { return FWD(cloth_ext_f(0, ext_f)); }
+int smac_cloth_clear_ext_f(smac_handle h) { return FWD(cloth_ext_f(1, nullptr)); }
+int smac_cloth_set_ext_f_grad(smac_handle h, const double* ext_f_grad) { return FWD(cloth_ext_f(2, const_cast<double*>(ext_f_grad))); }
+int smac_cloth_contact_pair(smac_handle h, int f) { return FWD(cloth_contact(0, f)); }
+int smac_cloth_backup_contact_pair(smac_handle h, int f) { return FWD(cloth_contact(1, f)); }
+int smac_cloth_trace_penetration(smac_handle h, int f, int after_cloth) { return FWD(cloth_contact(after_cloth ? 3 : 2, f)); }
+int smac_cloth_get_contact(smac_handle h, int f, int32_t* contact_id, int8_t* penetration) { return FWD(cloth_get_contact(f, contact_id, penetration)); }
+int smac_cloth_set_contact(smac_handle h, int f, const int32_t* contact_id, const int8_t* penetration) { return FWD(cloth_set_contact(f, contact_id, penetration)); }
+int smac_cloth_check_penetration(smac_handle h, int f, int32_t* total, int32_t* warnings) { return FWD(cloth_check_penetration(f, total, warnings)); }
 int smac_loss_set_target(smac_handle h, const double* target, int m) { return FWD(loss_set_target(target, m)); }
 int smac_loss_chamfer(smac_handle h, int f, double weight, int add_grad, double* loss_out) { return FWD(loss_chamfer(f, weight, add_grad, loss_out)); }
 int smac_loss_min_dist(smac_handle h, int f, int id_begin, int id_end, const double center[3], double offset, double weight, int add_grad,

@@ -1,0 +1,186 @@
+"""What pins oracle/cloth_oracle.py (the reference has no tests; Taichi and DiffClothAI are absent): an independent point-triangle
+distance, finite differences of the whole substep's adjoint, invariants of the von-Mises return mapping, brute-force restatements
+of the integer kernels, and the face-neighbourhood tables against the product's own implementation."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import scenes_cloth as S
+from oracle import cloth_oracle as CO
+
+
+def _closest_point_triangle(p, a, b, c):
+    """Ericson, Real-Time Collision Detection 5.1.5 (Voronoi regions) - independent of the reference's plane / edge split"""
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = ab @ ap, ac @ ap
+    if d1 <= 0 and d2 <= 0:
+        return a
+    bp = p - b
+    d3, d4 = ab @ bp, ac @ bp
+    if d3 >= 0 and d4 <= d3:
+        return b
+    vc = d1 * d4 - d3 * d2
+    if vc <= 0 and d1 >= 0 and d3 <= 0:
+        return a + ab * (d1 / (d1 - d3))
+    cp = p - c
+    d5, d6 = ab @ cp, ac @ cp
+    if d6 >= 0 and d5 <= d6:
+        return c
+    vb = d5 * d2 - d1 * d6
+    if vb <= 0 and d2 >= 0 and d6 <= 0:
+        return a + ac * (d2 / (d2 - d6))
+    va = d3 * d6 - d5 * d4
+    if va <= 0 and (d4 - d3) >= 0 and (d5 - d6) >= 0:
+        return b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)))
+    den = 1.0 / (va + vb + vc)
+    return a + ab * (vb * den) + ac * (vc * den)
+
+
+def test_distance_function_is_the_point_triangle_distance():
+    rng = np.random.default_rng(0)
+    for mesh in ("tortilla.obj", "towel.obj"):
+        V, F = S.load_obj(S.CLOTH / mesh)
+        fid = rng.integers(0, len(F), 400)
+        tri = V[F[fid]]
+        size = np.linalg.norm(tri[:, 1] - tri[:, 0], axis=1)
+        p = tri.mean(1) + rng.standard_normal((400, 3)) * size[:, None]
+        d = CO.distance_function(torch.as_tensor(p), *(torch.as_tensor(tri[:, i]) for i in range(3))).numpy()
+        ref = np.array([np.linalg.norm(p[i] - _closest_point_triangle(p[i], *tri[i])) for i in range(400)])
+        assert np.abs(d - ref).max() < 1e-6 * size.max()          # (length() carries the reference's 1e-14 under the root)
+        # signed distance: unsigned for a free particle, negative for a penetrated one; the normal points from the sheet to the particle side
+        for pen in (0, 1):
+            sd, n = CO.sdf_and_normal(torch.as_tensor(p), torch.full((400,), pen), *(torch.as_tensor(tri[:, i]) for i in range(3)))
+            assert ((sd.numpy() >= 0) == (pen == 0)).all()
+            assert np.abs(np.linalg.norm(n.numpy(), axis=1) - 1).max() < 1e-6
+
+
+def test_barycentric_weights_reproduce_the_point_in_both_projections():
+    rng = np.random.default_rng(1)
+    for flat_axis in (1, 2):                                      # y-flat sheet: the x-y determinant vanishes -> the x-z branch (:106-108)
+        tri = rng.uniform(0, 1, (50, 3, 3))
+        tri[:, :, flat_axis] = 0.3
+        w = rng.dirichlet([1, 1, 1], 50)
+        p = (w[:, :, None] * tri).sum(1)
+        w1, w2, w3 = CO.barycentric_coordinate(torch.as_tensor(p), *(torch.as_tensor(tri[:, i]) for i in range(3)))
+        # the reference's convention: w1 weights x1, w2 weights x2, w3 = 1 - w1 - w2 weights x0 ... but collide_mixed applies
+        # (w1, w2, w3) to vertices (0, 1, 2) as written (:244-245, :276-278); what must hold is the partition of unity
+        assert np.abs((w1 + w2 + w3).numpy() - 1).max() < 1e-12
+        assert np.abs(w1.numpy() - w[:, 1]).max() < 1e-9 and np.abs(w2.numpy() - w[:, 2]).max() < 1e-9
+
+
+def test_von_mises_return_mapping_invariants():
+    rng = np.random.default_rng(2)
+    N = 200
+    amp = torch.as_tensor(np.where(np.arange(N) % 2 == 0, 0.2, 0.004))[:, None, None]
+    F = torch.eye(3, dtype=CO.DT)[None] + amp * torch.as_tensor(rng.standard_normal((N, 3, 3)))
+    U, sig, V = CO.O.svd3(F)
+    mu, ys = 2000.0, 60.0
+    Fn = CO.compute_von_mises(F, U, sig, V, ys, mu)
+    s0, s1 = torch.linalg.svdvals(F), torch.linalg.svdvals(Fn)
+    e0, e1 = torch.log(s0), torch.log(s1)
+    dev = lambda e: e - e.mean(1, keepdim=True)
+    n0, n1 = dev(e0).norm(dim=1), dev(e1).norm(dim=1)
+    c = ys / (2 * mu)
+    yields = torch.sqrt(n0 ** 2 + 1e-8) > c
+    assert yields.sum() > 50 and (~yields).sum() > 5
+    assert torch.allclose(Fn[~yields], F[~yields])                               # inside the yield surface: untouched
+    assert (e0.sum(1) - e1.sum(1)).abs()[yields].max() < 1e-10                   # volume preserved
+    assert (n1[yields] - c * n0[yields] / torch.sqrt(n0[yields] ** 2 + 1e-8)).abs().max() < 1e-10   # back on the surface (with the 1e-8 of norm())
+
+
+@pytest.mark.parametrize("kind", ["taco", "hit"])
+def test_substep_adjoint_matches_finite_differences(kind):
+    sc = S.build(kind, "float64", N=300, seed=3)
+    P = S.oracle_params(sc)
+    N, V = 300, len(sc["vertices"])
+    x, v, C, F = CO.O.state24_split(sc["state"])
+    cx, cv = (torch.as_tensor(a) for a in sc["motion"](0.3))
+    # (tilted: on the exactly flat tortilla barycentric_coordinate :106 sits ON its branch point |A0 B1 - A1 B0| < 1e-10 and any
+    # perturbation of a vertex switches to the other, ill-conditioned projection - a kink of the reference's function, not a derivative)
+    cx = cx + torch.stack([torch.zeros(len(cx), dtype=CO.DT), 0.02 * (cx[:, 0] - 2.5 * sc["scale"] / 5) + 0.01 * cx[:, 2], 0.015 * cx[:, 0]], 1)
+    ids = CO.get_contact_pair(x, cx, sc["faces"], None, sc["scale"])
+    rng = np.random.default_rng(4)
+    pen = ((rng.uniform(size=N) < 0.2) & (ids >= 0)).astype(np.int8)
+    assert (ids >= 0).sum() > 30
+    ci = None if sc["control_idx"] is None else torch.as_tensor(sc["control_idx"], dtype=torch.int64)
+    act = None if sc["action"] is None else torch.as_tensor(sc["action"], dtype=CO.DT)
+    seeds = [torch.as_tensor(rng.standard_normal(s)) for s in ((N, 3), (N, 3), (N, 3, 3), (N, 3, 3))]
+    eg = torch.as_tensor(rng.standard_normal((V, 3)) * 1e-2 / P.p_mass * P.dt)
+
+    def loss(x_, v_, C_, F_, cx_, cv_, a_):
+        pr = S.oracle_prim(sc, cx_, cv_)
+        nx, nv, nC, nF, ext = CO.substep(x_, v_, C_, F_, P, pr, ids, pen, 0, ci, a_)
+        return float((nx * seeds[0]).sum() + (nv * seeds[1]).sum() + (nC * seeds[2]).sum() + (nF * seeds[3]).sum() + (ext * eg).sum())
+    g = CO.substep_grad(x, v, C, F, P, S.oracle_prim(sc, cx, cv), ids, pen, 0, *seeds, ext_f_grad=eg, control_idx=ci, action=act)
+    args = [x, v, C, F, cx, cv, act]
+    grads = [g["gx"], g["gv"], g["gC"], g["gF"], g["cloth_pos"], g["cloth_vel"], g["action"]]
+    for k, (a, ga) in enumerate(zip(args, grads)):
+        if a is None:
+            continue
+        d = torch.as_tensor(rng.standard_normal(tuple(a.shape)))
+        h = 1e-7 * float(a.abs().max() + 1e-3)
+        plus = [t if i != k else a + h * d for i, t in enumerate(args)]
+        minus = [t if i != k else a - h * d for i, t in enumerate(args)]
+        fd = (loss(*plus) - loss(*minus)) / (2 * h)
+        an = float((ga * d).sum())
+        assert abs(fd - an) < 2e-5 * max(abs(an), abs(fd), 1e-6), (kind, k, fd, an)
+
+
+def test_contact_pair_and_tracing_against_plain_loops():
+    sc = S.build("taco", "float64", N=150, seed=5)
+    x = sc["state"][:, :3]
+    V, F = sc["vertices"], sc["faces"]
+    ids = CO.get_contact_pair(x, V, F, None, sc["scale"])
+    pen_prev = (np.arange(150) % 7 == 0)
+    ids_p = CO.get_contact_pair(x, V, F, pen_prev, sc["scale"])
+    Vt = torch.as_tensor(V)
+    for i in range(150):                                         # the sequential loop of :456-461
+        for flagged, got in ((False, ids[i]), (bool(pen_prev[i]), ids_p[i])):
+            best, dmin = -1, 1e10
+            p = torch.as_tensor(x[i])
+            for fc in range(len(F)):
+                tri = [Vt[int(q)] for q in F[fc]]
+                if flagged or bool(CO.in_bounding_box(p, *tri, 1e-2 * sc["scale"])):
+                    d = float(CO.distance_function(p[None], *(t[None] for t in tri))[0])
+                    if d < dmin:
+                        best, dmin = fc, d
+            assert best == got
+    # a particle crossing a flat sheet flips its flag, crossing back restores it; a particle that loses its face is reset
+    Vs = np.array([[0, 0.5, 0], [1, 0.5, 0], [0, 0.5, 1], [1, 0.5, 1]], dtype=np.float64)
+    Fs = np.array([[0, 1, 2], [1, 3, 2]])
+    nb, nbd = CO.process_faces(Fs, 4)
+    xa, xb = np.array([[0.3, 0.52, 0.3], [0.7, 0.52, 0.7]]), np.array([[0.3, 0.48, 0.3], [0.7, 0.52, 0.6]])
+    c = np.array([0, 1], dtype=np.int32)
+    pen, w = CO.trace_penetration_after_mpm(xb, xa, Vs, Vs, Fs, c, c, np.zeros(2, dtype=np.int8), nb, nbd)
+    assert pen.tolist() == [1, 0] and w == 0
+    pen2, _ = CO.trace_penetration_after_mpm(xa, xb, Vs, Vs, Fs, c, c, pen, nb, nbd)
+    assert pen2.tolist() == [0, 0]
+    pen3, _ = CO.trace_penetration_after_mpm(xb, xa, Vs, Vs, Fs, np.array([-1, 1], dtype=np.int32), c, np.ones(2, dtype=np.int8), nb, nbd)
+    assert pen3.tolist() == [0, 1]
+    # crossing while the contact face changes to the (consistently oriented) neighbour: same rule through the neighbour table
+    pen4, _ = CO.trace_penetration_after_mpm(np.array([[0.6, 0.48, 0.6]]), np.array([[0.3, 0.52, 0.3]]), Vs, Vs, Fs, np.array([1], dtype=np.int32),
+                                             np.array([0], dtype=np.int32), np.zeros(1, dtype=np.int8), nb, nbd)
+    assert pen4.tolist() == [1]
+
+
+def test_face_neighbourhoods():
+    from softmac_amd.soft_cloth.engine.primitive.process_faces import process
+    for mesh in ("tortilla.obj", "towel.obj"):
+        _, F = S.load_obj(S.CLOTH / mesh)
+        nb, nbd = process(F, 200)
+        onb, onbd = CO.process_faces(F, 200)
+        assert (nb == onb).all() and (nbd == onbd).all()
+        assert nbd.sum() == 0                                   # the reference's sheets are consistently oriented
+        # first-ring neighbours really share an edge
+        for i in range(0, len(F), 17):
+            ring = [j for j in nb[i][:3] if j != i]
+            assert all(len(set(F[i]) & set(F[j])) == 2 for j in ring[:1])
+        G = F.copy()
+        G[5] = G[5][[0, 2, 1]]                                  # flip one face: every table row that lists it is flagged there
+        nb2, nbd2 = process(G, 200)
+        for i in range(len(G)):
+            hit = np.nonzero(nb2[i] == 5)[0]
+            if i != 5 and len(hit):
+                assert nbd2[i, hit[0]] == 1
+        assert nbd2[5].sum() == (nb2[5] != 5).sum()

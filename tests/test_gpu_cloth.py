@@ -1,0 +1,219 @@
+"""Soft <-> cloth contact on the GPU against oracle/cloth_oracle.py: contact-face search and penetration tracing
+(integer results: equal, except where two faces tie to rounding), the substep with the sheet's forecast contact in f64 and f32
+(helpers.F32_TOL), its adjoint including the sheet's position / velocity adjoints and the action, and the env loop."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import scenes_cloth as S
+from oracle import cloth_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs_match(x, verts, faces, ids_dev, ids_ref):
+    """equal ids, or - where they differ - both faces at the same distance to 1e-12 (closest point on a shared edge / vertex)"""
+    bad = np.nonzero(ids_dev != ids_ref)[0]
+    if len(bad) == 0:
+        return 0
+    assert ((ids_dev[bad] >= 0) & (ids_ref[bad] >= 0)).all()
+    P = torch.as_tensor(x[bad])
+    Vt = torch.as_tensor(verts)
+    d = []
+    for ids in (ids_dev[bad], ids_ref[bad]):
+        f = faces[ids].astype(np.int64)
+        d.append(CO.distance_function(P, Vt[f[:, 0]], Vt[f[:, 1]], Vt[f[:, 2]]).numpy())
+    assert np.abs(d[0] - d[1]).max() < 1e-12 * max(1.0, np.abs(verts).max())
+    return len(bad)
+
+
+@pytest.mark.parametrize("kind", ["taco", "hit"])
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_contact_pairs_and_tracing_match_oracle(kind, precision):
+    sc = S.build(kind, precision, n_env_steps=1)
+    sim, prim = S.build_engine(sc)
+    N = len(sc["state"])
+    x0, v0 = sc["motion"](0.0)
+    prim.set_all_states(0, x0, v0, f_end=sc["nframes"] + 2)
+    sim.reset(sc["state"])
+    sim.get_contact_pair(0)
+    ids_dev, pen_dev = sim.get_contact(0)
+    xs = sim.get_x(0)                                   # what the device sees (f32: positions on its 2^-32 lattice)
+    ids_ref = CO.get_contact_pair(xs, x0, sc["faces"], None, sc["scale"])
+    ties = _pairs_match(xs, x0, sc["faces"], ids_dev, ids_ref)
+    assert (ids_dev >= 0).sum() > N // 10 and ties < N // 20
+    assert (pen_dev == 0).all()
+    # three substeps with the sheet moving: trace after each; flags must equal the oracle's on the device's own trajectory
+    nb, nbd = prim.neighbor_faces_np, prim.neighbor_faces_direction_np
+    onb, onbd = CO.process_faces(sc["faces"], 200)
+    assert (nb == onb).all() and (nbd == onbd).all()
+    pen_prev, ids_prev, x_prev, cl_prev = pen_dev.copy(), ids_dev.copy(), xs, x0
+    flips = 0
+    for f in range(1, 4):
+        xc, vc = sc["motion"](f * sc["cfg"].dt * 40)   # exaggerated sheet motion: vertices sweep through the particles
+        prim.set_all_states(f, xc, vc)
+        sim.substep(f - 1, sc["action"])
+        sim.get_contact_pair(f)
+        sim.trace_penetration_after_mpm(f)
+        ids_c, pen_c = sim.get_contact(f)
+        x_c = sim.get_x(f)
+        ids_o = CO.get_contact_pair(x_c, xc, sc["faces"], pen_prev, sc["scale"])
+        _pairs_match(x_c, xc, sc["faces"], ids_c, ids_o)
+        pen_o, _ = CO.trace_penetration_after_mpm(x_c, x_prev, xc, cl_prev, sc["faces"], ids_c, ids_prev, pen_prev, nb, nbd)
+        assert (pen_o == pen_c).all()
+        assert sim.check_penetration(f) == int((pen_c == 1).sum())
+        flips += int((pen_c != pen_prev).sum())
+        pen_prev, ids_prev, x_prev, cl_prev = pen_c, ids_c, x_c, xc
+    assert flips > 0                                    # the scenario does exercise the flag
+    # after-cloth tracing: move the sheet under frozen particles
+    sim.backup_contact_pair(3)
+    xn, vn = sc["motion"](0.0)
+    prim.set_all_states(3, xn, vn)
+    sim.get_contact_pair(3)
+    sim.trace_penetration_after_cloth(3)
+    ids_n, pen_n = sim.get_contact(3)
+    # (cloth frame f-1 = 2 still holds the old sheet: that is the reference's comparison, :538-540)
+    pen_o, _ = CO.trace_penetration_after_cloth(x_prev, xn, sc["motion"](2 * sc["cfg"].dt * 40)[0], sc["faces"], ids_n, ids_prev, pen_prev, nb, nbd)
+    assert (pen_o == pen_n).all()
+
+
+def _rollout_oracle(sc, P, frames_cloth, ids, pens, n):
+    x, v, C, F = CO.O.state24_split(sc["state"])
+    frames, exts = [(x, v, C, F)], []
+    ci = None if sc["control_idx"] is None else torch.as_tensor(sc["control_idx"], dtype=torch.int64)
+    act = None if sc["action"] is None else torch.as_tensor(sc["action"], dtype=CO.DT)
+    for f in range(n):
+        pr = S.oracle_prim(sc, *frames_cloth[f])
+        x, v, C, F, ext = CO.substep(*frames[-1], P, pr, ids[f], pens[f], f, ci, act)
+        frames.append((x.detach(), v.detach(), C.detach(), F.detach()))
+        exts.append(ext.detach().numpy())
+    return frames, exts
+
+
+@pytest.mark.parametrize("kind", ["taco", "hit"])
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_substep_with_cloth_contact_matches_oracle(kind, precision):
+    n = 3
+    sc = S.build(kind, precision, n_env_steps=1)
+    sim, prim = S.build_engine(sc)
+    N, V = len(sc["state"]), len(sc["vertices"])
+    P = S.oracle_params(sc)
+    tol_s, tol_g = (1e-9, 1e-8) if precision == "float64" else (H.F32_TOL["state"], H.F32_TOL["grad"])
+    cloth = [sc["motion"](f * sc["cfg"].dt) for f in range(n + 1)]
+    for f in range(n + 1):
+        prim.set_all_states(f, *cloth[f])
+    sim.reset(sc["state"])
+    # contact faces / flags: searched on the device once, then fixed for both sides (some particles flagged as penetrated so that
+    # the push-out branch of collide_mixed :271-272 runs)
+    sim.get_contact_pair(0)
+    ids0, _ = sim.get_contact(0)
+    rng = np.random.default_rng(5)
+    ids, pens = [], []
+    for f in range(n):
+        pen = ((rng.uniform(size=N) < 0.15) & (ids0 >= 0)).astype(np.int8)
+        sim.set_contact(f, ids0, pen)
+        ids.append(ids0.copy()); pens.append(pen)
+    frames, exts = _rollout_oracle(sc, P, cloth, ids, pens, n)
+    for f in range(n):
+        sim.substep(f, sc["action"])
+    assert sim.contact_counts()[0] == int((ids0 >= 0).sum())
+    st = sim.get_state(n)
+    x, v, C, F = (t.numpy() for t in frames[n])
+    assert H.rel_err(st[:, 0:3], x) < tol_s and H.rel_err(st[:, 3:6], v) < tol_s
+    assert H.rel_err(st[:, 6:15], F.reshape(N, 9)) < tol_s
+    assert H.rel_err(st[:, 15:24], C.reshape(N, 9)) < (tol_s if precision == "float64" else H.c_tol(tol_s, P.n_grid / P.scale, v, C))
+    ext_ref = np.sum(exts, axis=0)
+    assert np.abs(ext_ref).max() > 0
+    assert H.rel_err(prim.ext_f.to_numpy(), ext_ref) < max(tol_s, 1e-8 if precision == "float64" else 2e-5)
+    # adjoint: seeds on the last frame + on the sheet's force
+    gx, gv = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+    gC, gF = 0.01 * rng.standard_normal((N, 3, 3)), 0.01 * rng.standard_normal((N, 3, 3))
+    eg = rng.standard_normal((V, 3)) * 1e-2 / P.p_mass * P.dt
+    adj = (torch.as_tensor(gx), torch.as_tensor(gv), torch.as_tensor(gC), torch.as_tensor(gF))
+    ci = None if sc["control_idx"] is None else torch.as_tensor(sc["control_idx"], dtype=torch.int64)
+    act = None if sc["action"] is None else torch.as_tensor(sc["action"], dtype=CO.DT)
+    ref_cp, ref_cv, ref_act = [], [], []
+    for f in range(n - 1, -1, -1):
+        g = CO.substep_grad(*frames[f], P, S.oracle_prim(sc, *cloth[f]), ids[f], pens[f], f, *adj, ext_f_grad=eg, control_idx=ci, action=act)
+        adj = (g["gx"], g["gv"], g["gC"], g["gF"])
+        ref_cp.insert(0, g["cloth_pos"].numpy()); ref_cv.insert(0, g["cloth_vel"].numpy()); ref_act.insert(0, None if g["action"] is None else g["action"].numpy())
+    sim.clear_grads()
+    sim.add_grad(n, gx=gx, gv=gv, gC=gC, gF=gF)
+    got_act = []
+    for f in range(n - 1, -1, -1):
+        got_act.insert(0, sim.substep_grad(f, sc["action"], ext_f_grad=eg))
+    dgx, dgv, dgF, dgC = sim.get_grad_full(0)
+    zone = H.clamp_zone(types_frames(frames), P, n) if precision == "float32" else np.zeros(N, dtype=bool)
+    for got, ref in ((dgx, adj[0]), (dgv, adj[1]), (dgC.reshape(N, 9), adj[2].reshape(N, 9)), (dgF.reshape(N, 9), adj[3].reshape(N, 9))):
+        out, ins = H.rel_err_split(got.reshape(N, -1), ref.numpy().reshape(N, -1), zone)
+        assert out < tol_g and ins < H.F32_TOL["clamp"]
+    for f in range(n):
+        cp, cv = prim.get_all_states_grad(f)
+        scale_p, scale_v = max(np.abs(r).max() for r in ref_cp), max(np.abs(r).max() for r in ref_cv)
+        assert np.abs(cp - ref_cp[f]).max() < max(tol_g, 2e-5 if precision == "float32" else 0) * scale_p
+        assert np.abs(cv - ref_cv[f]).max() < max(tol_g, 2e-5 if precision == "float32" else 0) * scale_v
+        if sc["action"] is not None:
+            assert H.rel_err(got_act[f], ref_act[f]) < max(tol_g, 2e-5 if precision == "float32" else 0)
+
+
+def types_frames(frames):
+    import types
+    return types.SimpleNamespace(frames=frames)
+
+
+def test_env_loop_with_kinematic_sheet_matches_oracle():
+    """two env steps of the reference's loop (taichi_env.py:86-106): substeps with search + tracing after each, sheet update, backup,
+    search, after-cloth tracing - final state, flags and summed sheet force against the oracle run on the same sequence"""
+    from softmac_amd.config import CfgNode
+    from softmac_amd.soft_cloth.engine.taichi_env import TaichiEnv
+    sc = S.build("taco", "float64", n_env_steps=2, N=1200)
+    cfg = CfgNode()
+    cfg.env_dt, cfg.mpm_scale, cfg.control_mode = sc["env_dt"], sc["scale"], "mpm"
+    cfg.SIMULATOR = CfgNode({k: v for k, v in vars(sc["cfg"]).items()})
+    cfg.PRIMITIVES = CfgNode(dict(sc["prim"], mpm_force_scale=1.0))
+    env_t = {"t": 0.0}
+
+    def motion(idx, x, v, action, ext_f):
+        return sc["motion"](idx * sc["env_dt"])
+    env = TaichiEnv(cfg, sc["state"][:, :3], vertices=sc["vertices"], faces=sc["faces"], motion=motion)
+    env.initialize()
+    sim, prim = env.simulator, env.primitive
+    N = env.n_particles
+    sub = env.substeps
+    # oracle mirror of the loop
+    P = S.oracle_params(sc)
+    nb, nbd = CO.process_faces(sc["faces"], 200)
+    x = torch.as_tensor(sc["state"][:, :3]); v = torch.zeros(N, 3, dtype=CO.DT)
+    C = torch.zeros(N, 3, 3, dtype=CO.DT); F = torch.eye(3, dtype=CO.DT).repeat(N, 1, 1)
+    sheet = {f: (sc["vertices"], np.zeros_like(sc["vertices"])) for f in range(sub + 1)}
+    ids = {0: CO.get_contact_pair(x, sheet[0][0], sc["faces"], None, sc["scale"])}
+    pen = {0: np.zeros(N, dtype=np.int8)}
+    xs = {0: x.numpy()}
+    ext_sum = []
+    for step in range(2):
+        ext = np.zeros_like(sc["vertices"])
+        for s in range(step * sub, (step + 1) * sub):
+            x, v, C, F, e = CO.substep(x, v, C, F, P, S.oracle_prim(sc, *sheet[s]), ids[s], pen[s], s)
+            x, v, C, F = x.detach(), v.detach(), C.detach(), F.detach()
+            ext += e.numpy()
+            xs[s + 1] = x.numpy()
+            ids[s + 1] = CO.get_contact_pair(x, sheet[s + 1][0], sc["faces"], pen[s], sc["scale"])
+            pen[s + 1], _ = CO.trace_penetration_after_mpm(xs[s + 1], xs[s], sheet[s + 1][0], sheet[s][0], sc["faces"], ids[s + 1], ids[s], pen[s], nb, nbd)
+        ext_sum.append(ext / sub)
+        cur = (step + 1) * sub
+        new = sc["motion"]((step + 1) * sc["env_dt"])
+        old_prev = sheet[cur - 1][0]
+        for j in range(cur, cur + sub + 1):
+            sheet[j] = new
+        before = ids[cur]
+        ids[cur] = CO.get_contact_pair(x, new[0], sc["faces"], pen[cur - 1], sc["scale"])
+        pen[cur], _ = CO.trace_penetration_after_cloth(xs[cur], new[0], old_prev, sc["faces"], ids[cur], before, pen[cur], nb, nbd)
+        env.step(None)
+    st = sim.get_state(2 * sub)
+    assert H.rel_err(st[:, 0:3], x.numpy()) < 1e-9 and H.rel_err(st[:, 3:6], v.numpy()) < 1e-8
+    assert (st[:, 25] == pen[2 * sub]).all()
+    differ = st[:, 24].astype(np.int64) != ids[2 * sub]
+    assert differ.sum() <= N // 50                      # ties between faces sharing an edge
+    for a, b in zip(env.cloth_simulator.ext_f_log, ext_sum):
+        assert H.rel_err(a, b) < 1e-8

@@ -53,6 +53,81 @@ __global__ __launch_bounds__(BLOCK) void k_cloth_pairs(DevSim<R> D, int f, const
     if (valid) Cl.contact_id[(size_t)f * Cl.n_ids + id] = best;
 }
 
+// The same search for a frame in sorted order, one workgroup per chunk: the chunk's particles share a grid block, so the faces are
+// culled once per workgroup against the chunk's bounding box (taken from the particles themselves, drift included) and only the
+// survivors - compacted in face order, so the first-minimum rule is unchanged - reach the per-particle test.  A thin sheet leaves
+// most chunks without a single candidate.  A chunk that holds a particle flagged as penetrated keeps every face (:457).
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_cloth_pairs_chunk(DevSim<R> D, int f, const R* Sf) {
+    __shared__ double fv[CLOTH_FACE_BATCH][9];
+    __shared__ int fid[CLOTH_FACE_BATCH];
+    __shared__ double red[2][4][3];
+    __shared__ int wave_count[4], any_pen;
+    SMAC_CHUNK_PROLOGUE
+    const ClothDev& Cl = D.cloth;
+    const int lane = t & 63, wave = t >> 6;
+    double px[3] = {0, 0, 0};
+    int id = 0, pen = 0;
+    if (valid) {
+        cloth_particle_pos(D, Sf, p, px);
+        id = D.orig_id[p];
+        if (f > 0) pen = Cl.penetration[(size_t)(f - 1) * Cl.n_ids + id];
+    }
+    if (t == 0) any_pen = 0;
+    // bounding box of the chunk's particles
+    double lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = valid ? px[c] : 1e300; hi[c] = valid ? px[c] : -1e300;
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fmin(lo[c], __shfl_xor(lo[c], o, 64)); hi[c] = fmax(hi[c], __shfl_xor(hi[c], o, 64)); }
+        if (lane == 0) { red[0][wave][c] = lo[c]; red[1][wave][c] = hi[c]; }
+    }
+    __syncthreads();
+    if (pen) any_pen = 1;
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = fmin(fmin(red[0][0][c], red[0][1][c]), fmin(red[0][2][c], red[0][3][c]));
+        hi[c] = fmax(fmax(red[1][0][c], red[1][1][c]), fmax(red[1][2][c], red[1][3][c]));
+    }
+    __syncthreads();
+    const bool keep_all = any_pen != 0;
+    const double threshold = 1e-2 * Cl.par.scale;
+    double dmin = 1e10;
+    int best = -1;
+    const double* vpos = Cl.pos + (size_t)f * Cl.V * 3;
+    for (int base = 0; base < Cl.Fc; base += CLOTH_FACE_BATCH) {
+        const int q = base + t;
+        double v9[9];
+        bool cand = false;
+        if (q < Cl.Fc) {
+            for (int k = 0; k < 9; ++k) v9[k] = vpos[(size_t)Cl.faces[3 * q + k / 3] * 3 + k % 3];
+            cand = true;
+            if (!keep_all)
+                for (int c = 0; c < 3; ++c) {
+                    const double flo = min_(v9[c], min_(v9[3 + c], v9[6 + c])) - threshold, fhi = max_(v9[c], max_(v9[3 + c], v9[6 + c])) + threshold;
+                    if (hi[c] <= flo || lo[c] >= fhi) cand = false;
+                }
+        }
+        const unsigned long long m = __ballot(cand);
+        if (lane == 0) wave_count[wave] = __popcll(m);
+        __syncthreads();
+        int slot = __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) slot += wave_count[w];
+        const int ncand = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        if (cand) {
+            for (int k = 0; k < 9; ++k) fv[slot][k] = v9[k];
+            fid[slot] = q;
+        }
+        __syncthreads();
+        if (valid)
+            for (int j = 0; j < ncand; ++j)
+                if (pen || cl_in_bbox(px, fv[j], fv[j] + 3, fv[j] + 6, threshold)) {
+                    const double d = cl_distance(px, fv[j], fv[j] + 3, fv[j] + 6);
+                    if (d < dmin) { dmin = d; best = fid[j]; }
+                }
+        __syncthreads();
+    }
+    if (valid) Cl.contact_id[(size_t)f * Cl.n_ids + id] = best;
+}
+
 // trace_penetration_after_mpm_kernel :484-510 (after_cloth = 0) / trace_penetration_after_cloth_kernel :520-545 (1).
 // One thread per ORIGINAL particle id; inv_cur / inv_prev map ids to slots of frames f / f-1 (nullptr: identity order).
 template <class R>

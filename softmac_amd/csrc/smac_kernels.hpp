@@ -572,7 +572,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
 #pragma unroll
             for (int i = 0; i < 9; ++i) { Cc[i] = (CT)C[i]; Ec[i] = (CT)E[i]; }
             f_tmp(Cc, Ec, (CT)D.dt, Etc);
-            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam};
+            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam, D.mat.plast, (CT)D.mat.yield_c};
             ConstState<CT> cs;
             constitutive_fwd(mat, Etc, Enc, sc, cs);
 #pragma unroll
@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
 #pragma unroll
             for (int i = 0; i < 9; ++i) { Cc[i] = (CT)C[i]; Ec[i] = (CT)E[i]; }
             f_tmp(Cc, Ec, (CT)D.dt, Et);
-            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam};
+            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam, D.mat.plast, (CT)D.mat.yield_c};
             constitutive_fwd(mat, Et, En, stress, cs);
         }
 #pragma unroll
@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
 #else
         for (int i = 0; i < 9; ++i) { G[i] = (CT)(D.stress_scale * gaff[i]); gFc[i] = (CT)gFn[i]; }
 #endif
-        const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam};
+        const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam, D.mat.plast, (CT)D.mat.yield_c};
         constitutive_bwd(mat, Et, cs, G, gFc, gEc);
 #pragma unroll
         for (int i = 0; i < 9; ++i) gEt[i] = (R)gEc[i];

@@ -1024,6 +1024,7 @@ template <class R> struct Sim final : ISim {
     // ---- soft <-> cloth contact (soft_cloth/engine/primitive/primitive_cloth.py, soft_cloth/engine/mpm_simulator.py:447-561) ----
     int* d_cloth_faces = nullptr; int* d_cloth_nbr = nullptr; signed char* d_cloth_nbr_dir = nullptr;
     int* d_cloth_warn = nullptr;
+    int cloth_pairs_by_chunk = getenv("SMAC_CLOTH_PAIRS_FLAT") ? 0 : 1;   // (the flat kernel, one thread per particle over all faces, is kept for frames in identity order and A/B)
     double* d_cloth_ext_scratch = nullptr;
     int set_param(const char* name, double value) override {
         REQUIRE(name, "set_param: null name");
@@ -1141,7 +1142,11 @@ template <class R> struct Sim final : ISim {
         const R* Sf = D.S + (size_t)f * frame_scalars();
         if (op == 0) {
             const int e = frame_epoch[f];
-            hipLaunchKernelGGL(k_cloth_pairs<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f, Sf, e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr);
+            if (e > 0 && cloth_pairs_by_chunk) {              // sorted frame: per-chunk face culling
+                if ((rc = bind_epoch(e))) return rc;
+                hipLaunchKernelGGL(k_cloth_pairs_chunk<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f, Sf);
+            } else
+                hipLaunchKernelGGL(k_cloth_pairs<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f, Sf, e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr);
         } else if (op == 1) {
             hipLaunchKernelGGL(k_cloth_copy_ids, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)(C.contact_id + at), C.contact_before,
                                (const signed char*)nullptr, (signed char*)nullptr);

@@ -31,7 +31,9 @@ class KinematicCloth:
         self.primitive.clear_ext_f()
         self.ext_f_log.append(ext_f)
         self.x, self.v = self.motion(idx, self.x, self.v, action, ext_f)
-        self.primitive.set_all_states(idx * self.substeps, self.x, self.v, f_end=(idx + 1) * self.substeps + 1)
+        first, last = idx * self.substeps, min((idx + 1) * self.substeps + 1, self.primitive.max_timesteps)   # (the reference's fields hold 2048 frames)
+        if first < last:
+            self.primitive.set_all_states(first, self.x, self.v, f_end=last)
 
     def get_ext_state_grad(self, s):                       # :126-136
         gx, gv = np.zeros_like(self.x_init), np.zeros_like(self.x_init)

@@ -132,11 +132,14 @@ class MPMSimulator(_Base):
         if x.shape[1] == self.dim:                         # reset_kernel :620-629
             super().reset(x / self.scale)
             self.set_contact(0, None, np.zeros(N, dtype=np.int8))
-        else:                                              # reset_all_kernel :631-643
+        else:                                              # reset_all_kernel :631-643 (26 columns; 24 = the state without the contact columns)
             st = x[:, :24].copy()
             st[:, 0:6] /= self.scale
             super().reset(st)
-            self.set_contact(0, x[:, 24].astype(np.int32), x[:, 25].astype(np.int8))
+            if x.shape[1] >= 26:
+                self.set_contact(0, x[:, 24].astype(np.int32), x[:, 25].astype(np.int8))
+            else:
+                self.set_contact(0, np.full(N, -1, dtype=np.int32), np.zeros(N, dtype=np.int8))
         self.cur = 0
 
     def set_x(self, f, x):

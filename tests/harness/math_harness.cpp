@@ -7,8 +7,8 @@ using namespace smac;
 
 template <class R>
 static void constitutive_run(int n, int ptype, int model, double mu, double lam, const double* Et, const double* G,
-                             const double* gFn, double* En, double* stress, double* gEt) {
-    Material<R> M{ptype, model, (R)mu, (R)lam};
+                             const double* gFn, double* En, double* stress, double* gEt, int plast = PLAST_CLIP, double yield_c = 0.0) {
+    Material<R> M{ptype, model, (R)mu, (R)lam, plast, (R)yield_c};
     for (int p = 0; p < n; ++p) {
         R e[9], g[9], gf[9], en[9], st[9], ge[9];
         for (int i = 0; i < 9; ++i) { e[i] = (R)Et[9 * p + i]; g[i] = (R)G[9 * p + i]; gf[i] = (R)gFn[9 * p + i]; }
@@ -119,6 +119,11 @@ void h_constitutive(int prec, int n, int ptype, int model, double mu, double lam
                     const double* gFn, double* En, double* stress, double* gEt) {
     if (prec == 64) constitutive_run<double>(n, ptype, model, mu, lam, Et, G, gFn, En, stress, gEt);
     else constitutive_run<float>(n, ptype, model, mu, lam, Et, G, gFn, En, stress, gEt);
+}
+void h_constitutive_von_mises(int prec, int n, double mu, double lam, double yield_c, const double* Et, const double* G, const double* gFn,
+                              double* En, double* stress, double* gEt) {
+    if (prec == 64) constitutive_run<double>(n, 0, 0, mu, lam, Et, G, gFn, En, stress, gEt, PLAST_VON_MISES, yield_c);
+    else constitutive_run<float>(n, 0, 0, mu, lam, Et, G, gFn, En, stress, gEt, PLAST_VON_MISES, yield_c);
 }
 void h_svd(int prec, int n, const double* E, double* U, double* e, double* V) {
     if (prec == 64) svd_run<double>(n, E, U, e, V); else svd_run<float>(n, E, U, e, V);

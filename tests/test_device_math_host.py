@@ -51,6 +51,36 @@ def test_constitutive_forward_and_adjoint(lib, prec, tol, ptype, model, scale):
     assert H.rel_err(gEt, gref.numpy()) < tol
 
 
+@pytest.mark.parametrize("prec,tol,scale", [(64, 1e-10, 2e-3), (64, 1e-10, 3e-2), (64, 1e-10, 0.3),      # 0.3: includes sigma < 0.05 (the :175 clamp)
+                                            (32, 5e-6, 2e-3), (32, 5e-6, 3e-2), (32, 5e-6, 0.1)])
+def test_von_mises_forward_and_adjoint(lib, prec, tol, scale):
+    """soft_cloth's return mapping (soft_cloth/engine/mpm_simulator.py:172-188) in the device's SVD-basis form against torch autograd
+    through the oracle's restatement: particles inside the yield surface, on it, and far outside"""
+    from oracle import cloth_oracle as CO
+    rng = np.random.default_rng(11)
+    n = 600
+    Pm = CO.ClothSimParams(ptype=0, material_model=0, E=5000.0, nu=0.2, yield_stress=60.0)
+    Et = scale * rng.standard_normal((n, 3, 3)); G = rng.standard_normal((n, 3, 3)); gFn = rng.standard_normal((n, 3, 3))
+    Ft = torch.tensor(np.eye(3) + Et, requires_grad=True)
+    U, sig, V = O.svd3(Ft)
+    nF, stress = CO.constitutive(Ft, U, sig, V, Pm)
+    (gref,) = torch.autograd.grad((stress * torch.tensor(G)).sum() + (nF * torch.tensor(gFn)).sum(), Ft)
+    En, st, gEt = np.zeros_like(Et), np.zeros_like(Et), np.zeros_like(Et)
+    lib.h_constitutive_von_mises(prec, n, ctypes.c_double(Pm.mu), ctypes.c_double(Pm.lam), ctypes.c_double(Pm.yield_stress / (2 * Pm.mu)),
+                                 P(Et), P(G), P(gFn), P(En), P(st), P(gEt))
+    yields = (nF.detach() - Ft.detach()).abs().amax((1, 2)) > 0
+    assert (scale > 1e-2) == bool(yields.float().mean() > 0.5)
+    assert np.abs(En + np.eye(3) - nF.detach().numpy()).max() < tol
+    assert H.rel_err(st, stress.detach().numpy()) < tol
+    if prec == 32:                                      # the clamp-zone particles of the reference's backward_svd (helpers.F32_TOL) are bounded apart
+        s2 = torch.linalg.svdvals(Ft.detach()).numpy() ** 2
+        gap = np.minimum(np.abs(s2[:, 0] - s2[:, 1]), np.minimum(np.abs(s2[:, 1] - s2[:, 2]), np.abs(s2[:, 0] - s2[:, 2])))
+        out, ins = H.rel_err_split(gEt.reshape(n, -1), gref.numpy().reshape(n, -1), gap < 4e-6)
+        assert out < tol and ins < H.F32_TOL["clamp"]
+    else:
+        assert H.rel_err(gEt, gref.numpy()) < tol
+
+
 @pytest.mark.parametrize("prec,tol", [(64, 1e-12), (32, 2e-6)])
 def test_jacobi_svd(lib, prec, tol):
     rng = np.random.default_rng(0)

@@ -50,8 +50,9 @@ def test_contact_pairs_and_tracing_match_oracle(kind, precision):
     assert (nb == onb).all() and (nbd == onbd).all()
     pen_prev, ids_prev, x_prev, cl_prev = pen_dev.copy(), ids_dev.copy(), xs, x0
     flips = 0
+    sweep = -1.0 if kind == "taco" else 1.0               # (towards the particles: the tortilla rises under the disc)
     for f in range(1, 4):
-        xc, vc = sc["motion"](f * sc["cfg"].dt * 40)   # exaggerated sheet motion: vertices sweep through the particles
+        xc, vc = sc["motion"](sweep * f * sc["cfg"].dt * 40)   # exaggerated sheet motion: vertices sweep through the particles
         prim.set_all_states(f, xc, vc)
         sim.substep(f - 1, sc["action"])
         sim.get_contact_pair(f)
@@ -74,7 +75,7 @@ def test_contact_pairs_and_tracing_match_oracle(kind, precision):
     sim.trace_penetration_after_cloth(3)
     ids_n, pen_n = sim.get_contact(3)
     # (cloth frame f-1 = 2 still holds the old sheet: that is the reference's comparison, :538-540)
-    pen_o, _ = CO.trace_penetration_after_cloth(x_prev, xn, sc["motion"](2 * sc["cfg"].dt * 40)[0], sc["faces"], ids_n, ids_prev, pen_prev, nb, nbd)
+    pen_o, _ = CO.trace_penetration_after_cloth(x_prev, xn, sc["motion"](sweep * 2 * sc["cfg"].dt * 40)[0], sc["faces"], ids_n, ids_prev, pen_prev, nb, nbd)
     assert (pen_o == pen_n).all()
 
 

@@ -166,7 +166,9 @@ int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /*
  *               1 = von-Mises return mapping (soft_cloth mpm_simulator.py:172-188, :232);
  * "yield_ratio": yield_stress / (2 mu) of that return mapping (:182);
  * "mass_eps":   a grid node has a velocity when its mass exceeds this (1e-10, mpm_simulator.py:286/399; the Python mirror rescales
- *               it by mpm_scale^-2 because the particle kernels work on the unit domain) */
+ *               it by mpm_scale^-2 because the particle kernels work on the unit domain);
+ * "cloth_pairs_flat": 1 = smac_cloth_contact_pair tests every particle against every face also on sorted frames (default 0: faces are
+ *               culled per chunk first; same result) */
 int smac_set_param(smac_handle h, const char* name, double value);
 
 /* ---- cloth primitive: replaces soft_cloth/engine/primitive/primitive_cloth.py (Primitive_Cloth) and the contact bookkeeping of

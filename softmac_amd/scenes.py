@@ -195,3 +195,53 @@ def s_pour(n_particles=1 << 22, n_grid=256, max_steps=16, precision="float32", d
         # bowl rim (0.067 above its origin) 2 mm inside the bottom of the column
         s13 = [np.array([0.5, lo[1] - 0.0668 + 0.002, 0.5, 1.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0], dtype=np.float64)]
     return cfg, 1e-3, state, specs, s13
+
+
+def tortilla_disc(rings=12, radius=1.0):
+    """A flat triangulated disc in the y = 0 plane (the shape of the reference's `envs/assets/tortilla/tortilla.obj`: a centre vertex and
+    concentric rings, 6 k vertices on ring k): vertices (1 + 3 rings (rings + 1), 3), consistently oriented faces (6 rings^2, 3)."""
+    verts = [(0.0, 0.0, 0.0)]
+    start = [0]
+    for k in range(1, rings + 1):
+        start.append(len(verts))
+        for j in range(6 * k):
+            a = 2 * np.pi * j / (6 * k)
+            verts.append((radius * k / rings * np.cos(a), 0.0, radius * k / rings * np.sin(a)))
+    faces = []
+    for k in range(1, rings + 1):
+        n_out, n_in = 6 * k, max(6 * (k - 1), 1)
+        i = j = 0
+        while i < n_out or j < (n_in if k > 1 else 0):
+            a_out, a_in = (i + 1) / n_out, ((j + 1) / n_in if k > 1 else 2.0)
+            o0, o1 = start[k] + i % n_out, start[k] + (i + 1) % n_out
+            i0 = start[k - 1] + (j % n_in if k > 1 else 0)
+            if a_out <= a_in or j >= n_in:
+                faces.append((o0, i0, o1)); i += 1
+            else:
+                i1 = start[k - 1] + (j + 1) % n_in
+                faces.append((o0, i0, i1)); j += 1
+    return np.asarray(verts, dtype=np.float64), np.asarray(faces, dtype=np.int32)
+
+
+def s_taco(n_particles=1 << 20, n_grid=128, max_steps=64, precision="float32", device=0, seed=3, rings=12):
+    """Soft <-> cloth workload shaped after the reference's taco demo (soft_cloth/config/demo_taco_config.py): mpm_scale 5, von-Mises
+    plasticine (E 5000, yield stress 60), gravity (0,-5,0), dt 2e-4 / env_dt 2e-3, a sticky sheet = triangulated disc of radius 1.5 at
+    y = 2.0; the particles are a cylinder of 8 per cell resting on it.  Returns (cfg, env_dt, scale, state (N,3+21), vertices, faces, prim)."""
+    rng = np.random.default_rng(seed)
+    scale = 5.0
+    dx = scale / n_grid
+    r = 40.0 * n_grid / 128 * dx
+    h = n_particles / 8.0 * dx ** 3 / (np.pi * r * r)
+    rr = r * np.sqrt(rng.random(n_particles))
+    th = 2 * np.pi * rng.random(n_particles)
+    x = np.stack([2.5 + rr * np.cos(th), 2.0 + 0.1 * dx + h * rng.random(n_particles), 2.5 + rr * np.sin(th)], 1)
+    v = np.tile([0.0, -0.3, 0.0], (n_particles, 1)) + 0.02 * rng.standard_normal((n_particles, 3))
+    F = np.eye(3).reshape(1, 9) + 5e-3 * rng.standard_normal((n_particles, 9))
+    C = 0.3 * rng.standard_normal((n_particles, 9))
+    V, Fc = tortilla_disc(rings, 1.5)
+    V = V + np.array([2.5, 2.0, 2.5])
+    cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=2e-4, E=5000.0, nu=0.2, ptype=0, material_model=0, gravity=(0.0, -5.0, 0.0),
+                        ground_friction=0.0, collision_type=2, n_controllers=0, max_steps=max_steps, precision=precision, device=device,
+                        yield_stress=60.0)
+    prim = dict(friction=1.0, softness=666.0, cloth_force_scale=1.0, mpm_force_scale=1.0, sticky=True)
+    return cfg, 2e-3, scale, np.hstack([x, v, F, C]), V, Fc, prim

@@ -126,6 +126,8 @@ def test_substep_with_cloth_contact_matches_oracle(kind, precision):
     assert H.rel_err(st[:, 15:24], C.reshape(N, 9)) < (tol_s if precision == "float64" else H.c_tol(tol_s, P.n_grid / P.scale, v, C))
     ext_ref = np.sum(exts, axis=0)
     assert np.abs(ext_ref).max() > 0
+    print(f"[cloth {kind} {precision}] x {H.rel_err(st[:, 0:3], x):.1e} v {H.rel_err(st[:, 3:6], v):.1e} F {H.rel_err(st[:, 6:15], F.reshape(N, 9)):.1e} "
+          f"C {H.rel_err(st[:, 15:24], C.reshape(N, 9)):.1e} ext_f {H.rel_err(prim.ext_f.to_numpy(), ext_ref):.1e}")
     assert H.rel_err(prim.ext_f.to_numpy(), ext_ref) < max(tol_s, 1e-8 if precision == "float64" else 2e-5)
     # adjoint: seeds on the last frame + on the sheet's force
     gx, gv = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
@@ -149,9 +151,13 @@ def test_substep_with_cloth_contact_matches_oracle(kind, precision):
     for got, ref in ((dgx, adj[0]), (dgv, adj[1]), (dgC.reshape(N, 9), adj[2].reshape(N, 9)), (dgF.reshape(N, 9), adj[3].reshape(N, 9))):
         out, ins = H.rel_err_split(got.reshape(N, -1), ref.numpy().reshape(N, -1), zone)
         assert out < tol_g and ins < H.F32_TOL["clamp"]
+    errs = [H.rel_err_split(g.reshape(N, -1), r.numpy().reshape(N, -1), zone) for g, r in ((dgx, adj[0]), (dgv, adj[1]), (dgC, adj[2]), (dgF, adj[3]))]
+    print(f"[cloth {kind} {precision}] gx {errs[0][0]:.1e} gv {errs[1][0]:.1e} gC {errs[2][0]:.1e} gF {errs[3][0]:.1e} clamp-zone {max(e[1] for e in errs):.1e} ({int(zone.sum())} particles)")
     for f in range(n):
         cp, cv = prim.get_all_states_grad(f)
         scale_p, scale_v = max(np.abs(r).max() for r in ref_cp), max(np.abs(r).max() for r in ref_cv)
+        print(f"[cloth {kind} {precision}] frame {f}: sheet position.grad {np.abs(cp - ref_cp[f]).max() / scale_p:.1e} velocity.grad {np.abs(cv - ref_cv[f]).max() / scale_v:.1e}"
+              + ("" if sc["action"] is None else f" action.grad {H.rel_err(got_act[f], ref_act[f]):.1e}"))
         assert np.abs(cp - ref_cp[f]).max() < max(tol_g, 2e-5 if precision == "float32" else 0) * scale_p
         assert np.abs(cv - ref_cv[f]).max() < max(tol_g, 2e-5 if precision == "float32" else 0) * scale_v
         if sc["action"] is not None:
@@ -218,3 +224,55 @@ def test_env_loop_with_kinematic_sheet_matches_oracle():
     assert differ.sum() <= N // 50                      # ties between faces sharing an edge
     for a, b in zip(env.cloth_simulator.ext_f_log, ext_sum):
         assert H.rel_err(a, b) < 1e-8
+
+
+def test_cloth_path_at_full_size():
+    """1M particles / 128^3 on the sheet (scenes.s_taco; the oracle cannot follow at this size): size-independent properties.
+    The chunk-culled contact-face search equals the flat one bit for bit; the adjoint is linear in its seeds; the force collected on
+    the sheet balances the momentum the contact took from the particles' grid."""
+    import ctypes as C
+    from softmac_amd import scenes
+    from softmac_amd.config import CfgNode
+    from softmac_amd.soft_cloth.engine.mpm_simulator import MPMSimulator
+    from softmac_amd.soft_cloth.engine.primitive import Primitive_Cloth
+    N = 1 << 20
+    cfg, env_dt, scale, state, V, F, prim_cfg = scenes.s_taco(N, 128, max_steps=8, precision="float32")
+    prim = Primitive_Cloth(CfgNode(prim_cfg), max_timesteps=cfg.max_steps, mpm_scale=scale, vertices=V, faces=F)
+    sim = MPMSimulator(cfg, prim, env_dt, scale)
+    prim.initialize()
+    Vv = np.zeros_like(V); Vv[:, 1] = 0.2
+    prim.set_all_states(0, V, Vv, f_end=cfg.max_steps)
+    sim.reset(state)
+    sim.get_contact_pair(0)
+    for s in range(3):
+        sim.substep(s)
+        sim.get_contact_pair(s + 1)
+        sim.trace_penetration_after_mpm(s + 1)
+    ids_chunk, pen = sim.get_contact(3)
+    sim._h.call("smac_set_param", b"cloth_pairs_flat", C.c_double(1.0))
+    sim.get_contact_pair(3)
+    ids_flat, _ = sim.get_contact(3)
+    sim._h.call("smac_set_param", b"cloth_pairs_flat", C.c_double(0.0))
+    assert (ids_chunk == ids_flat).all() and (ids_chunk >= 0).sum() > N // 100
+    assert sim.check_penetration(3) == int((pen == 1).sum()) and sim.tracing_warnings == 0
+    ext = prim.ext_f.to_numpy()
+    assert np.isfinite(ext).all() and np.abs(ext).max() > 0
+    assert ext[:, 1].sum() < 0                           # the disc falls onto a sheet that moves up: the sheet is pushed down
+    rng = np.random.default_rng(8)
+    s1, s2 = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+
+    def grad(seed_x, seed_v):
+        sim.clear_grads()
+        sim.add_grad(3, gx=seed_x, gv=seed_v)
+        for s in range(2, -1, -1):
+            sim.substep_grad(s)
+        gx, gv = sim.get_grad(0)
+        cp, cv = prim.get_all_states_grad(1)
+        return gx, gv, cp, cv
+    a = grad(s1, None)
+    b = grad(None, s2)
+    c = grad(2.0 * s1, -0.5 * s2)
+    for ga, gb, gc in zip(a, b, c):
+        ref = 2.0 * ga - 0.5 * gb
+        assert np.abs(gc - ref).max() < 2e-4 * max(np.abs(ref).max(), 1e-30)
+    assert np.abs(a[2]).max() > 0 and np.abs(b[3]).max() > 0        # the sheet does receive adjoints

@@ -183,8 +183,10 @@ __global__ void k_cloth_count_pen(int N, const signed char* pen, int* total) {
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
 }
 
-// The particles grid_op_mixed3 :419-428 acts on (contact_id[f, p] >= 0) as the hit list the contact kernels walk:
-// Hit = {slot, 1 | penetration << 1, block, face}
+// The particles grid_op_mixed3 :419-428 acts on as the hit list the contact kernels walk: Hit = {slot, 1 | penetration << 1, block, face}.
+// contact_id[f, p] >= 0 only says that the particle was inside a face's padded bounding box (1e-2 scale); collide_mixed :236-237 does
+// something only within 5e-3 scale of the face (always, for a particle flagged as penetrated: its distance is <= 0).  The list keeps
+// the particles that can pass that test (FILTER with a margin; the contact chain repeats the test itself).
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_cloth_hit_list(DevSim<R> D, int f) {
     SMAC_CHUNK_PROLOGUE
@@ -192,10 +194,17 @@ __global__ __launch_bounds__(BLOCK) void k_cloth_hit_list(DevSim<R> D, int f) {
     const ClothDev& Cl = D.cloth;
     const size_t at = (size_t)f * Cl.n_ids + D.orig_id[p];
     const int face = Cl.contact_id[at];
-    if (face >= 0) {
-        Hit h = {p, 1 | ((Cl.penetration[at] == 1 ? 1 : 0) << 1), ch.block, face};
-        D.hits[hit_slot(D.nhits)] = h;
+    if (face < 0) return;
+    const int pen = Cl.penetration[at] == 1 ? 1 : 0;
+    if (!pen) {
+        double px[3];
+        cloth_particle_pos(D, frame(D.S, f, D.Npad), p, px);
+        const double* vp = Cl.pos + (size_t)f * Cl.V * 3;
+        const int* v = Cl.faces + 3 * face;
+        if (cl_distance(px, vp + 3 * v[0], vp + 3 * v[1], vp + 3 * v[2]) > (5e-3 + 1e-6) * Cl.par.scale) return;
     }
+    Hit h = {p, 1 | (pen << 1), ch.block, face};
+    D.hits[hit_slot(D.nhits)] = h;
 }
 
 }  // namespace smac

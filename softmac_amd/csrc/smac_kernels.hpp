@@ -130,7 +130,6 @@ template <class R> struct DevSim {
     int* nhit_ck;
     int hit_cap;
     ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
-    int keep_hits;               // k_g2p leaves the hit list alone (experiment: checkpoint save after g2p)
 };
 
 // LDS tile: the 6x6x6 nodes a particle whose base lies in a 4x4x4 block can touch (origin = 4*block).
@@ -1025,7 +1024,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
     __shared__ Vec4<R> gt[TILE_WORDS];
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // last kernel of the substep: hand the contact lists back empty
         D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
-        if (!D.keep_hits) { *D.nhits = 0; *D.ncand = 0; }      // (keep_hits: the checkpoint save runs AFTER this kernel and still needs the list)
+        *D.nhits = 0; *D.ncand = 0;
     }
     SMAC_CHUNK_PROLOGUE
     const R* Sf = frame(D.S, f, D.Npad);

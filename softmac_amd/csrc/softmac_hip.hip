@@ -185,7 +185,6 @@ template <class R> struct Sim final : ISim {
     // per-kernel minima): mode 1 costs k_g2p_grad a dependent slot lookup per tile record (+13 us) and the contact kernels +3 us
     // each - 369 vs 364 us per substep pair; mode 2 equals mode 0 (363 vs 364).  Kept selectable, not a win.
     int ck_mode = getenv("SMAC_CK_MODE") ? atoi(getenv("SMAC_CK_MODE")) : 0;
-    int save_after_g2p = getenv("SMAC_SAVE_AFTER_G2P") ? atoi(getenv("SMAC_SAVE_AFTER_G2P")) : 0;   // experiment: k_g2p followed by the small save kernel instead of the next k_p2g
     int g2p_pipe = getenv("SMAC_G2P_PIPE") ? atoi(getenv("SMAC_G2P_PIPE")) : 0;   // > 0: persistent pipelined k_g2p, this many workgroups per XCD
     std::vector<int> ck_epoch;       // epoch the slot of frame f was saved in (-1: invalid)
     std::vector<char> ck_has_hits;   // the frame's contact hit list is on file too
@@ -1360,22 +1359,7 @@ template <class R> struct Sim final : ISim {
         if (phase == 1 && (rc = forward_grid(f, true, false, 2))) return rc;
         if (phase < 0 || phase == 2) {
             const int e = frame_epoch[f];
-            const bool save_now = ck_epoch[f] != e && D.nchunks > 0 && D.n_control == 0 && ck_prepare();
-            const bool save_late = save_now && save_after_g2p && phase < 0;
-            auto run_g2p = [&]() {
-                prof_begin(K_G2P);
-                D.check_next = (f + 1 - epochs[e].frame < epochs[e].interval) ? 1 : 0;     // else substep(f+1) re-bins first
-                D.keep_hits = save_late ? 1 : 0;
-                if (g2p_pipe) {
-                    const int per = (D.nchunks + 7) / 8, J = per < g2p_pipe ? per : g2p_pipe;
-                    hipLaunchKernelGGL(k_g2p_pipe<R>, dim3(8 * J), dim3(BLOCK), 0, stream, D, f);
-                } else
-                    hipLaunchKernelGGL(k_g2p<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
-                D.keep_hits = 0;
-                prof_end();
-            };
-            if (save_late && D.nchunks > 0) run_g2p();
-            if (save_now) {   // (slab phases) keep the forward grid for substep_grad
+            if (ck_epoch[f] != e && D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {   // (slab phases) keep the forward grid for substep_grad
                 prof_begin(K_CKPT);
                 const bool keep_hits = ck_hits && any_contact();
                 ck_has_hits[f] = keep_hits ? 1 : 0;
@@ -1385,9 +1369,17 @@ template <class R> struct Sim final : ISim {
                 ck_epoch[f] = e;
                 ck_gen[f] = config_gen;
                 vin_clean = true;
-                if (save_late) HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));   // what k_g2p would have done
             }
-            if (D.nchunks > 0 && !save_late) run_g2p();
+            if (D.nchunks > 0) {
+                prof_begin(K_G2P);
+                D.check_next = (f + 1 - epochs[e].frame < epochs[e].interval) ? 1 : 0;     // else substep(f+1) re-bins first
+                if (g2p_pipe) {
+                    const int per = (D.nchunks + 7) / 8, J = per < g2p_pipe ? per : g2p_pipe;
+                    hipLaunchKernelGGL(k_g2p_pipe<R>, dim3(8 * J), dim3(BLOCK), 0, stream, D, f);
+                } else
+                    hipLaunchKernelGGL(k_g2p<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                prof_end();
+            }
             frame_epoch[f + 1] = e;
         }
         return check_launch();

@@ -118,7 +118,8 @@ def test_substep_with_cloth_contact_matches_oracle(kind, precision):
     frames, exts = _rollout_oracle(sc, P, cloth, ids, pens, n)
     for f in range(n):
         sim.substep(f, sc["action"])
-    assert sim.contact_counts()[0] == int((ids0 >= 0).sum())
+    nhit = sim.contact_counts()[0]                       # particles the contact kernels walked: those that can be inside the 5e-3 band
+    assert int(pens[n - 1].sum()) < nhit <= int((ids0 >= 0).sum())
     st = sim.get_state(n)
     x, v, C, F = (t.numpy() for t in frames[n])
     assert H.rel_err(st[:, 0:3], x) < tol_s and H.rel_err(st[:, 3:6], v) < tol_s
@@ -126,9 +127,9 @@ def test_substep_with_cloth_contact_matches_oracle(kind, precision):
     assert H.rel_err(st[:, 15:24], C.reshape(N, 9)) < (tol_s if precision == "float64" else H.c_tol(tol_s, P.n_grid / P.scale, v, C))
     ext_ref = np.sum(exts, axis=0)
     assert np.abs(ext_ref).max() > 0
-    print(f"[cloth {kind} {precision}] x {H.rel_err(st[:, 0:3], x):.1e} v {H.rel_err(st[:, 3:6], v):.1e} F {H.rel_err(st[:, 6:15], F.reshape(N, 9)):.1e} "
+    print(f"\n[cloth {kind} {precision}] x {H.rel_err(st[:, 0:3], x):.1e} v {H.rel_err(st[:, 3:6], v):.1e} F {H.rel_err(st[:, 6:15], F.reshape(N, 9)):.1e} "
           f"C {H.rel_err(st[:, 15:24], C.reshape(N, 9)):.1e} ext_f {H.rel_err(prim.ext_f.to_numpy(), ext_ref):.1e}")
-    assert H.rel_err(prim.ext_f.to_numpy(), ext_ref) < max(tol_s, 1e-8 if precision == "float64" else 2e-5)
+    assert H.rel_err(prim.ext_f.to_numpy(), ext_ref) < (1e-8 if precision == "float64" else tol_s)
     # adjoint: seeds on the last frame + on the sheet's force
     gx, gv = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
     gC, gF = 0.01 * rng.standard_normal((N, 3, 3)), 0.01 * rng.standard_normal((N, 3, 3))
@@ -152,16 +153,16 @@ def test_substep_with_cloth_contact_matches_oracle(kind, precision):
         out, ins = H.rel_err_split(got.reshape(N, -1), ref.numpy().reshape(N, -1), zone)
         assert out < tol_g and ins < H.F32_TOL["clamp"]
     errs = [H.rel_err_split(g.reshape(N, -1), r.numpy().reshape(N, -1), zone) for g, r in ((dgx, adj[0]), (dgv, adj[1]), (dgC, adj[2]), (dgF, adj[3]))]
-    print(f"[cloth {kind} {precision}] gx {errs[0][0]:.1e} gv {errs[1][0]:.1e} gC {errs[2][0]:.1e} gF {errs[3][0]:.1e} clamp-zone {max(e[1] for e in errs):.1e} ({int(zone.sum())} particles)")
+    print(f"\n[cloth {kind} {precision}] gx {errs[0][0]:.1e} gv {errs[1][0]:.1e} gC {errs[2][0]:.1e} gF {errs[3][0]:.1e} clamp-zone {max(e[1] for e in errs):.1e} ({int(zone.sum())} particles)")
     for f in range(n):
         cp, cv = prim.get_all_states_grad(f)
         scale_p, scale_v = max(np.abs(r).max() for r in ref_cp), max(np.abs(r).max() for r in ref_cv)
         print(f"[cloth {kind} {precision}] frame {f}: sheet position.grad {np.abs(cp - ref_cp[f]).max() / scale_p:.1e} velocity.grad {np.abs(cv - ref_cv[f]).max() / scale_v:.1e}"
               + ("" if sc["action"] is None else f" action.grad {H.rel_err(got_act[f], ref_act[f]):.1e}"))
-        assert np.abs(cp - ref_cp[f]).max() < max(tol_g, 2e-5 if precision == "float32" else 0) * scale_p
-        assert np.abs(cv - ref_cv[f]).max() < max(tol_g, 2e-5 if precision == "float32" else 0) * scale_v
+        assert np.abs(cp - ref_cp[f]).max() < tol_g * scale_p          # (measured in f32: 2e-8 ... 7e-7, profiles/r02_s_cloth_f32_errors.txt)
+        assert np.abs(cv - ref_cv[f]).max() < tol_g * scale_v
         if sc["action"] is not None:
-            assert H.rel_err(got_act[f], ref_act[f]) < max(tol_g, 2e-5 if precision == "float32" else 0)
+            assert H.rel_err(got_act[f], ref_act[f]) < tol_g
 
 
 def types_frames(frames):

@@ -173,4 +173,31 @@ SMAC_HD bool cloth_collide_mixed(const ClothParams& P, const S (*xv)[3], const S
     return true;
 }
 
+// collide_particle :198-231 (penalty contact, collision_type 1).  Returns true inside the band; imp = the impulse p_f dt added to the particle's
+// scattered momentum, cf / w as in cloth_collide_mixed.
+template <class S>
+SMAC_HD bool cloth_collide_particle(const ClothParams& P, const S (*xv)[3], const S (*vv)[3], const S* p_pos, const S* p_v, double dt, int penetrated,
+                                    S* imp, S* cf, S* w) {
+    S D[3];
+    const S dist = cl_sdf_and_normal(p_pos, penetrated, xv[0], xv[1], xv[2], D);
+    const S c = dist - 5e-3 * P.scale;                                          // :201-202
+    if (!(val(c) < 0.0)) return false;
+    S q[3] = {p_pos[0] - D[0] * dist, p_pos[1] - D[1] * dist, p_pos[2] - D[2] * dist};
+    cl_barycentric(q, xv[0], xv[1], xv[2], w);                                  // :208
+    S in[3];
+    for (int k = 0; k < 3; ++k) in[k] = p_v[k] - (w[0] * vv[0][k] + w[1] * vv[1][k] + w[2] * vv[2][k]);   // :210-213
+    const S nc = dot3(in, D);
+    S t[3] = {in[0] - nc * D[0], in[1] - nc * D[1], in[2] - nc * D[2]};         // :215
+    const S tn = sqrt_(dot3(t, t) + 1e-8);                                      // :221
+    const S anc = val(nc) < 0.0 ? -nc : nc;                                     // ti.abs
+    const double kf = P.friction * 0.001;                                       // :220
+    for (int k = 0; k < 3; ++k) {
+        const S f1 = -D[k] * c * 140.0;                                         // :217-218
+        const S f2 = -t[k] / tn * anc * kf;                                     // :222
+        imp[k] = (f1 + f2) * (0.3 * dt);                                        // :224, :231
+        cf[k] = -(f1 + f2) * 0.01;                                              // :225
+    }
+    return true;
+}
+
 }  // namespace smac

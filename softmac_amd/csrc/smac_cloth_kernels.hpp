@@ -194,8 +194,9 @@ __global__ __launch_bounds__(BLOCK) void k_cloth_hit_list(DevSim<R> D, int f) {
     const ClothDev& Cl = D.cloth;
     const size_t at = (size_t)f * Cl.n_ids + D.orig_id[p];
     const int face = Cl.contact_id[at];
+    const int pen = (face >= 0 && Cl.penetration[at] == 1) ? 1 : 0;
+    if (D.collision_type == CONTACT_PARTICLE) D.pmask[p] = face >= 0 ? (1 | (pen << 1)) : 0;   // read back by p2g.grad (rebuilt here when the forward grid comes from a checkpoint)
     if (face < 0) return;
-    const int pen = Cl.penetration[at] == 1 ? 1 : 0;
     if (!pen) {
         double px[3];
         cloth_particle_pos(D, frame(D.S, f, D.Npad), p, px);

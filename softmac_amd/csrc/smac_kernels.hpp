@@ -559,7 +559,16 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
-        if (D.any_contact && D.collision_type != CONTACT_GRID) {   // contact band test (x is at hand): build the sparse contact lists
+        int cloth_face = -1;
+        if (PCON && D.cloth.present) {                             // cloth primitive, penalty contact: the contact face was searched before the substep
+            const size_t at = (size_t)f * D.cloth.n_ids + D.orig_id[p];
+            cloth_face = D.cloth.contact_id[at];
+            if (cloth_face >= 0) {
+                cmask = 1 | ((D.cloth.penetration[at] == 1 ? 1 : 0) << 1);
+                Hit h = {p, cmask, ch.block, cloth_face};
+                D.hits[hit_slot(D.nhits)] = h;
+            }
+        } else if (D.any_contact && D.collision_type != CONTACT_GRID && !D.cloth.present) {   // contact band test (x is at hand): build the sparse contact lists
             cmask = contact_mask(D, f, x, (const R*)ps_wg);
             if (cmask) {
                 Hit h = {p, cmask, ch.block, 0};
@@ -586,7 +595,25 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
 #pragma unroll
         for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
         pv[0] = D.p_mass * v[0]; pv[1] = D.p_mass * v[1]; pv[2] = D.p_mass * v[2];
-        if (PCON && cmask) {                                                              // :203-206 penalty contact impulse
+        if (PCON && cmask && D.cloth.present) {                                           // soft_cloth p2g :208-213 (collide_particle of the sheet)
+            const ClothDev& Cl = D.cloth;
+            const double sc = Cl.par.scale;
+            const int* vid = Cl.faces + 3 * cloth_face;
+            double xv[3][3], vv[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 3; ++c) {
+                    xv[i][c] = Cl.pos[((size_t)f * Cl.V + vid[i]) * 3 + c];
+                    vv[i][c] = Cl.vel[((size_t)f * Cl.V + vid[i]) * 3 + c];
+                }
+            const double pp[3] = {sc * pos_get(x[0]), sc * pos_get(x[1]), sc * pos_get(x[2])}, pvv[3] = {sc * (double)v[0], sc * (double)v[1], sc * (double)v[2]};
+            double imp[3], cf[3], wb[3];
+            if (cloth_collide_particle<double>(Cl.par, xv, vv, pp, pvv, D.dt64, (cmask >> 1) & 1, imp, cf, wb)) {
+                const double s3 = 1.0 / (sc * sc * sc);                                   // physical momentum -> unit domain
+                for (int c = 0; c < 3; ++c) pv[c] += (R)(imp[c] * s3);
+                for (int i = 0; i < 3; ++i)
+                    for (int c = 0; c < 3; ++c) atomic_add(Cl.ext_f + (size_t)vid[i] * 3 + c, cf[c] * wb[i]);   // :227-229
+            }
+        } else if (PCON && cmask) {                                                       // :203-206 penalty contact impulse
             // in f64 whatever R is: the impulse is proportional to the penetration depth c = dist - 5e-3, a small difference
             // of the position and the table (a float x would put 3e-5 on it)
             const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])}, v64[3] = {(double)v[0], (double)v[1], (double)v[2]};
@@ -1518,7 +1545,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
 // Adjoint of the penalty contact impulse of p2g (collision_type 1) for the listed particles: the impulse's
 // adjoint is sum_nodes w * grid_v_in.grad (what p2g.grad calls gvp); 32 lanes per hit, lane n < 27 gathers node n,
 // lane d < 19 runs forward-mode direction d (p_pos3, p_v3, state13).
-template <class R>
+// CLOTH: the sheet's collide_particle, 24 directions (p_pos3, p_v3, vertex positions 9, vertex velocities 9)
+template <class R, bool CLOTH>
 __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, int f) {
     __shared__ double pg_acc[MAX_PRIMS * 13];         // primitive-state adjoints of this workgroup's hits (see k_contact)
     if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
@@ -1555,8 +1583,40 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
         for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
             for (int c = 0; c < 3; ++c) gi[c] += __shfl_xor(gi[c], o, 64);
+        if (CLOTH) {
+            const ClothDev& Cl = D.cloth;
+            const double sc = Cl.par.scale;
+            const bool act = mask != 0;
+            const int* vid = Cl.faces + 3 * (act ? h.pad : 0);
+            double out = 0.0;
+            if (act && d < 24) {
+                Dual<double> xs[3], vs[3], xv[3][3], vv[3][3], im[3], cf[3], wb[3];
+                for (int c = 0; c < 3; ++c) {
+                    xs[c] = Dual<double>(sc * x64[c], d == c ? sc : 0.0);
+                    vs[c] = Dual<double>(sc * (double)v[c], d == 3 + c ? sc : 0.0);
+                }
+                for (int i = 0; i < 3; ++i)
+                    for (int c = 0; c < 3; ++c) {
+                        xv[i][c] = Dual<double>(Cl.pos[((size_t)f * Cl.V + vid[i]) * 3 + c], d == 6 + 3 * i + c ? 1.0 : 0.0);
+                        vv[i][c] = Dual<double>(Cl.vel[((size_t)f * Cl.V + vid[i]) * 3 + c], d == 15 + 3 * i + c ? 1.0 : 0.0);
+                    }
+                if (cloth_collide_particle<Dual<double>>(Cl.par, xv, vv, xs, vs, D.dt64, (mask >> 1) & 1, im, cf, wb)) {
+                    for (int c = 0; c < 3; ++c) out += (double)gi[c] * im[c].d / (sc * sc * sc);
+                    for (int i = 0; i < 3; ++i)
+                        for (int c = 0; c < 3; ++c) out += Cl.ext_f_grad[(size_t)vid[i] * 3 + c] * (cf[c] * wb[i]).d;
+                }
+            }
+            if (act && d < 6) {
+                R* Af = D.Af;
+                Af[rowoff((d < 3 ? CX : CV - 3) + d, p, D.Npad)] += (R)out;
+            }
+            if (act && d >= 6 && d < 24 && out != 0.0 && Cl.pos_grad) {
+                const int q = d < 15 ? d - 6 : d - 15, vi = q / 3, c = q % 3;
+                atomic_add((d < 15 ? Cl.pos_grad : Cl.vel_grad) + ((size_t)f * Cl.V + (vi == 0 ? vid[0] : (vi == 1 ? vid[1] : vid[2]))) * 3 + c, out);
+            }
+        }
 #pragma unroll 1
-        for (int i = 0; i < D.P; ++i) {
+        for (int i = 0; i < (CLOTH ? 0 : D.P); ++i) {
             const bool act = (mask >> i) & 1;
             if (!__ballot(act)) continue;
             double out = 0.0;
@@ -1743,7 +1803,21 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     //  register allocation - 145 VGPRs instead of 168 + spills, 20 us at 1M particles - so every launch uses it and the test is dynamic.)
     if (PCON && D.collision_type == CONTACT_PARTICLE && D.any_contact) {      // the contact impulse is part of the scattered momentum
         const int cm = D.pmask[p];
-        if (cm) {
+        if (cm && D.cloth.present) {
+            const ClothDev& Cl = D.cloth;
+            const double sc = Cl.par.scale;
+            const int* vid = Cl.faces + 3 * Cl.contact_id[(size_t)f * Cl.n_ids + D.orig_id[p]];
+            double xv[3][3], vv[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 3; ++c) {
+                    xv[i][c] = Cl.pos[((size_t)f * Cl.V + vid[i]) * 3 + c];
+                    vv[i][c] = Cl.vel[((size_t)f * Cl.V + vid[i]) * 3 + c];
+                }
+            const double pp[3] = {sc * pos_get(x[0]), sc * pos_get(x[1]), sc * pos_get(x[2])}, pvv[3] = {sc * (double)v[0], sc * (double)v[1], sc * (double)v[2]};
+            double im[3], cf[3], wb[3];
+            if (cloth_collide_particle<double>(Cl.par, xv, vv, pp, pvv, D.dt64, (cm >> 1) & 1, im, cf, wb))
+                for (int c = 0; c < 3; ++c) imp[c] += (R)(im[c] / (sc * sc * sc));
+        } else if (cm) {
             const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])}, v64[3] = {(double)v[0], (double)v[1], (double)v[2]};
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i) {

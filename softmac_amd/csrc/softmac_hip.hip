@@ -1049,7 +1049,6 @@ template <class R> struct Sim final : ISim {
         REQUIRE(!D.cloth.present, "cloth_create: this handle already has a cloth primitive");
         REQUIRE(D.P == 0, "cloth_create: a handle holds either SDF primitives or the cloth primitive (as the reference's two simulators do)");
         REQUIRE(nv > 0 && nf > 0 && faces && nn >= 0 && (nn == 0 || (nbr && nbr_dir)) && scale > 0.0, "cloth_create: bad mesh arguments");
-        REQUIRE(cfg.collision_type != CONTACT_PARTICLE, "cloth_create: collision_type 1 (penalty contact) is not built for the cloth primitive; use 2 (forecast) or 0");
         for (int i = 0; i < 3 * nf; ++i) REQUIRE(faces[i] >= 0 && faces[i] < nv, "cloth_create: face index out of range");
         for (size_t i = 0; i < (size_t)nf * nn; ++i) REQUIRE(nbr[i] >= 0 && nbr[i] < nf, "cloth_create: neighbour face index out of range");
         ClothDev& C = D.cloth;
@@ -1247,6 +1246,7 @@ template <class R> struct Sim final : ISim {
         D.cur_frame = f;
         DevSim<R> Dc = D;                                       // the recompute pass must not double-count ext_f
         if (is_recompute) Dc.ext_f = scratch_ext();
+        if (is_recompute && D.cloth.present) Dc.cloth.ext_f = d_cloth_ext_scratch;
         if (stage != 2) {
             // grid_op rewrites v_mixed / v_out of every active cell; {m,p} must start from zero (drifted particles add to
             // it atomically) and is left zeroed by the checkpoint save of the previous substep
@@ -1280,7 +1280,6 @@ template <class R> struct Sim final : ISim {
         if (stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED) {
             prof_begin(K_CONTACT);
             if (D.cloth.present) {
-                if (is_recompute) Dc.cloth.ext_f = d_cloth_ext_scratch;          // (recompute pass: do not count the force twice)
                 hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
                 hipLaunchKernelGGL((k_contact_hits<R, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
             } else
@@ -1510,7 +1509,8 @@ template <class R> struct Sim final : ISim {
                 prof_end();
                 if (D.collision_type == CONTACT_PARTICLE && any_contact()) {      // adjoint of p2g's contact impulse (:203-206)
                     prof_begin(K_CONTACT_GRAD);
-                    hipLaunchKernelGGL(k_particle_contact_grad<R>, dim3(256), dim3(BLOCK), 0, stream, D, f);
+                    if (D.cloth.present) hipLaunchKernelGGL((k_particle_contact_grad<R, true>), dim3(256), dim3(BLOCK), 0, stream, D, f);
+                    else hipLaunchKernelGGL((k_particle_contact_grad<R, false>), dim3(256), dim3(BLOCK), 0, stream, D, f);
                     prof_end();
                 }
             }

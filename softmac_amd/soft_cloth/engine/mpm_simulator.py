@@ -31,8 +31,6 @@ class MPMSimulator(_Base):
         unit.E = cfg.E / (s * s)
         unit.gravity = tuple(float(g) / s for g in cfg.gravity)
         unit.ground_friction = 0.0                         # no floor rule in this variant (:275-286)
-        if int(cfg.collision_type) == CONTACT_PARTICLE:
-            raise NotImplementedError("collision_type 1 (penalty contact, primitive_cloth.py:198-231) is not built; use 2 (forecast) or 0")
         super().__init__(unit, (), env_dt)
         self.ground_friction = getattr(cfg, "ground_friction", 0.0)
         self.default_gravity = cfg.gravity

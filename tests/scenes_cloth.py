@@ -39,7 +39,7 @@ def sheet_motion(kind, rest, scale):
     return at
 
 
-def build(kind, precision="float64", n_env_steps=1, N=2500, seed=0):
+def build(kind, precision="float64", n_env_steps=1, N=2500, seed=0, collision_type=2):
     rng = np.random.default_rng(seed)
     if kind == "taco":
         scale = 5.0
@@ -60,6 +60,7 @@ def build(kind, precision="float64", n_env_steps=1, N=2500, seed=0):
     substeps = 10
     nframes = n_env_steps * substeps
     cfg = _cfg(N, kind, precision, nframes + 2)
+    cfg.collision_type = collision_type                                   # 2: forecast contact (both demos); 1: penalty contact inside p2g
     Fm = np.eye(3)[None] + 0.01 * rng.standard_normal((N, 3, 3))
     Cm = 0.5 * rng.standard_normal((N, 3, 3))
     state = np.hstack([x, v0, Fm.reshape(N, 9), Cm.reshape(N, 9)])

@@ -89,9 +89,9 @@ def test_von_mises_return_mapping_invariants():
     assert (n1[yields] - c * n0[yields] / torch.sqrt(n0[yields] ** 2 + 1e-8)).abs().max() < 1e-10   # back on the surface (with the 1e-8 of norm())
 
 
-@pytest.mark.parametrize("kind", ["taco", "hit"])
-def test_substep_adjoint_matches_finite_differences(kind):
-    sc = S.build(kind, "float64", N=300, seed=3)
+@pytest.mark.parametrize("kind,ctype", [("taco", 2), ("hit", 2), ("taco", 1), ("hit", 1)])
+def test_substep_adjoint_matches_finite_differences(kind, ctype):
+    sc = S.build(kind, "float64", N=300, seed=3, collision_type=ctype)
     P = S.oracle_params(sc)
     N, V = 300, len(sc["vertices"])
     x, v, C, F = CO.O.state24_split(sc["state"])

@@ -92,11 +92,11 @@ def _rollout_oracle(sc, P, frames_cloth, ids, pens, n):
     return frames, exts
 
 
-@pytest.mark.parametrize("kind", ["taco", "hit"])
+@pytest.mark.parametrize("kind,ctype", [("taco", 2), ("hit", 2), ("taco", 1), ("hit", 1)])
 @pytest.mark.parametrize("precision", ["float64", "float32"])
-def test_substep_with_cloth_contact_matches_oracle(kind, precision):
+def test_substep_with_cloth_contact_matches_oracle(kind, ctype, precision):
     n = 3
-    sc = S.build(kind, precision, n_env_steps=1)
+    sc = S.build(kind, precision, n_env_steps=1, collision_type=ctype)
     sim, prim = S.build_engine(sc)
     N, V = len(sc["state"]), len(sc["vertices"])
     P = S.oracle_params(sc)
@@ -127,7 +127,7 @@ def test_substep_with_cloth_contact_matches_oracle(kind, precision):
     assert H.rel_err(st[:, 15:24], C.reshape(N, 9)) < (tol_s if precision == "float64" else H.c_tol(tol_s, P.n_grid / P.scale, v, C))
     ext_ref = np.sum(exts, axis=0)
     assert np.abs(ext_ref).max() > 0
-    print(f"\n[cloth {kind} {precision}] x {H.rel_err(st[:, 0:3], x):.1e} v {H.rel_err(st[:, 3:6], v):.1e} F {H.rel_err(st[:, 6:15], F.reshape(N, 9)):.1e} "
+    print(f"\n[cloth {kind} ctype {ctype} {precision}] x {H.rel_err(st[:, 0:3], x):.1e} v {H.rel_err(st[:, 3:6], v):.1e} F {H.rel_err(st[:, 6:15], F.reshape(N, 9)):.1e} "
           f"C {H.rel_err(st[:, 15:24], C.reshape(N, 9)):.1e} ext_f {H.rel_err(prim.ext_f.to_numpy(), ext_ref):.1e}")
     assert H.rel_err(prim.ext_f.to_numpy(), ext_ref) < (1e-8 if precision == "float64" else tol_s)
     # adjoint: seeds on the last frame + on the sheet's force
@@ -153,14 +153,17 @@ def test_substep_with_cloth_contact_matches_oracle(kind, precision):
         out, ins = H.rel_err_split(got.reshape(N, -1), ref.numpy().reshape(N, -1), zone)
         assert out < tol_g and ins < H.F32_TOL["clamp"]
     errs = [H.rel_err_split(g.reshape(N, -1), r.numpy().reshape(N, -1), zone) for g, r in ((dgx, adj[0]), (dgv, adj[1]), (dgC, adj[2]), (dgF, adj[3]))]
-    print(f"\n[cloth {kind} {precision}] gx {errs[0][0]:.1e} gv {errs[1][0]:.1e} gC {errs[2][0]:.1e} gF {errs[3][0]:.1e} clamp-zone {max(e[1] for e in errs):.1e} ({int(zone.sum())} particles)")
+    print(f"\n[cloth {kind} ctype {ctype} {precision}] gx {errs[0][0]:.1e} gv {errs[1][0]:.1e} gC {errs[2][0]:.1e} gF {errs[3][0]:.1e} clamp-zone {max(e[1] for e in errs):.1e} ({int(zone.sum())} particles)")
     for f in range(n):
         cp, cv = prim.get_all_states_grad(f)
         scale_p, scale_v = max(np.abs(r).max() for r in ref_cp), max(np.abs(r).max() for r in ref_cv)
         print(f"[cloth {kind} {precision}] frame {f}: sheet position.grad {np.abs(cp - ref_cp[f]).max() / scale_p:.1e} velocity.grad {np.abs(cv - ref_cv[f]).max() / scale_v:.1e}"
               + ("" if sc["action"] is None else f" action.grad {H.rel_err(got_act[f], ref_act[f]):.1e}"))
-        assert np.abs(cp - ref_cp[f]).max() < tol_g * scale_p          # (measured in f32: 2e-8 ... 7e-7, profiles/r02_s_cloth_f32_errors.txt)
-        assert np.abs(cv - ref_cv[f]).max() < tol_g * scale_v
+        # measured in f32 (profiles/r02_v_cloth_f32_errors.txt): forecast contact 2e-8 ... 7e-7; penalty contact (collision_type 1) up to 1.3e-6 on the
+        # positions and 1.0e-5 on velocity.grad, whose only source is the friction term -p_v_t / |p_v_t| |n.v| kf (primitive_cloth.py:220-222): a
+        # quotient of float32-stored particle velocities, 100x smaller than every other adjoint of the scene
+        assert np.abs(cp - ref_cp[f]).max() < tol_g * scale_p
+        assert np.abs(cv - ref_cv[f]).max() < (2 if (ctype == 1 and precision == "float32") else 1) * tol_g * scale_v
         if sc["action"] is not None:
             assert H.rel_err(got_act[f], ref_act[f]) < tol_g
 

@@ -184,3 +184,18 @@ def test_face_neighbourhoods():
             if i != 5 and len(hit):
                 assert nbd2[i, hit[0]] == 1
         assert nbd2[5].sum() == (nb2[5] != 5).sum()
+
+
+@pytest.mark.parametrize("name", ["taco", "hit", "hit_penalty"])
+def test_oracle_reproduces_committed_golden_vectors(name):
+    """regression pin: tests/golden/oracle_cloth_*.npz were made by tools/make_golden_cloth.py from this oracle"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_cloth", H.ROOT / "tools" / "make_golden_cloth.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kind, ctype = mod.CASES[name]
+    out = mod.run(kind, ctype)
+    gold = np.load(H.GOLDEN / f"oracle_cloth_{name}.npz")
+    assert (out["contact_id"] == gold["contact_id"]).all() and (out["penetration"] == gold["penetration"]).all()
+    for k in ("x", "v", "C", "F", "ext_f", "gx0", "gv0", "gC0", "gF0", "cloth_pos_grad", "cloth_vel_grad", "action_grad"):
+        assert np.abs(out[k] - gold[k]).max() <= 1e-11 * max(np.abs(gold[k]).max(), 1e-30), k

@@ -280,3 +280,65 @@ def test_cloth_path_at_full_size():
         ref = 2.0 * ga - 0.5 * gb
         assert np.abs(gc - ref).max() < 2e-4 * max(np.abs(ref).max(), 1e-30)
     assert np.abs(a[2]).max() > 0 and np.abs(b[3]).max() > 0        # the sheet does receive adjoints
+
+
+@pytest.mark.parametrize("name", ["taco", "hit", "hit_penalty"])
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_hip_path_against_committed_cloth_golden_vectors(name, precision):
+    """the committed vectors (tests/golden/oracle_cloth_*.npz, tools/make_golden_cloth.py) need no oracle on the GPU box"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_cloth", H.ROOT / "tools" / "make_golden_cloth.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kind, ctype = mod.CASES[name]
+    gold = np.load(H.GOLDEN / f"oracle_cloth_{name}.npz")
+    N = len(gold["contact_id"])
+    sc = S.build(kind, precision, N=N, seed=21, collision_type=ctype)
+    sim, prim = S.build_engine(sc)
+    n = mod.N_STEPS
+    for f in range(n + 1):
+        prim.set_all_states(f, *sc["motion"](f * sc["cfg"].dt))
+    sim.reset(sc["state"])
+    for f in range(n):
+        sim.set_contact(f, gold["contact_id"], gold["penetration"])
+        sim.substep(f, sc["action"])
+    ts, tg = (1e-9, 1e-8) if precision == "float64" else (H.F32_TOL["state"], H.F32_TOL["grad"])
+    st = sim.get_state(n)
+    P = S.oracle_params(sc)
+    assert H.rel_err(st[:, 0:3], gold["x"]) < ts and H.rel_err(st[:, 3:6], gold["v"]) < ts and H.rel_err(st[:, 6:15], gold["F"].reshape(N, 9)) < ts
+    assert H.rel_err(st[:, 15:24], gold["C"].reshape(N, 9)) < (ts if precision == "float64" else H.c_tol(ts, P.n_grid / P.scale, gold["v"], gold["C"]))
+    assert H.rel_err(prim.ext_f.to_numpy(), gold["ext_f"]) < (1e-8 if precision == "float64" else ts)
+    sim.clear_grads()
+    sim.add_grad(n, gx=gold["seed_gx"], gv=gold["seed_gv"], gC=gold["seed_gC"], gF=gold["seed_gF"])
+    acts = []
+    for f in range(n - 1, -1, -1):
+        acts.insert(0, sim.substep_grad(f, sc["action"], ext_f_grad=gold["ext_f_grad"]))
+    gx, gv, gF, gC = sim.get_grad_full(0)
+    for got, key in ((gx, "gx0"), (gv, "gv0"), (gC, "gC0"), (gF, "gF0")):
+        assert H.rel_err(got.reshape(N, -1), gold[key].reshape(N, -1)) < tg, key
+    slack = 2 if (ctype == 1 and precision == "float32") else 1            # (see test_substep_with_cloth_contact_matches_oracle)
+    for f in range(n):
+        cp, cv = prim.get_all_states_grad(f)
+        assert np.abs(cp - gold["cloth_pos_grad"][f]).max() < tg * np.abs(gold["cloth_pos_grad"]).max()
+        assert np.abs(cv - gold["cloth_vel_grad"][f]).max() < slack * tg * np.abs(gold["cloth_vel_grad"]).max()
+        if sc["action"] is not None:
+            assert H.rel_err(acts[f], gold["action_grad"][f]) < tg
+
+
+def test_cloth_api_rejects_misuse():
+    from softmac_amd._ffi import SmacError
+    sc = S.build("hit", "float64", N=200)
+    sim, prim = S.build_engine(sc)
+    sim.reset(sc["state"])
+    with pytest.raises(SmacError, match="already has a cloth"):
+        prim._bind(sim._h)
+    with pytest.raises(SmacError, match="frame range"):
+        prim.set_all_states(sc["cfg"].max_steps, sc["vertices"], sc["vertices"])
+    with pytest.raises(SmacError, match="face id out of range"):
+        sim.set_contact(0, np.full(200, len(sc["faces"]), dtype=np.int32), None)
+    with pytest.raises(SmacError, match="needs frame f-1"):
+        sim.trace_penetration_after_mpm(0)
+    with pytest.raises(SmacError, match="unknown parameter"):
+        sim._h.call("smac_set_param", b"no_such_knob", __import__("ctypes").c_double(1.0))
+    with pytest.raises(ValueError):
+        prim.set_all_states(0, sc["vertices"][:-1], sc["vertices"][:-1])

@@ -342,3 +342,70 @@ def test_cloth_api_rejects_misuse():
         sim._h.call("smac_set_param", b"no_such_knob", __import__("ctypes").c_double(1.0))
     with pytest.raises(ValueError):
         prim.set_all_states(0, sc["vertices"][:-1], sc["vertices"][:-1])
+
+
+@pytest.mark.parametrize("case", list(range(12)))
+def test_cloth_random_configurations(case):
+    """seeded corners the two demo scenes do not visit: every material, both contact models and stickiness settings, odd particle counts,
+    other length scales and friction / softness values, both precisions, re-sorting every substep or never - two substeps each"""
+    rng = np.random.default_rng(500 + case)
+    kind = "taco" if case % 2 == 0 else "hit"
+    precision = "float64" if case % 4 < 2 else "float32"
+    N = int(rng.choice([1, 63, 257, 900]))
+    ctype = int(rng.choice([1, 2, 2]))
+    sc = S.build(kind, precision, N=N, seed=600 + case, collision_type=ctype)
+    new_scale = float(rng.choice([1.0, 2.5, 5.0]))
+    f = new_scale / sc["scale"]
+    sc["state"][:, 0:6] *= f
+    sc["vertices"] = sc["vertices"] * f
+    sc["scale"] = new_scale
+    sc["motion"] = S.sheet_motion(kind, sc["vertices"], new_scale)
+    sc["cfg"].ptype = int(rng.integers(0, 3))
+    sc["cfg"].material_model = 0 if sc["cfg"].ptype == 0 else int(rng.integers(0, 2))
+    sc["cfg"].E = float(rng.choice([500.0, 5000.0])) if sc["cfg"].ptype != 2 else 30.0
+    sc["cfg"].sort_interval = int(rng.choice([1, 16]))
+    sc["prim"].update(sticky=bool(rng.integers(0, 2)), friction=float(rng.choice([0.0, 0.9, 10.0])), softness=float(rng.choice([66.0, 666.0])))
+    sim, prim = S.build_engine(sc)
+    P = S.oracle_params(sc)
+    n = 2
+    cloth = [sc["motion"](k * sc["cfg"].dt) for k in range(n + 1)]
+    for k in range(n + 1):
+        prim.set_all_states(k, *cloth[k])
+    sim.reset(sc["state"])
+    sim.get_contact_pair(0)
+    ids0, _ = sim.get_contact(0)
+    pen = ((rng.uniform(size=N) < 0.2) & (ids0 >= 0)).astype(np.int8)
+    for k in range(n):
+        sim.set_contact(k, ids0, pen)
+    frames, exts = _rollout_oracle(sc, P, cloth, [ids0] * n, [pen] * n, n)
+    for k in range(n):
+        sim.substep(k, sc["action"])
+    ts, tg = (1e-9, 1e-8) if precision == "float64" else (H.F32_TOL["state"], H.F32_TOL["grad"])
+    st = sim.get_state(n)
+    x, v, C, F = (t.numpy() for t in frames[n])
+    assert H.rel_err(st[:, 0:3], x) < ts and H.rel_err(st[:, 3:6], v) < ts and H.rel_err(st[:, 6:15], F.reshape(N, 9)) < ts
+    assert H.rel_err(st[:, 15:24], C.reshape(N, 9)) < (ts if precision == "float64" else H.c_tol(ts, P.n_grid / P.scale, v, C))
+    ext_ref = np.sum(exts, axis=0)
+    if np.abs(ext_ref).max() > 0:
+        assert H.rel_err(prim.ext_f.to_numpy(), ext_ref) < (1e-8 if precision == "float64" else ts)
+    gx, gv = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+    adj = (torch.as_tensor(gx), torch.as_tensor(gv), torch.zeros(N, 3, 3, dtype=CO.DT), torch.zeros(N, 3, 3, dtype=CO.DT))
+    ci = None if sc["control_idx"] is None else torch.as_tensor(sc["control_idx"], dtype=torch.int64)
+    act = None if sc["action"] is None else torch.as_tensor(sc["action"], dtype=CO.DT)
+    for k in range(n - 1, -1, -1):
+        g = CO.substep_grad(*frames[k], P, S.oracle_prim(sc, *cloth[k]), ids0, pen, k, *adj, control_idx=ci, action=act)
+        adj = (g["gx"], g["gv"], g["gC"], g["gF"])
+    sim.clear_grads()
+    sim.add_grad(n, gx=gx, gv=gv)
+    for k in range(n - 1, -1, -1):
+        sim.substep_grad(k, sc["action"])
+    got = sim.get_grad_full(0)
+    zone = H.clamp_zone(types_frames(frames), P, n) if precision == "float32" else np.zeros(N, dtype=bool)
+    pairs = ((got[0], adj[0]), (got[1], adj[1]), (got[3].reshape(N, 9), adj[2].reshape(N, 9)), (got[2].reshape(N, 9), adj[3].reshape(N, 9)))
+    top = max(float(b.abs().max()) for _, b in pairs)
+    for a, b in pairs:
+        if float(b.abs().max()) < 1e-6 * top:          # an exactly vanishing adjoint (one isolated particle: sum_n w_n (x_n - x_p) = 0 removes C and F from its
+            assert np.abs(a).max() < tg * top           # velocity) is compared on the scale of the others, not on its own rounding noise
+            continue
+        out, ins = H.rel_err_split(a.reshape(N, -1), b.numpy().reshape(N, -1), zone)
+        assert out < tg and ins < H.F32_TOL["clamp"]

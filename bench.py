@@ -134,6 +134,7 @@ def parse_args(argv=None):
     ap.add_argument("--precision", default="float32", choices=["float32", "float64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the float64 sub-record (the mode that equals the reference's dtype)")
+    ap.add_argument("--no-cloth", action="store_true", help="skip the soft <-> cloth sub-record (tools/bench_cloth.py in a child process)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
     ap.add_argument("--sort-interval", type=int, default=0, help="0: min(32, steps), so that every timed window holds a re-sort")
@@ -350,6 +351,17 @@ def main():
         w64, d64, _, _ = timed_windows(a64, sim, run, None, seed_gx, lambda: sim.sync(), None)
         out["f64"] = {"value": K / w64[0], "unit": "substeps/s", "ms_per_step": 1e3 * w64[0] / K, "device_ms_per_step": d64[0] / K,
                       "dtype": "f64", "note": "same workload, arithmetic and storage in float64 (parity 1e-9 state / 1e-8 gradients)"}
+    if world == 1 and args.precision == "float32" and not args.no_cloth and args.workload == "s-grip":
+        # the soft <-> cloth path at the same size, in a child process: whatever happens there cannot touch the metric line
+        try:
+            sim._h.close()
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_cloth.py"), "--particles", str(args.particles), "--grid", str(args.grid)],
+                               capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out["cloth"] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
+        except Exception as e:                                                     # noqa: BLE001
+            out["cloth"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

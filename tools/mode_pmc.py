@@ -4,7 +4,7 @@ import sys, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import bench
 
-a = bench.parse_args(["--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-f64", "--repeats", "1"])
+a = bench.parse_args(["--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-f64", "--no-cloth", "--repeats", "1"])
 sim, run, cfg = bench.build_sim(a, 0, 1)
 run.run_substeps(0, 4)
 sim.profile(True)

@@ -230,11 +230,13 @@ template <class R> __device__ __forceinline__ void load_pos(const R* fr, int Npa
 #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = ((const P*)fr)[rowbase(CX + i, Npad) + po];
 }
-// stores of whole frame rows (written once, read by a later kernel): SMAC_NT_STORES=1 issues them non-temporal (A/B, tools/r02_z.sh)
+// The 24 adjoint rows k_p2g_grad writes go out non-temporal: measured over 4 + 4 processes (profiles/r02_z_nt_stores.txt) 91.6 -> 89.1 us, against
+// +0.4 us in the k_g2p_grad that reads them a substep later.  The same on k_g2p's 15 rows saves it 1.4 us and costs the next k_p2g, which reads them
+// 80 us later, 1.2 us: those stay plain.
 #ifndef SMAC_NT_STORES
-#define SMAC_NT_STORES 0
+#define SMAC_NT_STORES 1
 #endif
-template <class T> __device__ __forceinline__ void row_store(T* p, T v) {
+template <class T> __device__ __forceinline__ void row_store_nt(T* p, T v) {
 #if SMAC_NT_STORES
     __builtin_nontemporal_store(v, p);
 #else
@@ -243,7 +245,7 @@ template <class T> __device__ __forceinline__ void row_store(T* p, T v) {
 }
 template <class R> __device__ __forceinline__ void store_pos(R* fr, int Npad, int p, int i, typename pos_of<R>::type v) {
     typedef typename pos_of<R>::type P;
-    row_store(&((P*)fr)[rowoff(CX + i, p, Npad)], v);
+    ((P*)fr)[rowoff(CX + i, p, Npad)] = v;
 }
 template <class R, class P> __device__ __forceinline__ void pos_to(const P* x, R* out) {
 #pragma unroll
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         if (STORE_F) {
             R* Sn = frame(D.S, f + 1, D.Npad);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) row_store(&Sn[rowoff(CF + i, p, D.Npad)], En[i]);     // :250
+            for (int i = 0; i < 9; ++i) Sn[rowoff(CF + i, p, D.Npad)] = En[i];     // :250
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) aff[i] = D.stress_scale * stress[i] + D.p_mass * C[i];   // :247-248
@@ -1042,7 +1044,7 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
     bool leaves = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        row_store(&Sn[rowoff(CV + c, p, D.Npad)], nv[c]);
+        Sn[rowoff(CV + c, p, D.Npad)] = nv[c];
         const typename pos_of<R>::type xn = pos_advance(x[c], D.dt64, nv[c]);          // :318
         store_pos(Sn, D.Npad, p, c, xn);
         // the position just written is scattered by the NEXT substep's P2G: if that substep keeps this binning, the new
@@ -1054,7 +1056,7 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
     }
     if (leaves && D.check_next) *D.drift_flag = 1;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) row_store(&Sn[rowoff(CC + c, p, D.Npad)], (R)(four_inv_dx * nC[c]));
+    for (int c = 0; c < 9; ++c) Sn[rowoff(CC + c, p, D.Npad)] = four_inv_dx * nC[c];
 }
 
 template <class R>
@@ -1776,7 +1778,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
 #if SMAC_GFN_STASH
         R gFn[9];
 #endif
-        load_vec(An, CF, 9, D.Npad, p, gFn);            // F.grad[f+1]: fetched with the rest (parked in LDS until the constitutive adjoint)
+        load_vec(An, CF, 9, D.Npad, p, gFn);       // F.grad[f+1]: fetched with the rest (parked in LDS until the constitutive adjoint)
         ConstState<CT> cs;
         {
             CT Cc[9], Ec[9];
@@ -1926,7 +1928,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         Af[rowoff(CX + d, p, D.Npad)] += D.inv_dx * gfx[d];
         const R gvv = D.p_mass * gvp[d];
         if (ACC_VCF) Af[rowoff(CV + d, p, D.Npad)] += gvv;
-        else row_store(&Af[rowoff(CV + d, p, D.Npad)], gvv);
+        else row_store_nt(&Af[rowoff(CV + d, p, D.Npad)], gvv);
     }
     // constitutive adjoint
     R gEt[9];
@@ -1976,8 +1978,8 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
             Af[rowoff(CC + i, p, D.Npad)] += gc;
             Af[rowoff(CF + i, p, D.Npad)] += gE[i];
         } else {
-            row_store(&Af[rowoff(CC + i, p, D.Npad)], gc);
-            row_store(&Af[rowoff(CF + i, p, D.Npad)], gE[i]);
+            row_store_nt(&Af[rowoff(CC + i, p, D.Npad)], gc);
+            row_store_nt(&Af[rowoff(CF + i, p, D.Npad)], gE[i]);
         }
     }
 }

@@ -69,8 +69,11 @@ def build_sim(args, rank, world, precision=None, frames=None):
     sim.reset(state)
     runner = sim
     if slab is not None:                                   # slab decomposition: halo exchange of the shared x-planes over RCCL
-        from softmac_amd.parallel import HipSlabEngine, SlabRunner
-        runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=True)
+        from softmac_amd.parallel import HipSlabEngine, SlabRunner, contact_sides
+        traj = [np.stack([s13[i] + np.concatenate([f * cfg.dt * s13[i][7:10], np.zeros(10)]) for f in range(frames)]) for i in range(len(specs))]
+        sides = contact_sides(specs, traj, args.grid, slab[0], slab[1], slab[2], rank, world)
+        runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=sides)
+        runner.contact_sides_note = sides
     return sim, runner, cfg
 
 
@@ -309,7 +312,8 @@ def main():
         elif strong:
             par = (f"strong scaling: the one {N}-particle scene cut into {world} x-slabs of one global {args.grid}^3 grid, balanced by particle count "
                    f"({[c[0] for c in allc]} particles per rank); per substep neighbour-only RCCL send/recv of the 4 shared grid planes "
-                   f"(fwd: m,p + contact corrections; bwd: grid_v_out.grad + grid_v_mixed.grad); ext_f all-reduced per env step, "
+                   f"(fwd: m,p + contact corrections; bwd: grid_v_out.grad + grid_v_mixed.grad; the two contact exchanges only across "
+                   f"boundaries a gripper finger can reach - rank 0: {getattr(run, 'contact_sides_note', None)}); ext_f all-reduced per env step, "
                    f"primitive adjoints per window")
         else:
             par = (f"weak scaling: {world} x-slabs of one bar, {N} particles each; value counts every slab's substep; per substep "

@@ -102,7 +102,13 @@ class SlabRunner:
     def __init__(self, engine, rank, world, left_plane0, right_plane0, nplanes=2, has_contact=True, group=None, own=None, ids=None):
         self.e, self.rank, self.world = engine, rank, world
         self.left0, self.right0, self.np = int(left_plane0), int(right_plane0), int(nplanes)
-        self.has_contact = bool(has_contact)
+        # has_contact: bool, or (left, right) - whether a contact primitive can touch the planes shared with that neighbour (`contact_sides`);
+        # a side without contact skips the two contact exchanges (v_out corrections, grid_v_mixed.grad) with that neighbour
+        if isinstance(has_contact, (tuple, list)):
+            self.contact_side = {"L": bool(has_contact[0]), "R": bool(has_contact[1])}
+        else:
+            self.contact_side = {"L": bool(has_contact), "R": bool(has_contact)}
+        self.has_contact = self.contact_side["L"] or self.contact_side["R"]
         self.group = group
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
@@ -119,12 +125,12 @@ class SlabRunner:
             self._buf[side] = (self.e.new_buffer(self.np), self.e.new_buffer(self.np))
         return self._buf[side]
 
-    def exchange(self, field, minus_mixed=0):
-        """SUM the partials of `field` on the shared planes with both neighbours."""
+    def exchange(self, field, minus_mixed=0, contact_only=False):
+        """SUM the partials of `field` on the shared planes with both neighbours (contact_only: only where a primitive reaches those planes)."""
         sides = []
-        if self.left is not None:
+        if self.left is not None and (self.contact_side["L"] or not contact_only):
             sides.append(("L", self.left, self.left0))
-        if self.right is not None:
+        if self.right is not None and (self.contact_side["R"] or not contact_only):
             sides.append(("R", self.right, self.right0))
         if not sides:
             return
@@ -150,7 +156,7 @@ class SlabRunner:
         self.exchange("grid_in")
         self.e.phase(f, 1)
         if self.has_contact:
-            self.exchange("grid_out", minus_mixed=1)
+            self.exchange("grid_out", minus_mixed=1, contact_only=True)
         self.e.phase(f, 2)
 
     def substep_grad(self, f, ext_f_grad=None):
@@ -158,7 +164,7 @@ class SlabRunner:
         self.exchange("grid_out.grad")
         self.e.grad_phase(f, 1)
         if self.has_contact:
-            self.exchange("grid_mixed.grad")
+            self.exchange("grid_mixed.grad", contact_only=True)
         self.e.grad_phase(f, 2)
 
     def run_substeps(self, f0, count):
@@ -237,6 +243,40 @@ class SlabRunner:
         self.e.add_grad_rows(f, old)
         self.ids = rec["ids_old"]
         return f
+
+
+def contact_sides(specs, states, n_grid, left_plane0, right_plane0, nplanes, rank, world, band=5e-3, drift_cells=2.0):
+    """(left, right): can a contact primitive put a correction on the x-planes shared with that neighbour?  Conservative: the primitive's
+    SDF table box, rotated by its pose, at (a sample of) the frames of `states` ([frame][13] per primitive, or one 13-vector), grown
+    by the contact band, the 2.5 cells a quadratic stencil reaches and the particle drift the binning tolerates.  Both neighbours of a boundary
+    evaluate the same planes with the same primitive data, so they agree.  SMAC_SLAB_ALL_EXCHANGES=1 turns the shortcut off."""
+    import os
+    if os.environ.get("SMAC_SLAB_ALL_EXCHANGES"):
+        return rank > 0, rank < world - 1
+    dx = 1.0 / n_grid
+    reach = band + (2.5 + drift_cells) * dx
+    out = []
+    for side, plane0, exists in (("L", left_plane0, rank > 0), ("R", right_plane0, rank < world - 1)):
+        hit = False
+        if exists:
+            lo, hi = plane0 * dx, (plane0 + nplanes) * dx
+            for spec, st in zip(specs, states):
+                if not spec.get("contact", True):
+                    continue
+                lw, up = np.asarray(spec["lower"], dtype=np.float64), np.asarray(spec["upper"], dtype=np.float64)
+                box = np.array([[a, b, c] for a in (lw[0], up[0]) for b in (lw[1], up[1]) for c in (lw[2], up[2])])
+                st2 = np.atleast_2d(np.asarray(st, dtype=np.float64))
+                for row in st2[:: max(1, len(st2) // 64)].tolist() + [st2[-1].tolist()]:
+                    w, q = row[3], np.asarray(row[4:7])
+                    n2 = w * w + q @ q
+                    # x-extent of the rotated table box (first row of the rotation matrix of the pose quaternion)
+                    r0 = np.array([w * w + q[0] * q[0] - q[1] * q[1] - q[2] * q[2], 2 * (q[0] * q[1] - w * q[2]), 2 * (q[0] * q[2] + w * q[1])]) / n2
+                    ext = box @ r0
+                    if row[0] + ext.max() + reach >= lo and row[0] + ext.min() - reach <= hi:
+                        hit = True
+                        break
+        out.append(hit)
+    return tuple(out)
 
 
 class _DevArray:

@@ -27,6 +27,8 @@ def main():
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
     if a.scene == "moving":
         return moving(a)
+    if a.scene == "grip_strong":
+        return grip_strong(a)
     sc = S.build(a.precision)
     idx = S.owned(sc, a.rank, a.world)
     state = sc["state"][idx]
@@ -68,6 +70,41 @@ def main():
                    ext=np.array([m.ext_f.to_numpy() for m in prims]) if sc["specs"] else np.zeros((0, 6)),
                    pgrad=np.array([[m.get_all_states_grad(f) for m in prims] for f in range(nsteps)]))
     np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=idx, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+GRIP_STRONG = dict(particles=1 << 18, grid=128, nsteps=6)
+
+
+def grip_strong_states(s13, nframes, dt):
+    return [[np.concatenate([st[:3] + f * dt * st[7:10], st[3:]]) for st in s13] for f in range(nframes)]
+
+
+def grip_strong(a):
+    """the strong-scaling bench scene at reduced size, HIP engine: the block cut at planes no gripper finger reaches, so that
+    `contact_sides` drops the two contact exchanges - the result must still equal the single-domain run (tests/test_slabs.py)"""
+    from softmac_amd import scenes
+    from softmac_amd.parallel import HipSlabEngine, contact_sides
+    G = GRIP_STRONG
+    n = G["nsteps"]
+    cfg, env_dt, state, specs, s13, slab, own = scenes.s_grip_strong(a.rank, a.world, G["particles"], G["grid"], n + 2, a.precision, 0)
+    pst = grip_strong_states(s13, n + 2, cfg.dt)
+    sim, prims = H.build_engine(cfg, env_dt, specs, pst)
+    sim.reset(state)
+    sides = contact_sides(specs, [np.stack([pst[f][i] for f in range(n + 2)]) for i in range(len(specs))], G["grid"], slab[0], slab[1], slab[2], a.rank, a.world)
+    run = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), a.rank, a.world, slab[0], slab[1], slab[2], has_contact=sides)
+    run.run_substeps(0, n)
+    hits = sim.contact_counts()[0]
+    rng = np.random.default_rng(5)
+    N = G["particles"]
+    gx, gv = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+    sim.clear_grads()
+    sim.add_grad(n, gx=gx[own], gv=gv[own])
+    run.run_substeps_grad(0, n)
+    g = sim.get_grad_full(0)
+    np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=own, st=sim.get_state(n), gx=g[0], gv=g[1], gF=g[2], gC=g[3], sides=np.array(sides), hits=hits,
+             ext=np.array([m.ext_f.to_numpy() for m in prims]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -103,3 +103,57 @@ def test_two_slabs_match_single_domain_cpu(tmp_path):
 @pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-8), ("float32", H.F32_TOL["state"], 5e-5)])
 def test_two_slabs_match_single_domain_gpu(tmp_path, precision, ts, tg):
     _check(_run_two_ranks("hip", precision, tmp_path), ts, tg)
+
+
+@pytest.mark.gpu
+def test_contact_exchange_shortcut_keeps_the_single_domain_result_gpu(tmp_path):
+    """`parallel.contact_sides`: a boundary no primitive can reach skips the two contact exchanges.  The strong-scaling bench scene at
+    262,144 particles cut in two at the block's centre (the fingers grip its x ends): both ranks drop them, contact still happens inside
+    each slab, and states / adjoints / wrenches equal the single-domain HIP run."""
+    import slab_worker as W
+    from softmac_amd import scenes
+    G = W.GRIP_STRONG
+    n = G["nsteps"]
+    parts = _run_ranks("hip", "float64", tmp_path, 2, "grip_strong")
+    assert all((p["sides"] == 0).all() for p in parts) and sum(int(p["hits"]) for p in parts) > 20
+    cfg, env_dt, state, specs, s13 = scenes.s_grip(G["particles"], G["grid"], n + 2, "float64", 0)
+    sim, prims = H.build_engine(cfg, env_dt, specs, W.grip_strong_states(s13, n + 2, cfg.dt))
+    sim.reset(state)
+    sim.run_substeps(0, n)
+    rng = np.random.default_rng(5)
+    N = G["particles"]
+    gx, gv = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+    sim.clear_grads()
+    sim.add_grad(n, gx=gx, gv=gv)
+    sim.run_substeps_grad(0, n)
+    st = sim.get_state(n)
+    g = sim.get_grad_full(0)
+    assert sorted(np.concatenate([p["idx"] for p in parts]).tolist()) == list(range(N))
+    for p in parts:
+        i = p["idx"]
+        assert H.rel_err(p["st"], st[i]) < 1e-9
+        for k, ref in zip(("gx", "gv", "gF", "gC"), g):
+            assert np.abs(p[k] - ref[i]).max() < 1e-8 * np.abs(ref).max(), k
+    ext = sum(p["ext"] for p in parts)
+    assert H.rel_err(ext, np.array([m.ext_f.to_numpy() for m in prims])) < 1e-9
+
+
+def test_contact_sides_predicate(monkeypatch):
+    from softmac_amd.parallel import contact_sides
+    spec = dict(lower=[-0.06, -0.11, -0.06], upper=[0.06, 0.11, 0.06], contact=True)
+    ident = [1.0, 0.0, 0.0, 0.0]
+    still = np.array([0.30, 0.3, 0.5] + ident + [0.0] * 6)
+    # planes 62..65 of a 128 grid = x in [0.484, 0.516): the box reaches 0.36 + 0.005 + 4.5 cells = 0.40 -> free; moved to x = 0.42 it touches
+    assert contact_sides([spec], [still], 128, 62, 62, 4, 1, 3) == (False, False)
+    near = still.copy(); near[0] = 0.42
+    assert contact_sides([spec], [near], 128, 62, 62, 4, 1, 3) == (True, True)
+    assert contact_sides([spec], [near], 128, 62, 62, 4, 0, 2) == (False, True)            # no left neighbour
+    assert contact_sides([dict(spec, contact=False)], [near], 128, 62, 62, 4, 1, 3) == (False, False)
+    moving = np.stack([still + np.concatenate([[0.004 * f, 0, 0], np.zeros(10)]) for f in range(40)])     # slides into reach during the window
+    assert contact_sides([spec], [moving], 128, 62, 62, 4, 1, 3) == (True, True)
+    turned = still.copy(); turned[3:7] = [np.cos(np.pi / 4), 0.0, 0.0, np.sin(np.pi / 4)]                 # 90 degrees about z: the long axis now lies along x
+    turned[0] = 0.345
+    assert contact_sides([spec], [turned], 128, 62, 62, 4, 1, 3) == (True, True)
+    assert contact_sides([spec], [np.concatenate([[0.345], still[1:]])], 128, 62, 62, 4, 1, 3) == (False, False)
+    monkeypatch.setenv("SMAC_SLAB_ALL_EXCHANGES", "1")
+    assert contact_sides([spec], [still], 128, 62, 62, 4, 1, 3) == (True, True)

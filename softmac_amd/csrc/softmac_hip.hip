@@ -162,6 +162,7 @@ template <class R> struct Sim final : ISim {
     void* d_cub = nullptr;
     size_t cub_bytes = 0;
     R* tmp_frame = nullptr;         // NCOMP*Npad scratch (sort moves, re-ordered adjoints)
+    R* tmp_frame2 = nullptr;        // second one, allocated when the adjoints of frames f AND f+1 both arrive in another particle order
     Vec4<R>* slab = nullptr;
     size_t slab_chunks = 0;
     Hit* d_hits = nullptr;           // capacity Npad
@@ -201,7 +202,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_bin_mask); hipFree(d_over_prefix); hipFree(d_vmax); hipFree(d_vmax_part);
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
-        hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
+        hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(tmp_frame2); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
         hipFree(d_io);
         hipFree(d_cloth_faces); hipFree(d_cloth_nbr); hipFree(d_cloth_nbr_dir); hipFree(d_cloth_warn); hipFree(d_cloth_ext_scratch);
@@ -977,7 +978,8 @@ template <class R> struct Sim final : ISim {
         return check_launch();
     }
     // adjoint frame f re-ordered from its own epoch into epoch `to` -> tmp_frame (returns pointer to use)
-    int adjoint_in_order(int f, int to, const R** out) {
+    int adjoint_in_order(int f, int to, const R** out, R* dst = nullptr) {
+        if (!dst) dst = tmp_frame;
         const R* Af = adj_ptr(f);
         REQUIRE(Af, kPoolMessage);
         const int from = adj_epoch[f];
@@ -995,9 +997,9 @@ template <class R> struct Sim final : ISim {
             }
         }
         prof_begin(K_REORDER);
-        hipLaunchKernelGGL(k_gather_rows<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, map, Af, tmp_frame, D.Npad, (int)NCOMP);
+        hipLaunchKernelGGL(k_gather_rows<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, map, Af, dst, D.Npad, (int)NCOMP);
         prof_end();
-        *out = tmp_frame;
+        *out = dst;
         return check_launch();
     }
     int check_drift() {
@@ -1416,8 +1418,12 @@ template <class R> struct Sim final : ISim {
             if ((rc = adjoint_in_order(f + 1, e, &An))) return rc;
             if (adj_epoch[f] >= 0 && adj_epoch[f] != e) {                         // seeds stored in another order: convert in place
                 const R* tmp = nullptr;
-                REQUIRE(An != tmp_frame, "adjoint frames f and f+1 both need re-ordering (unsupported seed placement)");
-                if ((rc = adjoint_in_order(f, e, &tmp))) return rc;
+                R* dst = tmp_frame;
+                if (An == tmp_frame) {                                            // frame f+1 already sits there: use the second scratch frame
+                    if (!tmp_frame2) HIP_TRY(hipMalloc((void**)&tmp_frame2, frame_scalars() * sizeof(R)));
+                    dst = tmp_frame2;
+                }
+                if ((rc = adjoint_in_order(f, e, &tmp, dst))) return rc;
                 HIP_TRY(hipMemcpyAsync(adj_ptr(f), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
             }
             D.Af = adj_ptr(f);

@@ -157,6 +157,32 @@ def test_resort_every_substep_and_long_window():
         _compare_rollout(cfg, 1e-3, state, steps)
 
 
+def test_seed_placed_before_the_frame_was_binned():
+    """A loss term seeded on frame 0 BEFORE the rollout (its adjoint row order is the caller's), with a re-sort at every substep: in
+    substep_grad(0) both adjoint frames - frame 1 (binned at substep 1) and frame 0 (caller's order) - have to be brought into
+    frame 0's binning (round 1 refused that placement)."""
+    n_grid, N, n = 32, 2000, 3
+    state = H.make_cloud(N, n_grid, seed=9, lo=(0.3, 0.1, 0.3), hi=(0.7, 0.4, 0.7), v_std=1.0)
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, ground_friction=0.0, precision="float64", sort_interval=1, max_steps=8)
+    P = H.oracle_params(cfg, 1e-3)
+    orc = H.OracleRollout(P, state).forward(n)
+    rng = np.random.default_rng(3)
+    s0 = (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), None, None)
+    sn = (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), 0.01 * rng.standard_normal((N, 3, 3)), 0.01 * rng.standard_normal((N, 3, 3)))
+    adj, _, _ = orc.backward({n: sn, 0: s0})
+    sim, _ = H.build_engine(cfg, 1e-3)
+    sim.reset(state)
+    sim.clear_grads()
+    sim.add_grad(0, gx=s0[0], gv=s0[1])                 # frame 0 is still in the caller's order here
+    sim.run_substeps(0, n)
+    sim.add_grad(n, gx=sn[0], gv=sn[1], gC=sn[2], gF=sn[3])
+    for f in range(n - 1, -1, -1):
+        sim.substep_grad(f)
+    gx, gv, gF, gC = sim.get_grad_full(0)
+    for got, ref in ((gx, adj[0][0]), (gv, adj[0][1]), (gC, adj[0][2]), (gF, adj[0][3])):
+        assert H.rel_err(got.reshape(N, -1), ref.numpy().reshape(N, -1)) < 1e-8
+
+
 def test_fast_particles_shorten_the_resort_interval():
     """A cloud crossing 5.4 cells in 14 substeps with sort_interval 16: more than the 4-cell halo a binning is good
     for, so the library has to re-bin on its own schedule (0.38 cells per substep -> every 5 substeps)."""

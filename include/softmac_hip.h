@@ -170,6 +170,9 @@ int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /*
  * "cloth_pairs_flat": 1 = smac_cloth_contact_pair tests every particle against every face also on sorted frames (default 0: faces are
  *               culled per chunk first; same result) */
 int smac_set_param(smac_handle h, const char* name, double value);
+/* reads a parameter back; also "drift_repairs": how many times an epoch was recomputed because a particle out-ran its binning (no reference
+ * counterpart: the reference's dense grid has no binning) */
+int smac_get_param(smac_handle h, const char* name, double* value);
 
 /* ---- cloth primitive: replaces soft_cloth/engine/primitive/primitive_cloth.py (Primitive_Cloth) and the contact bookkeeping of
  * soft_cloth/engine/mpm_simulator.py:447-561.  One per handle, instead of SDF primitives.  Vertex positions / velocities /

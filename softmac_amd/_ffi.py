@@ -84,6 +84,7 @@ SIGNATURES = {
     "smac_count_active_cells": (C.c_int, [H, C.c_int, C.POINTER(C.c_int64)]),
     "smac_contact_counts": (C.c_int, [H, c_int32_p, c_int32_p]),
     "smac_set_param": (C.c_int, [H, C.c_char_p, C.c_double]),
+    "smac_get_param": (C.c_int, [H, C.c_char_p, c_double_p]),
     "smac_cloth_create": (C.c_int, [H, C.c_int, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int8_p, C.c_double, C.c_double, C.c_double, C.c_int,
                                     C.c_double]),
     "smac_cloth_set_state": (C.c_int, [H, C.c_int, C.c_int, c_double_p, c_double_p]),

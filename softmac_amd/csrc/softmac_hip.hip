@@ -41,6 +41,9 @@ enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_G
 static const char* kDriftMessage =
     "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort "
     "interval): the frames after that substep are invalid - lower sort_interval or dt";
+static const char* kHitOverflowMessage =
+    "more than 1/8 of the particles were inside a contact band in one substep: its hit list does not fit the grid "
+    "checkpoint (create the handle with flags bit 0 - recompute_backward - for such scenes)";
 static const char* kKernelNames[K_COUNT] = {"clear_grid", "grid_checkpoint", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
                                             "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint"};
 
@@ -95,6 +98,7 @@ struct ISim {
     virtual int set_stream(void* s) = 0;
     virtual int stream_handle(void** s) = 0;
     virtual int set_param(const char* name, double value) = 0;
+    virtual int get_param(const char* name, double* value) = 0;
     virtual int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction,
                              double softness, double force_scale, int sticky, double scale) = 0;
     virtual int cloth_set_state(int f0, int f1, const double* pos, const double* vel) = 0;
@@ -204,7 +208,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(tmp_frame2); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
-        hipFree(d_io);
+        hipFree(d_io); hipFree(ext_snap); hipFree(cloth_ext_snap);
         hipFree(d_cloth_faces); hipFree(d_cloth_nbr); hipFree(d_cloth_nbr_dir); hipFree(d_cloth_warn); hipFree(d_cloth_ext_scratch);
         hipFree(D.cloth.pos); hipFree(D.cloth.vel); hipFree(D.cloth.pos_grad); hipFree(D.cloth.vel_grad); hipFree(D.cloth.ext_f);
         hipFree(D.cloth.ext_f_grad); hipFree(D.cloth.contact_id); hipFree(D.cloth.penetration); hipFree(D.cloth.contact_before);
@@ -865,7 +869,46 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     // Re-bin frame f (smac_sort.hpp).  The frame is rewritten in the new order and gets a new epoch.
-    int sort_frame(int f, bool read_drift = false) {
+    // ---- a particle out-ran its binning (k_g2p / the scatter kernels raised the drift flag): instead of failing, the frames of the
+    // epoch in use are recomputed from its first frame - which is intact and freshly binned - with a re-sort before every substep.
+    // What cannot be replayed stays an error: the slab phases (neighbours would have to replay too), particle actions (one buffer,
+    // already overwritten by later env steps) and a backward pass that has already consumed the bad frames.
+    int fwd_head = -1;                 // frame the forward pass has reached (f + 1 of the last substep)
+    bool repairing = false, bwd_since_fwd = false, slab_phase_used = false;
+    double* ext_snap = nullptr;        // ext_f (and the cloth's) at the start of the current epoch: the replay re-accumulates from there
+    double* cloth_ext_snap = nullptr;
+    int snapshot_ext() {
+        const int Pn = D.P > 0 ? D.P : 1;
+        if (!ext_snap) HIP_TRY(hipMalloc((void**)&ext_snap, Pn * 6 * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(ext_snap, D.ext_f, Pn * 6 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (D.cloth.present) {
+            if (!cloth_ext_snap) HIP_TRY(hipMalloc((void**)&cloth_ext_snap, (size_t)D.cloth.V * 3 * sizeof(double)));
+            HIP_TRY(hipMemcpyAsync(cloth_ext_snap, D.cloth.ext_f, (size_t)D.cloth.V * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+        return SMAC_OK;
+    }
+    int repair_drift(int f_end, int e_bad) {
+        if (repairing || bwd_since_fwd || slab_phase_used || D.n_control > 0 || e_bad <= 0 || !epochs[e_bad].live || !ext_snap) return SMAC_ERR_INVALID;
+        const int fs = epochs[e_bad].frame;
+        if (!(fs < f_end) || frame_epoch[fs] != e_bad) return SMAC_ERR_INVALID;
+        repairing = true;
+        const int Pn = D.P > 0 ? D.P : 1;
+        int rc = SMAC_OK;
+        if (hipMemcpyAsync(D.ext_f, ext_snap, Pn * 6 * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) rc = SMAC_ERR_HIP;
+        if (!rc && D.cloth.present && cloth_ext_snap &&
+            hipMemcpyAsync(D.cloth.ext_f, cloth_ext_snap, (size_t)D.cloth.V * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) rc = SMAC_ERR_HIP;
+        const int keep = sort_interval;
+        sort_interval = 1;
+        epochs[e_bad].interval = 1;                          // frame fs keeps its (fresh) binning; every later frame is re-binned before it is used
+        for (int g = fs; g < f_end && !rc; ++g) rc = substep_phase(g, nullptr, -1);
+        sort_interval = keep;
+        repairing = false;
+        ++drift_repairs;
+        return rc;
+    }
+    int drift_repairs = 0;
+
+    int sort_frame(int f, bool read_drift = false, bool allow_repair = true) {
         const int e_old = frame_epoch[f];
         gc_epochs();
         const int e_new = new_epoch_slot();
@@ -943,10 +986,16 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMalloc((void**)&slab, slab_chunks * TILE_WORDS * sizeof(Vec4<R>)));
             HIP_TRY(hipMalloc((void**)&d_cand, slab_chunks * sizeof(int)));
         }
+        if (drifted == 2) {
+            err = kHitOverflowMessage;
+            return SMAC_ERR_INVALID;
+        }
         if (drifted) {
+            if (allow_repair && repair_drift(f, e_old) == SMAC_OK) return sort_frame(f, true, false);   // frame f is recomputed: bin it again
             err = kDriftMessage;
             return SMAC_ERR_INVALID;
         }
+        if ((rc = snapshot_ext())) return rc;
         return check_launch();
     }
     // make epoch e the one the kernels see; the grid blocks the previous epoch may have dirtied are zeroed
@@ -1008,8 +1057,14 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h) {
             HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
-            err = h == 2 ? "more than 1/8 of the particles were inside a contact band in one substep: its hit list does not fit the grid "
-                           "checkpoint (create the handle with flags bit 0 - recompute_backward - for such scenes)" : kDriftMessage;
+            if (h == 1 && fwd_head > 0 && frame_epoch[fwd_head] > 0 && repair_drift(fwd_head, frame_epoch[fwd_head]) == SMAC_OK) {
+                int h2 = 0;                                   // the replay (re-binning before every substep) must itself come out clean
+                HIP_TRY(hipMemcpyAsync(&h2, d_drift, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (!h2) return SMAC_OK;
+                HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
+            }
+            err = h == 2 ? kHitOverflowMessage : kDriftMessage;
             return SMAC_ERR_INVALID;
         }
         return SMAC_OK;
@@ -1044,6 +1099,15 @@ template <class R> struct Sim final : ISim {
             return SMAC_OK;
         } else REQUIRE(false, "set_param: unknown parameter (plasticity | yield_ratio | mass_eps | cloth_pairs_flat)");
         ++config_gen;                                   // the forward grids on file were made with the old value
+        return SMAC_OK;
+    }
+    int get_param(const char* name, double* value) override {
+        REQUIRE(name && value, "get_param: null argument");
+        if (!strcmp(name, "drift_repairs")) *value = (double)drift_repairs;             // epochs recomputed because a particle out-ran its binning
+        else if (!strcmp(name, "plasticity")) *value = (double)D.mat.plast;
+        else if (!strcmp(name, "yield_ratio")) *value = (double)D.mat.yield_c;
+        else if (!strcmp(name, "mass_eps")) *value = (double)D.m_eps;
+        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | plasticity | yield_ratio | mass_eps)");
         return SMAC_OK;
     }
     int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,
@@ -1382,7 +1446,10 @@ template <class R> struct Sim final : ISim {
                 prof_end();
             }
             frame_epoch[f + 1] = e;
+            fwd_head = f + 1;
+            bwd_since_fwd = false;
         }
+        if (phase >= 0) slab_phase_used = true;
         return check_launch();
     }
     int substep(int f, const double* action) override { return substep_phase(f, action, -1); }
@@ -1401,6 +1468,10 @@ template <class R> struct Sim final : ISim {
     int substep_grad_phase(int f, const double* action, const double* ext_f_grad, double* action_grad_out, int phase) {
         int rc;
         if ((rc = need_grad())) return rc;
+        if (phase <= 0 && !bwd_since_fwd) {                 // first backward substep after a forward pass: a drifted epoch is repaired (or reported) now
+            if ((rc = check_drift())) return rc;
+            bwd_since_fwd = true;
+        }
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep_grad: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] > 0, "substep_grad: frame f was not produced/consumed by a forward substep");
         const int e = frame_epoch[f];
@@ -1939,6 +2010,7 @@ int smac_profile_get(smac_handle h, int i, char* name, int name_cap, double* tot
 int smac_count_active_cells(smac_handle h, int f, int64_t* cells) { return FWD(count_active_cells(f, cells)); }
 int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit) { return FWD(contact_counts(nhits, nchunks_hit)); }
 int smac_set_param(smac_handle h, const char* name, double value) { return FWD(set_param(name, value)); }
+int smac_get_param(smac_handle h, const char* name, double* value) { return FWD(get_param(name, value)); }
 int smac_cloth_create(smac_handle h, int n_vertices, int n_faces, const int32_t* faces, int n_neighbors, const int32_t* neighbor_faces,
                       const int8_t* neighbor_dir, double friction, double softness, double cloth_force_scale, int sticky, double mpm_scale) {
     return FWD(cloth_create(n_vertices, n_faces, faces, n_neighbors, neighbor_faces, neighbor_dir, friction, softness, cloth_force_scale, sticky, mpm_scale));

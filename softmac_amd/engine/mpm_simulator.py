@@ -299,6 +299,11 @@ class MPMSimulator:
                      C.c_double(float(weight)), 1 if add_grad else 0, _ffi.dptr(out))
         return float(out[0]), out[1:].copy()
 
+    def get_param(self, name):
+        v = C.c_double(0.0)
+        self._h.call("smac_get_param", name.encode(), C.byref(v))
+        return float(v.value)
+
     def contact_counts(self):
         """(particles inside a contact band, work items holding one) after the most recent forward substep."""
         a, b = C.c_int32(0), C.c_int32(0)

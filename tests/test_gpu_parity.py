@@ -183,6 +183,35 @@ def test_seed_placed_before_the_frame_was_binned():
         assert H.rel_err(got.reshape(N, -1), ref.numpy().reshape(N, -1)) < 1e-8
 
 
+def test_particles_that_outrun_their_binning_are_recomputed():
+    """A cloud at rest under an enormous acceleration: the re-sort interval is chosen from the speed at sort time (zero), so inside the
+    32-substep interval the cloud falls more than the 4-cell halo a binning is good for.  Round 1 reported that as an error; now the epoch is
+    recomputed from its first frame with a re-sort before every substep, and the result equals the oracle."""
+    n_grid, N, n = 32, 1500, 30
+    state = H.make_cloud(N, n_grid, seed=21, lo=(0.3, 0.6, 0.3), hi=(0.6, 0.8, 0.6), v_std=0.0)
+    state[:, 3:6] = 0.0
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, gravity=(0., -9000., 0.), ground_friction=0.0, precision="float64", sort_interval=32, max_steps=40)
+    P = H.oracle_params(cfg, 1e-3)
+    orc = H.OracleRollout(P, state).forward(n)
+    fall = (state[:, 1] - orc.frames[n][0][:, 1].numpy()).max() * n_grid
+    assert fall > 4.5                                   # cells: beyond the halo
+    sim, _ = H.build_engine(cfg, 1e-3)
+    sim.reset(state)
+    sim.run_substeps(0, n)
+    st = sim.get_state(n)                               # (the IO entry point is where the flag is read when no re-sort came first)
+    assert sim.get_param("drift_repairs") >= 1
+    x, v, C, F = orc.frames[n]
+    assert H.rel_err(st[:, 0:3], x.numpy()) < 1e-9 and H.rel_err(st[:, 3:6], v.numpy()) < 1e-9
+    rng = np.random.default_rng(4)
+    sn = (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), None, None)
+    adj, _, _ = orc.backward({n: sn})
+    sim.clear_grads()
+    sim.add_grad(n, gx=sn[0], gv=sn[1])
+    sim.run_substeps_grad(0, n)
+    gx, gv = sim.get_grad(0)
+    assert H.rel_err(gx, adj[0][0].numpy()) < 1e-8 and H.rel_err(gv, adj[0][1].numpy()) < 1e-8
+
+
 def test_fast_particles_shorten_the_resort_interval():
     """A cloud crossing 5.4 cells in 14 substeps with sort_interval 16: more than the 4-cell halo a binning is good
     for, so the library has to re-bin on its own schedule (0.38 cells per substep -> every 5 substeps)."""

@@ -319,6 +319,9 @@ __device__ __forceinline__ int xcd_chunk(int nchunks) {
     const int c = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     return c;
 }
+// The per-cell grid kernels give every wave one active block (4 per workgroup), in the order of the active list.  (XCD-contiguous ranges, as for
+// the chunks, were measured and made k_grid_op / k_reduce_* 0.5 us slower each: profiles/r02_ad_g2p_lds_gather.txt.)
+template <class R> __device__ __forceinline__ int active_slot(const DevSim<R>&) { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
 #define SMAC_CHUNK_PROLOGUE                                   \
     const int cid = xcd_chunk(D.nchunks);                     \
     if (cid >= D.nchunks) return;                             \
@@ -400,9 +403,10 @@ __device__ __forceinline__ void gather_tile_load(const DevSim<R>& D, const Vec4<
     for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
         const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
         const int i = 4 * bx + li, j = 4 * by + lj, k = 4 * bz + lk;
-        Vec4<R> v = {R(0), R(0), R(0), R(0)};
-        if (i < D.n && j < D.n && k < D.n) v = field[cell_of(nb, i, j, k)];
-        gt[idx] = v;
+        // (pointer select, not "zero record overwritten by a load": that form leaves a 16-byte per-thread temporary which the compiler promotes to LDS)
+        const Vec4<R>* src = (i < D.n && j < D.n && k < D.n) ? field + cell_of(nb, i, j, k) : nullptr;
+        if (src) gt[idx] = *src;
+        else { gt[idx].x = R(0); gt[idx].y = R(0); gt[idx].z = R(0); gt[idx].w = R(0); }
     }
 }
 
@@ -424,7 +428,7 @@ __device__ __forceinline__ void gather_tile_load_fwd(const DevSim<R>& D, int fie
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_clear_active(DevSim<R> D, Vec4<R>* base, int nfields) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }   // contact lists are rebuilt by k_p2g
-    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int a = active_slot(D);
     if (a >= D.nactive) return;
     const size_t cell = (size_t)D.active[a] * 64 + (threadIdx.x & 63);
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, H
         if (blockIdx.x == 0 && threadIdx.x == 0) *nhit_ck = nh;
         for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += gridDim.x * BLOCK) hit_ck[i] = D.hits[i];
     }
-    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int a = active_slot(D);
     if (a >= D.nactive) return;
     const int l = threadIdx.x & 63;
     const size_t cell = (size_t)D.active[a] * 64 + l;
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
         if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = nh; *D.ncand = 0; }
         for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += gridDim.x * BLOCK) D.hits[i] = hit_ck[i];
     } else if (blockIdx.x == 0 && threadIdx.x == 0) { *D.nhits = 0; *D.ncand = 0; }
-    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int a = active_slot(D);
     if (a >= D.nactive) return;
     const int l = threadIdx.x & 63;
     const size_t cell = (size_t)D.active[a] * 64 + l;
@@ -785,7 +789,7 @@ __device__ __forceinline__ void cell_ijk(int nb, unsigned cell, int& i, int& j, 
 
 // one thread per cell of an active block; returns false past the end
 template <class R> __device__ __forceinline__ bool active_cell(const DevSim<R>& D, int& b, int& l, size_t& cell, int& i, int& j, int& k) {
-    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int a = active_slot(D);
     if (a >= D.nactive) return false;
     b = D.active[a];
     l = threadIdx.x & 63;
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
     Vec4<R>* ckp = nullptr;
     if (D.ck) {                              // {m,p} lives in the checkpoint from here on; the dense array is left ZEROED for the next
-        ckp = D.ck + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 192 + l;           // P2G's drifted atomics (no clear pass)
+        ckp = D.ck + (size_t)active_slot(D) * 192 + l;           // P2G's drifted atomics (no clear pass)
         ckp[0] = acc;
         D.vin[cell] = z;
     }
@@ -1000,6 +1004,7 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
         const int nb = D.nb;
         const int pb[3] = {st.base[0] >> 2, st.base[1] >> 2, st.base[2] >> 2};
         const int cbk[3] = {ch.block / (nb * nb), (ch.block / nb) % nb, ch.block % nb};
+#pragma unroll
         for (int d = 0; d < 3; ++d)
             if (pb[d] < cbk[d] - 1 || pb[d] > cbk[d] + 1) *D.drift_flag = 1;            // beyond the active halo
     }
@@ -1008,30 +1013,37 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
     // new_v = M0, new_C[c][d] = 4 inv_dx (M_d[c] - f_d M0[c])   (dpos = offset - fx, mpm_simulator.py:308-314).
     R M0[3] = {R(0), R(0), R(0)}, Mx[3] = {R(0), R(0), R(0)}, My[3] = {R(0), R(0), R(0)}, Mz[3] = {R(0), R(0), R(0)};
     const R wz1 = st.w[1][2], wz2 = R(2) * st.w[2][2], wy1 = st.w[1][1], wy2 = R(2) * st.w[2][1];
+    // Two copies of the gather, chosen per WAVE: without a drifted lane every node is a plain ds_read_b128 of the tile.  Written as ONE
+    // loop with a per-lane choice, the compiler folds "LDS value, overridden from global memory for drifted lanes" into a flat load through
+    // a selected pointer - 27 flat_load per particle also for the waves that never leave LDS (found in the ISA, round 2).
+    auto gather = [&](auto mixed_tag) {
+        constexpr bool MIXED = decltype(mixed_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        R s0[3] = {R(0), R(0), R(0)}, sy[3] = {R(0), R(0), R(0)}, sz[3] = {R(0), R(0), R(0)};
+        for (int i = 0; i < 3; ++i) {
+            R s0[3] = {R(0), R(0), R(0)}, sy[3] = {R(0), R(0), R(0)}, sz[3] = {R(0), R(0), R(0)};
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            // LDS reads are unconditional (index 0 for a drifted lane) so that they can be issued in batches; the global
-            // loads of drifted lanes sit behind a branch no wave without such a lane takes
-            Vec4<R> g0 = gt[all_in ? nd.tile(i, j, 0) : 0], g1 = gt[all_in ? nd.tile(i, j, 1) : 0], g2 = gt[all_in ? nd.tile(i, j, 2) : 0];
-            if (!all_in) { g0 = gld(D.vout, nd.cell(i, j, 0)); g1 = gld(D.vout, nd.cell(i, j, 1)); g2 = gld(D.vout, nd.cell(i, j, 2)); }
-            const R r0[3] = {st.w[0][2] * g0.x + st.w[1][2] * g1.x + st.w[2][2] * g2.x, st.w[0][2] * g0.y + st.w[1][2] * g1.y + st.w[2][2] * g2.y,
-                             st.w[0][2] * g0.z + st.w[1][2] * g1.z + st.w[2][2] * g2.z};
-            const R r1[3] = {wz1 * g1.x + wz2 * g2.x, wz1 * g1.y + wz2 * g2.y, wz1 * g1.z + wz2 * g2.z};
-            const R wyj = st.w[j][1];
+            for (int j = 0; j < 3; ++j) {
+                Vec4<R> g0, g1, g2;
+                if (MIXED && !all_in) { g0 = gld(D.vout, nd.cell(i, j, 0)); g1 = gld(D.vout, nd.cell(i, j, 1)); g2 = gld(D.vout, nd.cell(i, j, 2)); }
+                else { g0 = gt[nd.tile(i, j, 0)]; g1 = gt[nd.tile(i, j, 1)]; g2 = gt[nd.tile(i, j, 2)]; }
+                const R r0[3] = {st.w[0][2] * g0.x + st.w[1][2] * g1.x + st.w[2][2] * g2.x, st.w[0][2] * g0.y + st.w[1][2] * g1.y + st.w[2][2] * g2.y,
+                                 st.w[0][2] * g0.z + st.w[1][2] * g1.z + st.w[2][2] * g2.z};
+                const R r1[3] = {wz1 * g1.x + wz2 * g2.x, wz1 * g1.y + wz2 * g2.y, wz1 * g1.z + wz2 * g2.z};
+                const R wyj = st.w[j][1];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { s0[c] += wyj * r0[c]; sz[c] += wyj * r1[c]; }
-            if (j == 1) { for (int c = 0; c < 3; ++c) sy[c] += wy1 * r0[c]; }
-            if (j == 2) { for (int c = 0; c < 3; ++c) sy[c] += wy2 * r0[c]; }
+                for (int c = 0; c < 3; ++c) { s0[c] += wyj * r0[c]; sz[c] += wyj * r1[c]; }
+                if (j == 1) { for (int c = 0; c < 3; ++c) sy[c] += wy1 * r0[c]; }
+                if (j == 2) { for (int c = 0; c < 3; ++c) sy[c] += wy2 * r0[c]; }
+            }
+            const R wxi = st.w[i][0];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { M0[c] += wxi * s0[c]; My[c] += wxi * sy[c]; Mz[c] += wxi * sz[c]; }
+            if (i == 1) { for (int c = 0; c < 3; ++c) Mx[c] += wxi * s0[c]; }
+            if (i == 2) { for (int c = 0; c < 3; ++c) Mx[c] += R(2) * wxi * s0[c]; }
         }
-        const R wxi = st.w[i][0];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { M0[c] += wxi * s0[c]; My[c] += wxi * sy[c]; Mz[c] += wxi * sz[c]; }
-        if (i == 1) { for (int c = 0; c < 3; ++c) Mx[c] += wxi * s0[c]; }
-        if (i == 2) { for (int c = 0; c < 3; ++c) Mx[c] += R(2) * wxi * s0[c]; }
-    }
+    };
+    if (__all(all_in)) gather(std::false_type{});
+    else gather(std::true_type{});
     R nv[3], nC[9];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -1666,7 +1678,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    const Vec4<R> in = D.ck ? D.ck[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 192 + l] : D.vin[cell];
+    const Vec4<R> in = D.ck ? D.ck[(size_t)active_slot(D) * 192 + l] : D.vin[cell];
     const Vec4<R> go = D.aout[cell];
     const Vec4<R> zero4 = {R(0), R(0), R(0), R(0)};
     Vec4<R> gm_ = zero4;

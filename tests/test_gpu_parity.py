@@ -61,12 +61,13 @@ def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None
         got_ag.append(sim.substep_grad(f, None if actions is None else actions[f], ext_f_grad))
     got_ag = got_ag[::-1]
     gx, gv, gF, gC = sim.get_grad_full(0)
-    zone = H.clamp_zone(orc, P, nsteps)
-    gerrs, zerrs = {}, {}
+    zone, near = H.clamp_zone(orc, P, nsteps, neighbours=True)
+    gerrs, nerrs, zerrs = {}, {}, {}
     for k, got, ref in (("gx", gx, adj[0][0]), ("gv", gv, adj[0][1]), ("gC", gC, adj[0][2]), ("gF", gF, adj[0][3])):
-        gerrs[k], zerrs[k] = H.rel_err_split(got, ref.numpy(), zone)
+        gerrs[k], nerrs[k], zerrs[k] = H.rel_err_tiers(got, ref.numpy(), zone, near)
     for k, e in gerrs.items():
         assert e < tol.get(k, tol["grad"]), (k, e, gerrs)
+        assert nerrs[k] < tol.get("near_clamp", tol["grad"]), ("next to the clamp zone", k, nerrs, int(near.sum()))
         assert zerrs[k] < tol.get("clamp", tol["grad"]), ("clamp zone", k, zerrs, int(zone.sum()))
     if prim_specs:
         for i, m in enumerate(prims):

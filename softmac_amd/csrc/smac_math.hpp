@@ -571,15 +571,29 @@ SMAC_HD double fast_sqrt(double x) { return std::sqrt(x); }
 
 // One Jacobi rotation on the symmetric matrix {a00,a01,a02,a11,a12,a22} in the (p,q) plane,
 // accumulated into V (columns = eigenvectors).  Written out per pair to keep everything in registers.
+// tan 2θ = b / d with d = aqq - app, b = 2 apq.  With r = |(d, b)| and the small-angle root:
+//     cos²θ = (1 + |d| / r) / 2,     sinθ cosθ = sgn(d) b / (2 r),     t = tanθ = sinθ / cosθ
+// which takes two reciprocal square roots where the textbook form (tau = d / b, t = sgn / (|tau| + sqrt(1 + tau²)), c = rsqrt(1 + t²))
+// takes four quarter-rate operations; no quantity is a difference of nearly equal numbers, so s and t keep full relative precision
+// for the tiny angles of the last sweep.  c² + s² = 1 to the rounding of the second rsqrt, as before.
+template <class R> struct tiny_of;
+template <> struct tiny_of<float> { static constexpr float v = 1.0e-30f, huge = 1.0e37f; };
+template <> struct tiny_of<double> { static constexpr double v = 1.0e-280, huge = 1.0e300; };
 template <class R> SMAC_HD void jacobi_cs(R app, R aqq, R apq, R& c, R& s, R& t) {
     SMAC_PRECISE_FP
-    if (apq == R(0)) { c = R(1); s = R(0); t = R(0); return; }
-    R tau = (aqq - app) * fast_rcp(R(2) * apq);
-    R at = tau < R(0) ? -tau : tau;
-    t = at > R(1e18) ? R(0) : fast_rcp(at + fast_sqrt(R(1) + tau * tau));     // huge tau: rotation is the identity
-    if (tau < R(0)) t = -t;
-    c = fast_rsqrt(R(1) + t * t);
-    s = t * c;
+    const R d = aqq - app, b = R(2) * apq;
+    const R rr = d * d + b * b;
+    // apq = 0: nothing to rotate.  rr below the underflow guard (strains under 1e-15): the rotation would change nothing representable;
+    // rr overflowed (an exploded state): left alone, as the textbook form did for a huge tau.
+    if (apq == R(0) || !(rr > tiny_of<R>::v && rr < tiny_of<R>::huge)) { c = R(1); s = R(0); t = R(0); return; }
+    const R rinv = fast_rsqrt(rr);
+    const R ad = d < R(0) ? -d : d;
+    const R c2 = R(0.5) + R(0.5) * (ad * rinv);
+    const R cinv = fast_rsqrt(c2);
+    c = c2 * cinv;
+    s = (R(0.5) * b * rinv) * cinv;
+    if (d < R(0)) s = -s;
+    t = s * cinv;
 }
 
 // SVD of F = I + E for the constitutive model: F = U diag(1+e) V^T.
@@ -628,9 +642,10 @@ template <class R> SMAC_HD void svd_I_plus_E(const R* E, R* U, R* e, R* V) {
     for (int i = 0; i < 9; ++i) B[i] += V[i];
     for (int i = 0; i < 3; ++i) {
         R hi = h[i] > R(-1) ? h[i] : R(-1);
-        R sg = std::sqrt(R(1) + hi);
-        e[i] = hi / (R(1) + sg);
-        R inv = sg > R(1e-20) ? R(1) / sg : R(0);
+        R s2 = R(1) + hi;
+        R inv = s2 > R(1e-38) ? fast_rsqrt(s2) : R(0);              // 1 / sigma_i (one rsqrt gives sigma_i and its reciprocal)
+        R sg = s2 * inv;
+        e[i] = hi * fast_rcp(R(1) + sg);
         U[i] = B[i] * inv; U[3 + i] = B[3 + i] * inv; U[6 + i] = B[6 + i] * inv;
     }
     // inverted element: flip the smallest singular value and its U column

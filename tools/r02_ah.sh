@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 2, GPU session AH: fixed-point tile words rounded with v_cvt_rpi (1 instruction instead of 2), Jacobi rotation from two rsqrt (instead of rcp sqrt rcp rsq) vs the previous commit, 4 processes each; parity suites
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02ah; mkdir -p $O
+make -C oracle -s
+bash tools/ab_runs.sh $O 4 prev=libsoftmac_hip_prev.so new=libsoftmac_hip.so 2>&1 | tail -3
+python3 - $O <<'PY'
+import json, sys, glob
+O = sys.argv[1]
+for label in ("prev", "new"):
+    acc = {}; best = []
+    for f in sorted(glob.glob(f"{O}/run_{label}_*.json")):
+        d = json.loads([l for l in open(f) if l.startswith('{')][-1])
+        best.append(min(d['ms_per_step_all']))
+        for k, v in d['kernels_ms'].items():
+            acc.setdefault(k, []).append(round(v * 1e3, 1))
+    print(label, 'best window ms', best, {k: v for k, v in acc.items() if k in ('g2p', 'p2g_grad', 'g2p_grad', 'p2g')})
+PY
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_cloth.py -m gpu -q -x > $O/pytest.log 2>&1; tail -2 $O/pytest.log

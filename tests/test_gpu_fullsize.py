@@ -130,15 +130,17 @@ def test_fullsize_adjoint_dot_product_and_linearity(ptype, model, tol):
     assert H.rel_err(g3, 2.5 * g + g2) < 1e-11
 
 
-def _rebinning_outputs(precision, si, nsub=20):
+def _rebinning_outputs(precision, si, nsub=20, with_zone=True):
     cfg, env_dt, state, specs, pst, sim, prm = _engine(precision, max_steps=nsub + 4, sort_interval=si)
     N = cfg.n_particles
     sim.reset(state)
     sim.run_substeps(0, nsub)
     st = sim.get_state(nsub)
-    # particles that enter the reference's SVD-adjoint clamp at some frame of the window (helpers.F32_TOL "clamp")
+    # particles that enter the reference's SVD-adjoint clamp at some frame of the window (helpers.F32_TOL "clamp"); the window is 4x the
+    # clamp's own 1e-6, so the zone of ONE rollout covers the other two (their states differ by 1e-6 at most) - 20 batched SVDs of 1M
+    # matrices per rollout are most of this test's time
     zone = np.zeros(N, dtype=bool)
-    for f in range(nsub):
+    for f in range(nsub if with_zone else 0):
         s = sim.get_state(f)
         Ft = (np.eye(3)[None] + cfg.dt * s[:, 15:24].reshape(N, 3, 3)) @ s[:, 6:15].reshape(N, 3, 3)
         s2 = np.linalg.svd(Ft, compute_uv=False) ** 2
@@ -161,7 +163,7 @@ def test_fullsize_rebinning_invariance(precision):
     multiplies the difference itself - a 3e-10 change of F moves the reference's own f64 gradient of such a particle by up to
     1e-4 per substep.  f64 rollouts agree to 1e-8 for every particle (deterministic check of the re-ordering code); in f32
     the clamp-zone particles (~0.1 % per frame) are bounded separately, all others in max-norm."""
-    outs = [_rebinning_outputs(precision, si) for si in (1, 16, 1000)]
+    outs = [_rebinning_outputs(precision, si, with_zone=(si == 1)) for si in (1, 16, 1000)]
     N = outs[0][0].shape[0]
     per = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).reshape(N, -1).max(1) / np.abs(np.asarray(b)).max()
     # f32: two 20-substep rollouts that differ only in summation order - a 1e-7 perturbation per substep, carried through

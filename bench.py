@@ -88,6 +88,8 @@ KERNEL_BYTES = {
     "g2p_grad": (3 + 15 + 3, 3 + 3), "contact_grad": (0, 0), "grid_op_grad": (0, 4 + 6 + 4), "p2g_grad": (24 + 9 + 3 + 24, 4),
     "clear_grid": (0, 10), "grid_checkpoint": (0, 20), "reduce_agvout": (0, 6), "forward_kinematics": (0, 0),
     "sort": (48, 0), "reorder_adjoint": (48, 0),
+    # p2g.grad of substep f + g2p.grad of substep f-1 in one launch: p2g.grad's rows, + x of frame f-1 and its x.grad; both gather tiles + the slab
+    "p2g_g2p_grad": (24 + 9 + 3 + 24 + 3 + 3, 4 + 3 + 3),
 }
 
 

@@ -81,6 +81,7 @@ template <class R> struct DevSim {
     R* S;
     R* A;
     R* Af;                       // adjoint frame of the substep being reversed (frames may live in rolling slots: set per launch)
+    R* Af_prev;                  // adjoint frame f - 1 (k_p2g_g2p_grad only)
     // grid: one 4-scalar record per cell and field, so a stencil node is ONE 16-byte access
     Vec4<R> *vin, *vmix, *vout;         // {m, p_x, p_y, p_z} / {v_mixed, 0} / {v_out, 0}
     Vec4<R> *ain, *amix, *aout;         // adjoints: {grid_m.grad, grid_v_in.grad} / {grid_v_mixed.grad, 0} / {grid_v_out.grad, 0}
@@ -1178,38 +1179,19 @@ template <class R> struct WGrad {
     }
 };
 
+// G2P adjoint of one chunk, from the adjoint of the substep's outputs held in registers: gx1 = x'.grad, gnv = v'.grad + dt x'.grad, gC1 = 4 inv_dx C'.grad
+// (all zero for an idle lane).  `x` are the positions the substep started from, `gt` the staged grid_v_out tile, `tile_raw` the zeroed scatter
+// tile; writes x.grad to `Af`, the node adjoints to the chunk's slab.  Every thread of the workgroup calls it (two barriers).
 template <class R, bool ACC_X>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k_g2p_grad(DevSim<R> D, int f) {
+__device__ __forceinline__ void g2p_grad_chunk(const DevSim<R>& D, const Chunk& ch, int p, int t, bool valid, const typename pos_of<R>::type* x,
+                                               const R* gx1, const R* gnv, const R* gC1, R* Af, double* tile_raw, const Vec4<R>* gt, R* smax) {
     typedef typename ScatterTile<R>::word W;
-    __shared__ double tile_raw[3 * TILE_WORDS];
-    __shared__ Vec4<R> gt[TILE_WORDS];
-    __shared__ R smax[4];
-    SMAC_CHUNK_PROLOGUE
     W* const tile = (W*)tile_raw;
     double* const tile64 = tile_raw;
     const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;       // f64 words instead of fixed point (see SPARSE_MAX)
-    if (sparse) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
-    else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
-    gather_tile_load_fwd(D, 2, ch.block, gt);       // (its barrier is the one inside tile_scale below: the particle loads
-                                                    //  that follow are then in flight together with the tile's)
-    typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
-    R gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) gC1[c] = R(0);
+    (void)t;
     R bound = R(0);                       // no single scattered component of this particle exceeds it
     if (valid) {
-        const R* Sf = frame(D.S, f, D.Npad);
-        const R* An = D.An;
-        R gv1[3];
-        load_pos(Sf, D.Npad, p, x);
-        load_vec(An, CX, 3, D.Npad, p, gx1);
-        load_vec(An, CV, 3, D.Npad, p, gv1);
-        load_vec(An, CC, 9, D.Npad, p, gC1);
-        const R four_inv_dx = R(4) * D.inv_dx;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gnv[c] = gv1[c] + D.dt * gx1[c];                        // x' = x + dt v'
-#pragma unroll
-        for (int c = 0; c < 9; ++c) gC1[c] *= four_inv_dx;
 #pragma unroll
         for (int c = 0; c < 3; ++c)      // |w (gnv + gC (offset - fx))|
             bound = maxc(bound, R(W_MAX) * abs_(gnv[c]) + R(WD_MAX) * (abs_(gC1[3 * c]) + abs_(gC1[3 * c + 1]) + abs_(gC1[3 * c + 2])));
@@ -1217,7 +1199,6 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     R to_tile, from_tile;
     tile_scale<R>(bound, smax, to_tile, from_tile);                                        // one barrier (all threads)
     if (valid) {
-        R* Af = D.Af;
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, ch.block);
@@ -1306,6 +1287,42 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     __syncthreads();
     if (sparse) tile_store<R, 3>(D, tile64, R(1), R(1));
     else tile_store<R, 3>(D, tile, from_tile, from_tile);
+}
+
+
+template <class R, bool ACC_X>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k_g2p_grad(DevSim<R> D, int f) {
+    typedef typename ScatterTile<R>::word W;
+    __shared__ double tile_raw[3 * TILE_WORDS];
+    __shared__ Vec4<R> gt[TILE_WORDS];
+    __shared__ R smax[4];
+    SMAC_CHUNK_PROLOGUE
+    W* const tile = (W*)tile_raw;
+    double* const tile64 = tile_raw;
+    const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;
+    if (sparse) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
+    else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
+    gather_tile_load_fwd(D, 2, ch.block, gt);       // (its barrier is the one inside tile_scale: the particle loads
+                                                    //  that follow are then in flight together with the tile's)
+    typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+    R gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gC1[c] = R(0);
+    if (valid) {
+        const R* Sf = frame(D.S, f, D.Npad);
+        const R* An = D.An;
+        R gv1[3];
+        load_pos(Sf, D.Npad, p, x);
+        load_vec(An, CX, 3, D.Npad, p, gx1);
+        load_vec(An, CV, 3, D.Npad, p, gv1);
+        load_vec(An, CC, 9, D.Npad, p, gC1);
+        const R four_inv_dx = R(4) * D.inv_dx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gnv[c] = gv1[c] + D.dt * gx1[c];                        // x' = x + dt v'
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gC1[c] *= four_inv_dx;
+    }
+    g2p_grad_chunk<R, ACC_X>(D, ch, p, t, valid, x, gx1, gnv, gC1, D.Af, tile_raw, gt, smax);
 }
 
 // completes the G2P-adjoint scatter: grid_v_out.grad += sum of overlapping slabs
@@ -1759,17 +1776,14 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
 // that at most 9 nodes of loads are in flight: 4 waves/SIMD instead of 1.
 constexpr int STASH = SMAC_GFN_STASH ? 43 : 34;   // U9 V9 e3 ep3 Et9 Jm1 (gFn9): parked in LDS across the gather loop
 template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SMAC_OCC_P2GG : 2; };   // waves/SIMD asked of the register allocator
-template <class R, bool ACC_VCF, bool PCON>
-__global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
+// p2g.grad + svd_grad + compute_F_tmp.grad of one particle (mpm_simulator.py:371-374): `gt` is the staged grid_v_in.grad / grid_m.grad tile, `stash` the
+// workgroup's LDS parking space.  Writes the adjoint of frame f to D.Af; KEEP: also hands x.grad, v.grad, C.grad of frame f back in registers
+// (k_p2g_g2p_grad feeds them to the G2P adjoint of the substep before) - only with ACC_VCF = false, i.e. when frame f carried no seed.
+template <class R, bool ACC_VCF, bool PCON, bool KEEP>
+__device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, const Chunk& ch, int p, int t, typename const_t<R>::type* stash, const Vec4<R>* gt,
+                                                  R* gx_o, R* gv_o, R* gC_o) {
     constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
     typedef typename const_t<R>::type CT;
-    __shared__ CT stash[(STASH + (STASH_CE ? 18 : 0)) * BLOCK];
-    static_assert(!STASH_CE || !SMAC_GFN_STASH, "the C / E stash slots would collide with gFn's");
-    __shared__ Vec4<R> gt[TILE_WORDS];
-    SMAC_CHUNK_PROLOGUE
-    gather_tile_load(D, D.ain, ch.block, gt);
-    __syncthreads();
-    if (!valid) return;
     const R* Sf = frame(D.S, f, D.Npad);
     const R* An = D.An;
     R* Af = D.Af;
@@ -1937,10 +1951,12 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
         for (int d = 0; d < 3; ++d) atomic_add(D.action_grad + 3 * ci + d, R(6e-4) * D.dt * gvp[d]);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        Af[rowoff(CX + d, p, D.Npad)] += D.inv_dx * gfx[d];
+        const R gxx = Af[rowoff(CX + d, p, D.Npad)] + D.inv_dx * gfx[d];
+        Af[rowoff(CX + d, p, D.Npad)] = gxx;
         const R gvv = D.p_mass * gvp[d];
         if (ACC_VCF) Af[rowoff(CV + d, p, D.Npad)] += gvv;
         else row_store_nt(&Af[rowoff(CV + d, p, D.Npad)], gvv);
+        if (KEEP) { gx_o[d] = gxx; gv_o[d] = gvv; }
     }
     // constitutive adjoint
     R gEt[9];
@@ -1993,7 +2009,59 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
             row_store_nt(&Af[rowoff(CC + i, p, D.Npad)], gc);
             row_store_nt(&Af[rowoff(CF + i, p, D.Npad)], gE[i]);
         }
+        if (KEEP) gC_o[i] = gc;
     }
+}
+
+template <class R, bool ACC_VCF, bool PCON>
+__global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
+    typedef typename const_t<R>::type CT;
+    __shared__ CT stash[STASH * BLOCK];
+    __shared__ Vec4<R> gt[TILE_WORDS];
+    SMAC_CHUNK_PROLOGUE
+    gather_tile_load(D, D.ain, ch.block, gt);
+    __syncthreads();
+    if (!valid) return;
+    p2g_grad_particle<R, ACC_VCF, PCON, false>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr);
+}
+
+// k_p2g_grad of substep f and k_g2p_grad of substep f - 1 in one launch.  Between two re-sorts a particle keeps its chunk, and the adjoint of
+// (x, v, C) at frame f that p2g.grad completes is exactly the input of the G2P adjoint one substep earlier: it stays in registers (15 rows of
+// reads, a kernel boundary and a workgroup prologue less per backward substep; the rows are still written, so every adjoint frame stays readable).
+// The host restores the forward grid of substep f - 1 BEFORE this launch (k_grid_restore leaves grid_v_in.grad alone), so `grid_v_out` is the
+// earlier substep's while `grid_v_in.grad` is still this one's.  D.Af_prev: adjoint frame f - 1.  ACC_X: frame f - 1 carries a seed.
+template <class R, bool ACC_X>
+__global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_g2p_grad(DevSim<R> D, int f) {
+    typedef typename const_t<R>::type CT;
+    typedef typename ScatterTile<R>::word W;
+    __shared__ CT stash[STASH * BLOCK];
+    __shared__ Vec4<R> gt[TILE_WORDS];          // grid_v_in.grad, grid_m.grad of substep f
+    __shared__ double tile_raw[3 * TILE_WORDS];  // scatter tile of grid_v_out.grad of substep f - 1
+    __shared__ Vec4<R> gtv[TILE_WORDS];         // grid_v_out of substep f - 1
+    __shared__ R smax[4];
+    SMAC_CHUNK_PROLOGUE
+    W* const tile = (W*)tile_raw;
+    double* const tile64 = tile_raw;
+    if (sizeof(R) == 4 && ch.count <= SPARSE_MAX) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
+    else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
+    gather_tile_load(D, D.ain, ch.block, gt);
+    gather_tile_load_fwd(D, 2, ch.block, gtv);
+    typename pos_of<R>::type xp[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+    if (valid) load_pos(frame(D.S, f - 1, D.Npad), D.Npad, p, xp);
+    __syncthreads();
+    R gx[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gC1[c] = R(0);
+    if (valid) {
+        R gv[3];
+        p2g_grad_particle<R, false, true, true>(D, f, ch, p, t, stash, gt, gx, gv, gC1);
+        const R four_inv_dx = R(4) * D.inv_dx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gnv[c] = gv[c] + D.dt * gx[c];                           // x' = x + dt v'
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gC1[c] *= four_inv_dx;
+    }
+    g2p_grad_chunk<R, ACC_X>(D, ch, p, t, valid, xp, gx, gnv, gC1, D.Af_prev, tile_raw, gtv, smax);
 }
 
 // ------------------------------------------------------------------------------------------

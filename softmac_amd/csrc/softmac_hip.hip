@@ -37,7 +37,7 @@ static thread_local std::string g_create_error;
         }                                    \
     } while (0)
 
-enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_COUNT };
+enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_P2G_G2P_GRAD, K_COUNT };
 static const char* kDriftMessage =
     "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort "
     "interval): the frames after that substep are invalid - lower sort_interval or dt";
@@ -45,7 +45,7 @@ static const char* kHitOverflowMessage =
     "more than 1/8 of the particles were inside a contact band in one substep: its hit list does not fit the grid "
     "checkpoint (create the handle with flags bit 0 - recompute_backward - for such scenes)";
 static const char* kKernelNames[K_COUNT] = {"clear_grid", "grid_checkpoint", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
-                                            "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint"};
+                                            "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint", "p2g_g2p_grad"};
 
 struct ISim {
     std::string err;
@@ -97,6 +97,7 @@ struct ISim {
     virtual int halo_unpack_add(const char* field, int plane0, int np, const void* dev_in) = 0;
     virtual int set_stream(void* s) = 0;
     virtual int stream_handle(void** s) = 0;
+    virtual void hint_backward_next(int f) = 0;
     virtual int set_param(const char* name, double value) = 0;
     virtual int get_param(const char* name, double* value) = 0;
     virtual int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction,
@@ -1448,6 +1449,7 @@ template <class R> struct Sim final : ISim {
             frame_epoch[f + 1] = e;
             fwd_head = f + 1;
             bwd_since_fwd = false;
+            g2p_done_frame = -1;
         }
         if (phase >= 0) slab_phase_used = true;
         return check_launch();
@@ -1459,6 +1461,23 @@ template <class R> struct Sim final : ISim {
     // of grid_v_mixed.grad phase 1.
     bool pending_adj_zero = false;
     bool direct_bwd = false;
+    // Fused backward step (k_p2g_g2p_grad): when the batched loop (smac_substeps_grad) announces that substep f - 1 is reversed next, the
+    // p2g.grad launch of substep f also does the G2P adjoint of substep f - 1 - its forward grid is restored first - and the call for f - 1
+    // resumes at the slab reduction.  SMAC_FUSED_PG=0 keeps the two kernels apart.
+    int fused_pg_env = getenv("SMAC_FUSED_PG") ? atoi(getenv("SMAC_FUSED_PG")) : 1;
+    int bwd_hint = -1;                   // frame the caller will reverse next (-1: unknown)
+    int g2p_done_frame = -1;             // substep whose restore + g2p.grad already ran inside the previous call
+    bool g2p_done_paz = false;           // ... and whether its adjoint frame started from zero
+    void hint_backward_next(int f) override { bwd_hint = f; }
+    bool can_fuse_prev(int f, int e, int phase, const double* action_grad_out) {
+        if (!fused_pg_env || sizeof(R) != 4 || phase >= 0 || bwd_hint != f - 1 || f < 1 || action_grad_out) return false;   // (f64: 256 VGPRs + 88 KB of LDS, one workgroup per CU)
+        if (!pending_adj_zero || rolling() || !fused_grid_bwd(phase) || ck_mode != 0) return false;          // frame f carried a seed / frames come and go
+        if (frame_epoch[f - 1] != e || !(adj_epoch[f - 1] < 0 || adj_epoch[f - 1] == e)) return false;        // a re-sort lies between the two substeps
+        if (!(ck_arena && ck_epoch[f - 1] == e && ck_gen[f - 1] == config_gen && D.n_control == 0 && D.nchunks > 0)) return false;
+        if (D.collision_type == CONTACT_PARTICLE || D.cloth.present) return false;
+        if (any_contact() && D.collision_type == CONTACT_MIXED && !ck_has_hits[f - 1]) return false;          // (the band test would have to run in between)
+        return true;
+    }
     // whole-substep backward without grid-node contact: k_reduce_grid_grad does k_reduce_aout's and k_grid_op_grad's work in one pass
     // (SMAC_FUSED_GRID_BWD=0 keeps the three-kernel sequence the slab phases use)
     int fused_bwd_env = getenv("SMAC_FUSED_GRID_BWD") ? atoi(getenv("SMAC_FUSED_GRID_BWD")) : 1;
@@ -1475,7 +1494,24 @@ template <class R> struct Sim final : ISim {
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep_grad: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] > 0, "substep_grad: frame f was not produced/consumed by a forward substep");
         const int e = frame_epoch[f];
-        if (phase <= 0) {
+        if (g2p_done_frame >= 0 && (g2p_done_frame != f || phase >= 0)) {
+            g2p_done_frame = -1;
+            REQUIRE(false, "substep_grad: the batched backward sweep was interrupted (its next substep had been started)");
+        }
+        if (phase < 0 && g2p_done_frame == f) {           // restore + g2p.grad of this substep ran inside the previous call (k_p2g_g2p_grad)
+            g2p_done_frame = -1;
+            if (ext_f_grad && D.P > 0) {
+                HIP_TRY(hipMemcpyAsync(D.ext_f_grad, ext_f_grad, 6 * D.P * sizeof(double), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
+            D.Af = adj_ptr(f);
+            D.An = adj_ptr(f + 1);                          // same epoch (can_fuse_prev): in this order already
+            pending_adj_zero = g2p_done_paz;
+            D.cur_frame = f;
+            prof_begin(K_REDUCE);
+            hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+            prof_end();
+        } else if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
             if (ext_f_grad && D.P > 0) {                                          // :342-344
@@ -1579,7 +1615,29 @@ template <class R> struct Sim final : ISim {
             if (cfg.rigid_velocity_control)                                       // :367-369
                 for (int i = D.P - 1; i >= 0; --i)
                     if ((rc = prim_fk_grad(i, f))) return rc;
-            if (D.nchunks > 0) {
+            if (D.nchunks > 0 && can_fuse_prev(f, e, phase, action_grad_out)) {
+                R* Af_prev = adj_ptr(f - 1);
+                REQUIRE(Af_prev, kPoolMessage);
+                const bool paz_prev = adj_epoch[f - 1] < 0;
+                const bool have_hits = ck_has_hits[f - 1] && D.any_contact && D.collision_type == CONTACT_MIXED;
+                prof_begin(K_CKPT);
+                hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f - 1),
+                                   have_hits ? (const Hit*)(ck_hits + (size_t)(f - 1) * ck_hit_cap) : (const Hit*)nullptr,
+                                   have_hits ? (const int*)(ck_nhits + (f - 1)) : (const int*)nullptr, 0);
+                prof_end();
+                DevSim<R> D2 = D;
+                D2.Af_prev = Af_prev;
+                prof_begin(K_P2G_G2P_GRAD);
+                if (paz_prev) hipLaunchKernelGGL((k_p2g_g2p_grad<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D2, f);
+                else hipLaunchKernelGGL((k_p2g_g2p_grad<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D2, f);
+                prof_end();
+                adj_epoch[f - 1] = e;
+                adj_stale[f - 1] = 0;
+                adj_grid_clean = false;
+                vin_clean = false;
+                g2p_done_frame = f - 1;
+                g2p_done_paz = paz_prev;
+            } else if (D.nchunks > 0) {
                 prof_begin(K_P2G_GRAD);
                 if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);   // :371-374
                 else hipLaunchKernelGGL((k_p2g_grad<R, true, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
@@ -1976,7 +2034,9 @@ int smac_substeps(smac_handle h, int f0, int count) {
 int smac_substeps_grad(smac_handle h, int f0, int count, const double* ext_f_grad) {
     if (!h) return SMAC_ERR_INVALID;
     for (int i = count - 1; i >= 0; --i) {
+        h->impl->hint_backward_next(i > 0 ? f0 + i - 1 : -1);       // lets substep f0 + i take the G2P adjoint of the substep before it along (k_p2g_g2p_grad)
         int rc = h->impl->substep_grad(f0 + i, nullptr, i == count - 1 ? ext_f_grad : nullptr, nullptr);
+        h->impl->hint_backward_next(-1);
         if (rc) return rc;
     }
     return SMAC_OK;

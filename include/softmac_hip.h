@@ -120,7 +120,9 @@ int smac_compute_grid_m(smac_handle h, int f, double* grid_m);                /*
 int smac_substep(smac_handle h, int f, const double* action);
 int smac_substep_grad(smac_handle h, int f, const double* action, const double* ext_f_grad, double* action_grad_out);
 /* Batched forms: frames f0 .. f0+count-1 forward; f0+count-1 down to f0 backward.  One call, no
- * host round trip between substeps (replaces the python loops at taichi_env.py:101-102,128-131). */
+ * host round trip between substeps (replaces the python loops at taichi_env.py:101-102,128-131).
+ * The backward form knows which substep follows: it reverses the P2G of substep f and the G2P of substep f-1 in one
+ * launch where the two share a binning (results as from count calls of smac_substep_grad). */
 int smac_substeps(smac_handle h, int f0, int count);
 int smac_substeps_grad(smac_handle h, int f0, int count, const double* ext_f_grad);
 

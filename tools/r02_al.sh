@@ -9,3 +9,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-f64 --no-cloth --repeats 1 > $O/fetch.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-f64 --no-cloth --repeats 1 > $O/write.log 2>&1
 find $O -name "*_kernel_stats.csv" | head -2; find $O -name "*counter_collection.csv" | head -4
+timeout -k 10 900 python -m pytest tests -m gpu -q --durations=8 > $O/pytest.log 2>&1; tail -14 $O/pytest.log | cut -c1-300

@@ -40,21 +40,21 @@ def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=6
     else:
         for f in range(n_sub - 1, -1, -1):
             sim.substep_grad(f)
-    frames = {f: np.hstack([a.reshape(N, -1) for a in sim.get_grad_full(f)]) for f in range(n_sub)}
+    frames = {f: np.hstack([a.reshape(N, -1) for a in sim.get_grad_full(f)]) for f in range(0, n_sub, 1 if n_sub <= 12 else 10)}
     prim = np.array([m.get_all_states_grad(f) for m in prm for f in range(n_sub)])
     counts = sim.profile_report()
     sim.profile(False)
     return frames, prim, counts
 
 
-@pytest.mark.parametrize("seeds,sort_interval", [((12,), 1000), ((12, 7, 6), 1000), ((12,), 5)])
-def test_fused_backward_step_equals_the_two_kernels(seeds, sort_interval):
-    n_sub = 12
+@pytest.mark.parametrize("n_sub,seeds,sort_interval", [(12, (12,), 1000), (12, (12, 7, 6), 1000), (12, (12,), 5), (120, (120, 80, 40), 16)])
+def test_fused_backward_step_equals_the_two_kernels(n_sub, seeds, sort_interval):
+    # (the last case: an episode of three env steps with a loss seed at the end of each, 8 re-sorts on the way)
     a, pa, ca = _rollout(True, n_sub, seeds, sort_interval)
     b, pb, cb = _rollout(False, n_sub, seeds, sort_interval)
     c, pc, cc = _rollout(True, n_sub, seeds, sort_interval, batched=False)       # no hint: never fused
     worst = noise = 0.0
-    for f in range(n_sub):
+    for f in sorted(b):
         scale = np.abs(b[f]).max()
         assert scale > 0
         worst = max(worst, np.abs(a[f] - b[f]).max() / scale)
@@ -63,8 +63,8 @@ def test_fused_backward_step_equals_the_two_kernels(seeds, sort_interval):
           f"apart vs apart (two handles, the un-hinted sweep never fuses) {noise:.1e}")
     # Two rollouts of the SAME path already differ in the last bits (float atomics of drifted lanes arrive in any order, and 12 backward substeps
     # carry that on); the fused step must stay inside that noise, not just inside a parity tolerance
-    assert noise < 2e-5 and worst < max(10 * noise, 5e-6)
-    assert np.abs(pb).max() > 0 and H.rel_err(pa, pb) < 2e-6                    # the primitives' state adjoints (contact runs between the two halves)
+    assert noise < (2e-5 if n_sub <= 12 else 2e-4) and worst < max(10 * noise, 5e-6)
+    assert np.abs(pb).max() > 0 and H.rel_err(pa, pb) < max(10 * H.rel_err(pc, pb), 2e-6)   # the primitives' state adjoints (contact runs between the two halves)
 
 
 def test_fused_backward_step_is_actually_taken():

@@ -552,6 +552,11 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     __shared__ double tile_raw[4 * TILE_WORDS];
     __shared__ R smax[4];
     __shared__ R ps_wg[MAX_PRIMS * 13];
+#ifdef SMAC_P2G_LDS_PAD          // experiment: fewer workgroups per CU at unchanged registers (profiles/r02_ao_p2g_occupancy.txt)
+    __shared__ int lds_pad[SMAC_P2G_LDS_PAD / 4];
+    if (D.n < 0) lds_pad[threadIdx.x] = 1;
+    if (D.n < -1) D.pmask[0] = lds_pad[(threadIdx.x * 7) % (SMAC_P2G_LDS_PAD / 4)];
+#endif
     if (D.any_contact) {                 // (uniform) primitive states of this frame, converted once per workgroup for the band test
         if (threadIdx.x < D.P * 13)
             ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];

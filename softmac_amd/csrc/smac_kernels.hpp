@@ -2036,7 +2036,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
 // The host restores the forward grid of substep f - 1 BEFORE this launch (k_grid_restore leaves grid_v_in.grad alone), so `grid_v_out` is the
 // earlier substep's while `grid_v_in.grad` is still this one's.  D.Af_prev: adjoint frame f - 1.  ACC_X: frame f - 1 carries a seed.
 template <class R, bool ACC_X>
-__global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_g2p_grad(DevSim<R> D, int f) {
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? occ<R>::heavy : 1)) void k_p2g_g2p_grad(DevSim<R> D, int f) {      // (f64: never launched, see can_fuse_prev)
     typedef typename const_t<R>::type CT;
     typedef typename ScatterTile<R>::word W;
     __shared__ CT stash[STASH * BLOCK];

@@ -125,6 +125,74 @@ def cpu_baseline(args):
                       f"f64 C++/OpenMP restatement of the reference's kernel decomposition (not Taichi), {dt:.1f} s on {port.threads()} threads"}
 
 
+def env_loop_record(args, seed_gx):
+    """The reference's OWN loop shape (taichi_env.py:93-151) on the same workload: TaichiEnv.step(action) per env step (its substeps, then the
+    velocity-controlled rigid step: clear_ext_f + set_action per primitive, rigid_simulator_vel.py:20-32), a loss seed on the last frame, then
+    env.backward() (step_grad per env step in reverse: get_action_grad per primitive + the substeps' adjoints).  Host orchestration included."""
+    from softmac_amd import scenes
+    from softmac_amd.config import CfgNode, get_cfg_defaults
+    from softmac_amd.engine.primitive import Mesh, Primitives
+    from softmac_amd.engine.taichi_env import TaichiEnv
+    import torch
+    scfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, args.precision, 0, seed=1)
+    n_env = max(1, args.steps // 10)
+    w_env = max(1, (args.warmup + 9) // 10)
+    cfg = get_cfg_defaults()
+    cfg.control_mode = "rigid"
+    cfg.rigid_velocity_control = True
+    cfg.env_dt = env_dt
+    S = cfg.SIMULATOR
+    for k in ("dt", "E", "nu", "ptype", "material_model", "gravity", "ground_friction", "collision_type", "yield_stress", "precision"):
+        setattr(S, k, getattr(scfg, k))
+    S.n_grid = args.grid
+    S.max_steps = (n_env + w_env) * 10 + 2
+    S.sort_interval = args.sort_interval
+    cfg.SHAPES = [{"shape": "predefined", "state": state}]
+    n = len(specs)
+    pose = np.zeros((n, 6)); vel = np.zeros((n, 6))
+    for i, st in enumerate(s13):
+        pose[i, 3:] = st[:3]                     # identity rotation (exp map 0), position
+        vel[i, :3], vel[i, 3:] = st[10:13], st[7:10]
+    cfg.RIGID.init_state = tuple(np.concatenate([pose.reshape(-1), vel.reshape(-1)]))
+    meshes = []
+    for sp in specs:
+        pc = CfgNode(); pc.friction = sp["friction"]; pc.enable_external_force = True; pc.urdf_path = ""
+        meshes.append(Mesh(sdf=sp, cfg=pc, max_timesteps=S.max_steps, rigid_velocity_control=True))
+    env = TaichiEnv(cfg, primitives=Primitives(primitives=meshes))
+    for m, sp in zip(meshes, specs):
+        m.friction[None] = sp["friction"]
+    env.simulator.primitives_contact = [bool(sp["contact"]) for sp in specs]
+    action = torch.tensor(vel.reshape(-1))       # constant closing speed: (w, v) per primitive
+    sim = env.simulator
+
+    def episode(k_env):
+        """returns (action gradient, seconds spent in the env steps + in backward()); reset and the loss seed's upload are not in it
+        (96 + 25 MB of host arrays at this size: the reference pays them once per epoch of 400 env steps, demo_grip.py:135-165)"""
+        env.reset()
+        sim.clear_grads()
+        sim.sync()
+        t0 = time.perf_counter()
+        for _ in range(k_env):
+            env.step(action)
+        sim.sync()
+        t1 = time.perf_counter()
+        sim.add_grad(sim.cur, gx=seed_gx)
+        sim.sync()
+        t2 = time.perf_counter()
+        g = env.backward()
+        sim.sync()
+        return g, (t1 - t0) + (time.perf_counter() - t2)
+
+    episode(w_env)
+    g, wall = episode(n_env)
+    sim._h.close()
+    return {"value": n_env * 10 / wall, "unit": "substeps/s", "ms_per_step": 1e3 * wall / (n_env * 10), "env_steps": n_env, "substeps_per_env_step": 10,
+            "action_grad_norm": float(np.linalg.norm(g.numpy())),
+            "note": "TaichiEnv.step x env_steps, then TaichiEnv.backward(), with velocity-controlled primitives (the reference's loop shape, "
+                    "taichi_env.py:93-151): host orchestration per env step included, reset and the loss seed's upload not; same particles / grid / "
+                    "primitives as `value`"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); spawned here when not already under torchrun")
@@ -140,6 +208,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the float64 sub-record (the mode that equals the reference's dtype)")
     ap.add_argument("--no-cloth", action="store_true", help="skip the soft <-> cloth sub-record (tools/bench_cloth.py in a child process)")
+    ap.add_argument("--no-env-loop", action="store_true", help="skip the env_loop sub-record (the reference's TaichiEnv.step / backward loop on the same workload)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
     ap.add_argument("--sort-interval", type=int, default=0, help="0: min(32, steps), so that every timed window holds a re-sort")
@@ -281,6 +350,20 @@ def main():
     backward(W, K)
     prof = sim.profile_report()
     sim.profile(False)
+    # SURVEY 8(d) asks for the two directions separately as well: one more pass with a sync between them
+    split = None
+    if world == 1:
+        sim.clear_grads()
+        sim.add_grad(W + K, gx=seed_gx)
+        barrier()
+        t0 = time.perf_counter()
+        forward(W, K)
+        barrier()
+        t1 = time.perf_counter()
+        backward(W, K)
+        barrier()
+        t2 = time.perf_counter()
+        split = (t1 - t0, t2 - t1)
     G_t = sim.count_active_cells(W)
     n_hits, n_hit_chunks = sim.contact_counts()
     counts = [N_local, G_t, n_hits]
@@ -346,6 +429,12 @@ def main():
             "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in kern.items()},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
         }
+        if split is not None:
+            for name, t, key in (("fwd_only", split[0], "fwd"), ("bwd_only", split[1], "bwd")):
+                gbs = ab[key] * K / t / 1e9
+                out[name] = {"value": K / t, "unit": "substeps/s", "ms_per_step": 1e3 * t / K, "algorithmic_bytes": ab[key],
+                             "achieved": gbs, "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS,
+                             "note": f"{K} {'forward' if key == 'fwd' else 'backward'} substeps of the same window, one sync before and after"}
     if world == 1 and args.precision == "float32" and not args.no_f64:
         # the mode that computes in the reference's own dtype (mpm_simulator.py:19) and meets 1e-9: one window, same workload
         del run
@@ -357,6 +446,13 @@ def main():
         w64, d64, _, _ = timed_windows(a64, sim, run, None, seed_gx, lambda: sim.sync(), None)
         out["f64"] = {"value": K / w64[0], "unit": "substeps/s", "ms_per_step": 1e3 * w64[0] / K, "device_ms_per_step": d64[0] / K,
                       "dtype": "f64", "note": "same workload, arithmetic and storage in float64 (parity 1e-9 state / 1e-8 gradients)"}
+    if world == 1 and not args.no_env_loop and args.workload == "s-grip":
+        try:
+            sim._h.close()
+            out["env_loop"] = env_loop_record(args, seed_gx)
+            out["env_loop"]["vs_value"] = out["env_loop"]["value"] / out["value"]
+        except Exception as e:                                                     # noqa: BLE001
+            out["env_loop"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world == 1 and args.precision == "float32" and not args.no_cloth and args.workload == "s-grip":
         # the soft <-> cloth path at the same size, in a child process: whatever happens there cannot touch the metric line
         try:

@@ -125,6 +125,11 @@ int smac_substep_grad(smac_handle h, int f, const double* action, const double* 
  * launch where the two share a binning (results as from count calls of smac_substep_grad). */
 int smac_substeps(smac_handle h, int f0, int count);
 int smac_substeps_grad(smac_handle h, int f0, int count, const double* ext_f_grad);
+/* The same with a particle action held over the window (control_mode "mpm", taichi_env.py:101-102 / :128-133): set_action once, then the
+ * substeps.  The backward form returns in action_grad_sum (n_control,3) the SUM over the window of what substep_grad returns per substep
+ * (:378; TaichiEnv.step_grad adds them up, taichi_env.py:130-133): accumulated on the device, one read-back per env step.  NULLs allowed. */
+int smac_substeps_action(smac_handle h, int f0, int count, const double* action);
+int smac_substeps_grad_action(smac_handle h, int f0, int count, const double* action, const double* ext_f_grad, double* action_grad_sum);
 
 /* ---- rigid primitives (primitive_base.py, mesh.py) */
 int smac_prim_upload_sdf(smac_handle h, int prim, const double* sdf, const double* normal, const int32_t res[3],

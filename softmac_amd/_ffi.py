@@ -62,6 +62,8 @@ SIGNATURES = {
     "smac_substep_grad": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_double_p]),
     "smac_substeps": (C.c_int, [H, C.c_int, C.c_int]),
     "smac_substeps_grad": (C.c_int, [H, C.c_int, C.c_int, c_double_p]),
+    "smac_substeps_action": (C.c_int, [H, C.c_int, C.c_int, c_double_p]),
+    "smac_substeps_grad_action": (C.c_int, [H, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     "smac_prim_upload_sdf": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p, C.c_double]),
     "smac_prim_set_params": (C.c_int, [H, C.c_int, C.c_double, C.c_double, C.c_int]),
     "smac_prim_set_state": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_double_p]),

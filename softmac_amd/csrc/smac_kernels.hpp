@@ -49,7 +49,7 @@ namespace smac {
 #ifndef SMAC_OCC_G2P_PIPE
 #define SMAC_OCC_G2P_PIPE 3
 #endif
-// register-pressure knobs of the two gradient kernels (A/B on MI355X: tools/r02_h.sh)
+// register-pressure knobs of the two gradient kernels (A/B on MI355X: profiles/scripts/r02_h.sh)
 #ifndef SMAC_DW_RECOMPUTE
 #define SMAC_DW_RECOMPUTE 1      // WGrad::to_fx recomputes dw from fx instead of keeping Stencil::dw live across the gather
 #endif
@@ -505,8 +505,8 @@ template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
     if (hit_ck) {
         int nh = *D.nhits;
-        if (nh > hit_cap) {                  // more particles in contact bands than a checkpoint slot holds: reported, never truncated silently
-            if (blockIdx.x == 0 && threadIdx.x == 0) *D.drift_flag = 2;
+        if (nh > hit_cap) {                  // more particles in contact bands than a checkpoint slot holds: never truncated silently - the host is
+            if (blockIdx.x == 0 && threadIdx.x == 0) D.drift_flag[1] = 1;      // told (second flag word) and substep_grad repeats the band test instead
             nh = 0;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) *nhit_ck = nh;
@@ -817,8 +817,8 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     if (!active_cell(D, b, l, cell, i, j, k)) return;
     if (D.hit_ck && phase != 1) {            // the frame's contact hit list (complete since k_p2g) goes on file with the checkpoint
         int nh = *D.nhits;
-        if (nh > D.hit_cap) {                // more particles in contact bands than a slot holds: reported, never truncated silently
-            if (blockIdx.x == 0 && threadIdx.x == 0) *D.drift_flag = 2;
+        if (nh > D.hit_cap) {                // more particles in contact bands than a slot holds: never truncated silently (see k_grid_save)
+            if (blockIdx.x == 0 && threadIdx.x == 0) D.drift_flag[1] = 1;
             nh = 0;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) *D.nhit_ck = nh;

@@ -2,6 +2,7 @@
 // Host side only: handle, device memory, launch sequencing, f64 <-> device-layout conversion.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,9 +44,19 @@ static const char* kDriftMessage =
     "interval): the frames after that substep are invalid - lower sort_interval or dt";
 static const char* kHitOverflowMessage =
     "more than 1/8 of the particles were inside a contact band in one substep: its hit list does not fit the grid "
-    "checkpoint (create the handle with flags bit 0 - recompute_backward - for such scenes)";
+    "checkpoint, which the direct-checkpoint modes (SMAC_CK_MODE=1/2) walk in place (use the default mode, or flags bit 0 - recompute_backward)";
 static const char* kKernelNames[K_COUNT] = {"clear_grid", "grid_checkpoint", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
                                             "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint", "p2g_g2p_grad"};
+
+// a few scalars handed to the device inside the kernel's argument block
+template <class T, int N> struct SmallArgs { T v[N]; };
+template <class T, int N>
+__global__ void k_set_small(SmallArgs<T, N> a, int n, T* dst, T* zero_too) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        dst[i] = a.v[i];
+        if (zero_too) zero_too[i] = T(0);
+    }
+}
 
 struct ISim {
     std::string err;
@@ -62,6 +73,7 @@ struct ISim {
     virtual int clear_grads() = 0;
     virtual int set_control_idx(const int32_t* idx) = 0;
     virtual int set_action_v(const double* action) = 0;
+    virtual int get_action_grad(double* out) = 0;
     virtual int set_segment(int n_live, int frame_shift) = 0;
     virtual int compute_grid_m(int f, double* out) = 0;
     virtual int substep(int f, const double* action) = 0;
@@ -187,7 +199,7 @@ template <class R> struct Sim final : ISim {
     bool adj_grid_clean = true;      // grid_v_out.grad / grid_v_mixed.grad of every active block are zero (direct-checkpoint backward)
     // grid checkpoint traffic.  0 (default): copy kernels both ways (k_grid_save / k_grid_restore, 10 us each at 1M particles).
     // 1: k_grid_op / k_contact_hits write the checkpoint and the backward kernels read it in place (gval / gather_tile_load_fwd);
-    // 2: written in place by the forward pass, restored by k_grid_restore.  Measured (tools/r02_h.sh, r02_i.sh: 3 interleaved runs,
+    // 2: written in place by the forward pass, restored by k_grid_restore.  Measured (profiles/scripts/r02_h.sh, r02_i.sh: 3 interleaved runs,
     // per-kernel minima): mode 1 costs k_g2p_grad a dependent slot lookup per tile record (+13 us) and the contact kernels +3 us
     // each - 369 vs 364 us per substep pair; mode 2 equals mode 0 (363 vs 364).  Kept selectable, not a win.
     int ck_mode = getenv("SMAC_CK_MODE") ? atoi(getenv("SMAC_CK_MODE")) : 0;
@@ -337,8 +349,8 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&d_active_flag, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_active_start, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&tmp_frame, fs));
-        HIP_TRY(hipMalloc((void**)&d_drift, sizeof(int)));
-        HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
+        HIP_TRY(hipMalloc((void**)&d_drift, 2 * sizeof(int)));                  // [0]: a particle out-ran its binning; [1]: a contact hit list did not fit its checkpoint slot
+        HIP_TRY(hipMemsetAsync(d_drift, 0, 2 * sizeof(int), stream));
         D.drift_flag = d_drift;
         epochs.clear();
         epochs.emplace_back();
@@ -876,9 +888,12 @@ template <class R> struct Sim final : ISim {
     // already overwritten by later env steps) and a backward pass that has already consumed the bad frames.
     int fwd_head = -1;                 // frame the forward pass has reached (f + 1 of the last substep)
     bool repairing = false, bwd_since_fwd = false, slab_phase_used = false;
-    double* ext_snap = nullptr;        // ext_f (and the cloth's) at the start of the current epoch: the replay re-accumulates from there
-    double* cloth_ext_snap = nullptr;
-    int snapshot_ext() {
+    double* ext_snap = nullptr;        // ext_f at frame `snap_frame`: the start of the current epoch, or the last point at which the host
+    double* cloth_ext_snap = nullptr;  // cleared a wrench accumulator inside it (env-step boundary) - the replay re-accumulates from THERE
+    int snap_frame = -1;
+    int replay_count_from = -1;        // repair_drift: substeps before this frame replay with their wrench sums diverted to the scratch slot
+    int snapshot_ext(int at_frame) {
+        snap_frame = at_frame;
         const int Pn = D.P > 0 ? D.P : 1;
         if (!ext_snap) HIP_TRY(hipMalloc((void**)&ext_snap, Pn * 6 * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(ext_snap, D.ext_f, Pn * 6 * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -889,19 +904,24 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     int repair_drift(int f_end, int e_bad) {
-        if (repairing || bwd_since_fwd || slab_phase_used || D.n_control > 0 || e_bad <= 0 || !epochs[e_bad].live || !ext_snap) return SMAC_ERR_INVALID;
+        // (the cloth variant is not replayed: its contact-face search and penetration tracing run on the host's schedule between the substeps)
+        if (repairing || bwd_since_fwd || slab_phase_used || D.n_control > 0 || D.cloth.present || e_bad <= 0 || !epochs[e_bad].live || !ext_snap)
+            return SMAC_ERR_INVALID;
         const int fs = epochs[e_bad].frame;
         if (!(fs < f_end) || frame_epoch[fs] != e_bad) return SMAC_ERR_INVALID;
         repairing = true;
         const int Pn = D.P > 0 ? D.P : 1;
         int rc = SMAC_OK;
+        // The wrench accumulators go back to their value at `snap_frame` - the epoch's first frame, or the last env-step boundary inside it at which
+        // the host read and cleared ext_f (rigid_simulator.py:92-93, 117): what the host has consumed must not be accumulated again.  Substeps
+        // replayed BEFORE that frame send their wrench sums to the scratch slot (as the backward recompute does); from that frame on they count.
+        replay_count_from = snap_frame < fs ? fs : snap_frame;
         if (hipMemcpyAsync(D.ext_f, ext_snap, Pn * 6 * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) rc = SMAC_ERR_HIP;
-        if (!rc && D.cloth.present && cloth_ext_snap &&
-            hipMemcpyAsync(D.cloth.ext_f, cloth_ext_snap, (size_t)D.cloth.V * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) rc = SMAC_ERR_HIP;
         const int keep = sort_interval;
         sort_interval = 1;
         epochs[e_bad].interval = 1;                          // frame fs keeps its (fresh) binning; every later frame is re-binned before it is used
         for (int g = fs; g < f_end && !rc; ++g) rc = substep_phase(g, nullptr, -1);
+        replay_count_from = -1;
         sort_interval = keep;
         repairing = false;
         ++drift_repairs;
@@ -945,12 +965,13 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemcpyAsync(&totals[0], d_chunk_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&totals[1], d_active_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&vbits, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        int drifted = 0;
-        if (read_drift) HIP_TRY(hipMemcpyAsync(&drifted, d_drift, sizeof(int), hipMemcpyDeviceToHost, stream));
+        int flags2[2] = {0, 0};
+        if (read_drift) HIP_TRY(hipMemcpyAsync(flags2, d_drift, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         // a drift error of the epoch that ends here is reported AFTER the new epoch is committed: S[f] is already in the
         // new order, so frame_epoch[f] must name it or every later get_state / set_frame of this frame would be scrambled
-        if (drifted) HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
+        const int drifted = flags2[0];
+        if (flags2[0] || flags2[1]) HIP_TRY(hipMemsetAsync(d_drift, 0, 2 * sizeof(int), stream));
         {
             // A particle may move 4 cells (its block's halo) before the binning breaks; budget 2 cells for the fastest
             // particle at its current speed, which leaves a factor two for acceleration inside the interval.
@@ -987,16 +1008,14 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMalloc((void**)&slab, slab_chunks * TILE_WORDS * sizeof(Vec4<R>)));
             HIP_TRY(hipMalloc((void**)&d_cand, slab_chunks * sizeof(int)));
         }
-        if (drifted == 2) {
-            err = kHitOverflowMessage;
-            return SMAC_ERR_INVALID;
-        }
+        if (flags2[1] && (rc = hit_overflow())) return rc;
         if (drifted) {
             if (allow_repair && repair_drift(f, e_old) == SMAC_OK) return sort_frame(f, true, false);   // frame f is recomputed: bin it again
             err = kDriftMessage;
             return SMAC_ERR_INVALID;
         }
-        if ((rc = snapshot_ext())) return rc;
+        // (inside a replay, frames before `replay_count_from` do not own the accumulator's value: the snapshot stays where it is)
+        if (!(repairing && f < replay_count_from) && (rc = snapshot_ext(f))) return rc;
         return check_launch();
     }
     // make epoch e the one the kernels see; the grid blocks the previous epoch may have dirtied are zeroed
@@ -1052,20 +1071,36 @@ template <class R> struct Sim final : ISim {
         *out = dst;
         return check_launch();
     }
+    // A substep had more particles inside contact bands than a checkpoint slot holds (max(8192, N/8)): its list was not filed.  The host does
+    // not know which frame it was, so every frame on file loses its list and substep_grad repeats the band test for them (k_contact_mask, as it
+    // does when the lists do not fit in memory at all) - slower, never wrong.  The direct-checkpoint modes walk the filed list in place: error.
+    int hit_overflows = 0;
+    int hit_overflow() {
+        REQUIRE(ck_mode == 0, kHitOverflowMessage);
+        std::fill(ck_has_hits.begin(), ck_has_hits.end(), (char)0);
+        ++hit_overflows;
+        return SMAC_OK;
+    }
     int check_drift() {
-        int h = 0;
-        HIP_TRY(hipMemcpyAsync(&h, d_drift, sizeof(int), hipMemcpyDeviceToHost, stream));
+        int h[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(h, d_drift, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (h) {
-            HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
-            if (h == 1 && fwd_head > 0 && frame_epoch[fwd_head] > 0 && repair_drift(fwd_head, frame_epoch[fwd_head]) == SMAC_OK) {
-                int h2 = 0;                                   // the replay (re-binning before every substep) must itself come out clean
-                HIP_TRY(hipMemcpyAsync(&h2, d_drift, sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (h[0] || h[1]) HIP_TRY(hipMemsetAsync(d_drift, 0, 2 * sizeof(int), stream));
+        int rc;
+        if (h[1] && (rc = hit_overflow())) return rc;
+        if (h[0]) {
+            if (fwd_head > 0 && frame_epoch[fwd_head] > 0 && repair_drift(fwd_head, frame_epoch[fwd_head]) == SMAC_OK) {
+                int h2[2] = {0, 0};                           // the replay (re-binning before every substep) must itself come out clean
+                HIP_TRY(hipMemcpyAsync(h2, d_drift, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
-                if (!h2) return SMAC_OK;
+                if (h2[1]) {
+                    HIP_TRY(hipMemsetAsync(d_drift + 1, 0, sizeof(int), stream));
+                    if ((rc = hit_overflow())) return rc;
+                }
+                if (!h2[0]) return SMAC_OK;
                 HIP_TRY(hipMemsetAsync(d_drift, 0, sizeof(int), stream));
             }
-            err = h == 2 ? kHitOverflowMessage : kDriftMessage;
+            err = kDriftMessage;
             return SMAC_ERR_INVALID;
         }
         return SMAC_OK;
@@ -1105,10 +1140,11 @@ template <class R> struct Sim final : ISim {
     int get_param(const char* name, double* value) override {
         REQUIRE(name && value, "get_param: null argument");
         if (!strcmp(name, "drift_repairs")) *value = (double)drift_repairs;             // epochs recomputed because a particle out-ran its binning
+        else if (!strcmp(name, "hit_overflows")) *value = (double)hit_overflows;      // times a contact hit list did not fit its checkpoint slot (backward then repeats the band test)
         else if (!strcmp(name, "plasticity")) *value = (double)D.mat.plast;
         else if (!strcmp(name, "yield_ratio")) *value = (double)D.mat.yield_c;
         else if (!strcmp(name, "mass_eps")) *value = (double)D.m_eps;
-        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | plasticity | yield_ratio | mass_eps)");
+        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | plasticity | yield_ratio | mass_eps)");
         return SMAC_OK;
     }
     int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,
@@ -1277,12 +1313,26 @@ template <class R> struct Sim final : ISim {
     }
     int set_action(const double* action) {                                    // :579-592
         REQUIRE(D.n_control > 0, "action given but n_control == 0");
-        R tmp[3 * 64];
         REQUIRE(D.n_control <= 64, "n_control > 64");
-        for (int i = 0; i < 3 * D.n_control; ++i) tmp[i] = (R)action[i];
-        HIP_TRY(hipMemcpyAsync(D.action, tmp, 3 * D.n_control * sizeof(R), hipMemcpyHostToDevice, stream));
+        // the values travel in the kernel's argument block (copied at launch): no staging buffer whose lifetime a stream sync would have to guard
+        SmallArgs<R, 3 * 64> a;
+        for (int i = 0; i < 3 * D.n_control; ++i) a.v[i] = (R)action[i];
+        hipLaunchKernelGGL((k_set_small<R, 3 * 64>), dim3(1), dim3(256), 0, stream, a, 3 * D.n_control, D.action, D.action_grad);   // action.grad zeroed (:584-586)
+        return check_launch();
+    }
+    int stage_ext_f_grad(const double* ext_f_grad) {                          // :342-344 set_ext_f_grad of every primitive, without a host sync
+        if (!ext_f_grad || D.P <= 0) return SMAC_OK;
+        SmallArgs<double, SMAC_MAX_PRIMS * 6> a;
+        for (int i = 0; i < 6 * D.P; ++i) a.v[i] = ext_f_grad[i];
+        hipLaunchKernelGGL((k_set_small<double, SMAC_MAX_PRIMS * 6>), dim3(1), dim3(256), 0, stream, a, 6 * D.P, D.ext_f_grad, (double*)nullptr);
+        return check_launch();
+    }
+    int get_action_grad(double* out) override {                               // action.grad.to_numpy() :378
+        REQUIRE(out && D.n_control > 0, "get_action_grad: null argument or n_control == 0");
+        R tmp[3 * 64];
+        HIP_TRY(hipMemcpyAsync(tmp, D.action_grad, 3 * D.n_control * sizeof(R), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemsetAsync(D.action_grad, 0, 3 * D.n_control * sizeof(R), stream));
+        for (int i = 0; i < 3 * D.n_control; ++i) out[i] = (double)tmp[i];
         return SMAC_OK;
     }
     int check_contact_supported() {
@@ -1312,7 +1362,7 @@ template <class R> struct Sim final : ISim {
         D.any_contact = any_contact() ? 1 : 0;
         D.cur_frame = f;
         DevSim<R> Dc = D;                                       // the recompute pass must not double-count ext_f
-        if (is_recompute) Dc.ext_f = scratch_ext();
+        if (is_recompute || (repairing && f < replay_count_from)) Dc.ext_f = scratch_ext();
         if (is_recompute && D.cloth.present) Dc.cloth.ext_f = d_cloth_ext_scratch;
         if (stage != 2) {
             // grid_op rewrites v_mixed / v_out of every active cell; {m,p} must start from zero (drifted particles add to
@@ -1500,10 +1550,7 @@ template <class R> struct Sim final : ISim {
         }
         if (phase < 0 && g2p_done_frame == f) {           // restore + g2p.grad of this substep ran inside the previous call (k_p2g_g2p_grad)
             g2p_done_frame = -1;
-            if (ext_f_grad && D.P > 0) {
-                HIP_TRY(hipMemcpyAsync(D.ext_f_grad, ext_f_grad, 6 * D.P * sizeof(double), hipMemcpyHostToDevice, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-            }
+            if ((rc = stage_ext_f_grad(ext_f_grad))) return rc;
             D.Af = adj_ptr(f);
             D.An = adj_ptr(f + 1);                          // same epoch (can_fuse_prev): in this order already
             pending_adj_zero = g2p_done_paz;
@@ -1514,10 +1561,7 @@ template <class R> struct Sim final : ISim {
         } else if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
-            if (ext_f_grad && D.P > 0) {                                          // :342-344
-                HIP_TRY(hipMemcpyAsync(D.ext_f_grad, ext_f_grad, 6 * D.P * sizeof(double), hipMemcpyHostToDevice, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-            }
+            if ((rc = stage_ext_f_grad(ext_f_grad))) return rc;                   // :342-344
             if ((rc = bind_epoch(e))) return rc;
             // adjoint of frame f+1 in this epoch's particle order; adjoint of frame f must be in it too
             const R* An = nullptr;
@@ -1824,7 +1868,7 @@ template <class R> struct Sim final : ISim {
     }
     int prim_get_ext_f(int prim, double* e6) override {
         int rc = check_prim(prim);
-        if (rc) return rc;
+        if (rc || (rc = check_drift())) return rc;             // a drifted epoch is repaired BEFORE the host consumes its wrench
         HIP_TRY(hipMemcpyAsync(e6, D.ext_f + prim * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return SMAC_OK;
@@ -1832,8 +1876,11 @@ template <class R> struct Sim final : ISim {
     int prim_clear_ext_f(int prim) override {                                 // :183-187 (value and grad)
         int rc = check_prim(prim);
         if (rc) return rc;
+        if (fwd_head >= 0 && !bwd_since_fwd && (rc = check_drift())) return rc;   // (repairs with the accumulator as the forward pass left it)
         HIP_TRY(hipMemsetAsync(D.ext_f + prim * 6, 0, 6 * sizeof(double), stream));
         HIP_TRY(hipMemsetAsync(D.ext_f_grad + prim * 6, 0, 6 * sizeof(double), stream));
+        // a later repair of this epoch re-accumulates from here, not from the epoch's first frame (no double counting)
+        if (ext_snap && fwd_head >= 0 && !repairing) return snapshot_ext(fwd_head);
         return SMAC_OK;
     }
     // velocity control (primitive_base.py:285-319): action_buffer[s] = a6 ; v[j] = a[3:6], w[j] = a[0:3] for j in [s n, (s+1) n)
@@ -2039,6 +2086,19 @@ int smac_substeps_grad(smac_handle h, int f0, int count, const double* ext_f_gra
         h->impl->hint_backward_next(-1);
         if (rc) return rc;
     }
+    return SMAC_OK;
+}
+int smac_substeps_action(smac_handle h, int f0, int count, const double* action) {
+    if (!h) return SMAC_ERR_INVALID;
+    if (action) { int rc = h->impl->set_action_v(action); if (rc) return rc; }
+    return smac_substeps(h, f0, count);
+}
+int smac_substeps_grad_action(smac_handle h, int f0, int count, const double* action, const double* ext_f_grad, double* action_grad_sum) {
+    if (!h) return SMAC_ERR_INVALID;
+    int rc;
+    if (action && (rc = h->impl->set_action_v(action))) return rc;      // zeroes action.grad; the sweep then accumulates the window's sum on the device
+    if ((rc = smac_substeps_grad(h, f0, count, ext_f_grad))) return rc;
+    if (action_grad_sum) return h->impl->get_action_grad(action_grad_sum);
     return SMAC_OK;
 }
 int smac_prim_upload_sdf(smac_handle h, int prim, const double* sdf, const double* normal, const int32_t res[3],

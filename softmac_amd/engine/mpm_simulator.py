@@ -175,17 +175,30 @@ class MPMSimulator:
             return None
         return out.reshape(np.asarray(action).shape)
 
-    def run_substeps(self, s0, count):
-        """Batched forward: frames s0 .. s0+count-1 in one FFI call."""
+    def run_substeps(self, s0, count, action=None):
+        """Batched forward: frames s0 .. s0+count-1 in one FFI call (the loop of taichi_env.py:101-102); `action`: the particle
+        action held over the window (control_mode "mpm")."""
         self._push_contact_flags()
-        self._h.call("smac_substeps", int(s0), int(count))
+        if action is None:
+            self._h.call("smac_substeps", int(s0), int(count))
+            return
+        a = _ffi.as_f64(np.asarray(action, dtype=np.float64).reshape(self.n_control, self.dim))
+        self._h.call("smac_substeps_action", int(s0), int(count), _ffi.dptr(a))
 
-    def run_substeps_grad(self, s0, count, ext_f_grad=None):
+    def run_substeps_grad(self, s0, count, ext_f_grad=None, action=None):
+        """Batched backward: substeps s0+count-1 .. s0 in one FFI call (the loop of taichi_env.py:128-133).  With `action` it returns the
+        sum over the window of the per-substep action gradients (what TaichiEnv.step_grad accumulates), read back once."""
         self._push_contact_flags()
         e = None
         if ext_f_grad is not None:
             e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]), (self.n_primitive, 6))
-        self._h.call("smac_substeps_grad", int(s0), int(count), _ffi.dptr(e))
+        if action is None:
+            self._h.call("smac_substeps_grad", int(s0), int(count), _ffi.dptr(e))
+            return None
+        a = _ffi.as_f64(np.asarray(action, dtype=np.float64).reshape(self.n_control, self.dim))
+        out = np.zeros((self.n_control, self.dim))
+        self._h.call("smac_substeps_grad_action", int(s0), int(count), _ffi.dptr(a), _ffi.dptr(e), _ffi.dptr(out))
+        return out.reshape(np.asarray(action).shape)
 
     # ------------------------------------------------------------------ IO (:448-574)
     def get_state(self, f):

@@ -83,11 +83,7 @@ class TaichiEnv:
         mpm_action = action if self.control_mode == "mpm" else None
         rigid_action = action if self.control_mode == "rigid" else None
         self.action_list.append(action)
-        if mpm_action is None:
-            self.simulator.run_substeps(start, self.substeps)    # one FFI call for the env step's substeps
-        else:
-            for s in range(start, self.simulator.cur):
-                self.simulator.substep(s, mpm_action)
+        self.simulator.run_substeps(start, self.substeps, mpm_action)    # one FFI call for the env step's substeps (:101-102)
         self.rigid_simulator.step(start // self.substeps, rigid_action)
         if self._is_copy:
             self.simulator.copyframe(self.simulator.cur, 0)
@@ -99,13 +95,12 @@ class TaichiEnv:
         mpm_action = action if self.control_mode == "mpm" else None
         rigid_action = action if self.control_mode == "rigid" else None
         rigid_action_grad, ext_f_grad_list = self.rigid_simulator.step_grad(self.simulator.cur // self.substeps, rigid_action)
-        mpm_action_grad = np.zeros(np.asarray(action).shape)
-        for s in range(start - 1, self.simulator.cur - 1, -1):
-            tmp = self.simulator.substep_grad(s, action=mpm_action, ext_f_grad=ext_f_grad_list)
-            if tmp is not None:
-                mpm_action_grad += tmp
+        # the reverse loop of :128-133 as ONE call: the library runs the env step's substeps back to back (no host round trip, no stream
+        # sync per substep; in float32 it reverses substep f's P2G and substep f-1's G2P in one launch) and sums action.grad on the device
+        tmp = self.simulator.run_substeps_grad(self.simulator.cur, self.substeps, ext_f_grad_list, mpm_action)
         if action is None:
             return None
+        mpm_action_grad = tmp if tmp is not None else np.zeros(np.asarray(action).shape)
         return torch.tensor(mpm_action_grad) if self.control_mode == "mpm" else rigid_action_grad
 
     def backward(self):                                          # :139-151

@@ -1,19 +1,24 @@
 """The batched backward sweep (`run_substeps_grad`) reverses substep f's P2G and substep f-1's G2P in ONE launch (k_p2g_g2p_grad) wherever
 the two substeps share a binning and frame f carries no seed.  It must give what the substep-by-substep sweep gives - for the final
 adjoint, for every intermediate adjoint frame (they stay readable), with seeds in the middle of the window, across a re-sort, and for
-the primitives' adjoints.  (The comparison with the oracle is the parity suite's: it runs the batched sweep as well.)"""
+the primitives' adjoints.  This file compares the library with itself; the comparison of the fused kernel with the ORACLE is
+tests/test_gpu_parity.py::test_batched_sweep_against_the_oracle (float32 legs, which assert that the fused launch was taken)."""
 import os
 
 import numpy as np
 import pytest
 
+import types
+
 import helpers as H
+import torch
+from helpers import O
 from softmac_amd import scenes
 
 pytestmark = pytest.mark.gpu
 
 
-def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=64):
+def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=64, want_zone=False):
     old = os.environ.get("SMAC_FUSED_PG")
     os.environ["SMAC_FUSED_PG"] = "1" if fused else "0"
     try:
@@ -44,6 +49,15 @@ def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=6
     prim = np.array([m.get_all_states_grad(f) for m in prm for f in range(n_sub)])
     counts = sim.profile_report()
     sim.profile(False)
+    if want_zone:
+        # particles inside the reference's SVD-adjoint clamp at some frame of the window, and their grid neighbours (helpers.F32_TOL): their
+        # adjoints are ill-conditioned by construction (1e-4 for 3e-10 of input noise in f64 arithmetic), so two runs of the SAME
+        # path differ there by more than anywhere else; they are bounded separately, as everywhere in the parity suite
+        st = [sim.get_state(f) for f in range(n_sub)]
+        shim = types.SimpleNamespace(frames=[tuple(torch.as_tensor(a) for a in (s[:, 0:3], s[:, 3:6], s[:, 15:24].reshape(N, 3, 3), s[:, 6:15].reshape(N, 3, 3)))
+                                             for s in st])
+        zone, near = H.clamp_zone(shim, H.oracle_params(cfg, env_dt), n_sub, neighbours=True)
+        return frames, prim, counts, zone | near
     return frames, prim, counts
 
 
@@ -51,19 +65,23 @@ def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=6
 def test_fused_backward_step_equals_the_two_kernels(n_sub, seeds, sort_interval):
     # (the last case: an episode of three env steps with a loss seed at the end of each, 8 re-sorts on the way)
     a, pa, ca = _rollout(True, n_sub, seeds, sort_interval)
-    b, pb, cb = _rollout(False, n_sub, seeds, sort_interval)
+    b, pb, cb, ill = _rollout(False, n_sub, seeds, sort_interval, want_zone=True)
     c, pc, cc = _rollout(True, n_sub, seeds, sort_interval, batched=False)       # no hint: never fused
-    worst = noise = 0.0
+    worst = noise = worst_ill = noise_ill = 0.0
     for f in sorted(b):
         scale = np.abs(b[f]).max()
         assert scale > 0
-        worst = max(worst, np.abs(a[f] - b[f]).max() / scale)
-        noise = max(noise, np.abs(c[f] - b[f]).max() / scale)
+        da, dc = np.abs(a[f] - b[f]).max(axis=1) / scale, np.abs(c[f] - b[f]).max(axis=1) / scale
+        worst, noise = max(worst, da[~ill].max()), max(noise, dc[~ill].max())
+        if ill.any():
+            worst_ill, noise_ill = max(worst_ill, da[ill].max()), max(noise_ill, dc[ill].max())
     print(f"\n[fused backward, seeds {seeds}, sort_interval {sort_interval}] worst adjoint-frame difference fused vs apart {worst:.1e}; "
-          f"apart vs apart (two handles, the un-hinted sweep never fuses) {noise:.1e}")
+          f"apart vs apart (two handles, the un-hinted sweep never fuses) {noise:.1e}; on the {int(ill.sum())} clamp-zone particles and their "
+          f"neighbours: {worst_ill:.1e} / {noise_ill:.1e}")
     # Two rollouts of the SAME path already differ in the last bits (float atomics of drifted lanes arrive in any order, and 12 backward substeps
-    # carry that on); the fused step must stay inside that noise, not just inside a parity tolerance
+    # carry that on); the fused step must stay inside that noise, not just inside a parity tolerance.  Clamp-zone particles: F32_TOL's tier.
     assert noise < (2e-5 if n_sub <= 12 else 2e-4) and worst < max(10 * noise, 5e-6)
+    assert worst_ill < H.F32_TOL["clamp"] and noise_ill < H.F32_TOL["clamp"]
     assert np.abs(pb).max() > 0 and H.rel_err(pa, pb) < max(10 * H.rel_err(pc, pb), 2e-6)   # the primitives' state adjoints (contact runs between the two halves)
 
 

@@ -7,7 +7,7 @@ for round in 1 2 3; do
   for spec in "$@"; do
     label=${spec%%=*}; rest=${spec#*=}; lib=${rest%%,*}; envs=""
     if [[ "$rest" == *,* ]]; then envs=$(echo "${rest#*,}" | tr ',' ' '); fi
-    env SMAC_LIB=$PWD/softmac_amd/lib/$lib $envs timeout -k 10 300 python bench.py --steps 64 --warmup 16 --no-cpu-baseline --no-f64 --no-cloth --repeats 2 > $O/ab_${label}_$round.json 2> $O/ab_${label}_$round.err
+    env SMAC_LIB=$PWD/softmac_amd/lib/$lib $envs timeout -k 10 300 python bench.py --steps 64 --warmup 16 --no-cpu-baseline --no-f64 --no-cloth --no-env-loop --repeats 2 > $O/ab_${label}_$round.json 2> $O/ab_${label}_$round.err
   done
 done
 python3 - "$O" "$@" <<'PY'

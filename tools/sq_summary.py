@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
-"""Per-kernel means of the SQ counters of one rocprofv3 --pmc pass -> CSV with derived columns.
+"""Per-kernel means of the SQ counters of one or several rocprofv3 --pmc passes -> CSV with derived columns.
 
-    python tools/sq_summary.py gpurun_out/r02j/sq/sq_counter_collection.csv > profiles/r02_j_sq_summary.csv
+    python tools/sq_summary.py gpurun_out/r03a/pmc_*/t_counter_collection.csv > profiles/r03_a_sq_summary.csv
 
-SQ_INSTS_VALU counts wave instructions; a wave64 VALU instruction occupies its SIMD (16 lanes) for 4 cycles, so
-`valu_floor_us` = INSTS_VALU * 4 / (1024 SIMDs * 2.4 GHz) is the time the kernel's arithmetic alone needs on a full chip."""
+What a wave64 VALU instruction costs (round 3, tools/microbench/valu_issue.hip, profiles/r03_a_valu_issue.txt): a wave ALONE on its SIMD
+issues one every 5.2 cycles; with >= 2 waves per SIMD the SIMD issues one every 2.3 ... 2.7 cycles (MI355X_MICROARCH.md: "2 cyc (SIMD-32);
+one wave alone: 4") at the 2.0 ... 2.2 GHz the chip holds under VALU load.  Round 2 priced floors at 4 cycles and 2.4 GHz; the columns here:
+
+    valu_floor_us        INSTS_VALU * 2.5 cycles / (1024 SIMDs * 2.1 GHz)   - the measured issue cost and clock
+    valu_floor_ideal_us  INSTS_VALU * 2.0 cycles / (1024 SIMDs * 2.4 GHz)   - the guide's figures
+
+The SQ counters themselves count a wave's view in quad-cycles (SQ_ACTIVE_INST_VALU ~ 1.0 per instruction = 4 cycles during which THAT wave's
+instruction is in the pipe; other waves issue meanwhile), so ACTIVE_INST_VALU / INSTS_VALU says nothing about the SIMD's issue cost."""
 import collections
 import csv
 import sys
 
+CYC, GHZ = 2.5, 2.1
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"].split("(")[0].replace("void smac::", "")
-    if not k.startswith("k_"):
-        continue
-    acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
-cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]
-print("kernel,launches,us_under_pmc," + ",".join(cols) + ",valu_per_wave,lds_per_wave,valu_floor_us,wait_any_frac,wait_inst_frac")
+for path in sys.argv[1:]:
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void smac::", "")
+        if not k.startswith("k_"):
+            continue
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAIT_ANY",
+        "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_THREAD_CYCLES_VALU"]
+cols = [c for c in cols if any(acc[k][c] for k in acc)]
+print("kernel,launches,us_under_pmc," + ",".join(cols) + ",valu_per_wave,valu_floor_us,valu_floor_ideal_us,lanes_active_frac,wait_any_frac")
+nan = float("nan")
 for k in sorted(acc, key=lambda k: -sum(dur[k])):
-    m = {c: (sum(acc[k][c]) / len(acc[k][c]) if acc[k][c] else float("nan")) for c in cols}
-    waves = m["SQ_WAVES"] or float("nan")
-    n = len(acc[k]["SQ_WAVES"]) or 1
+    m = {c: (sum(acc[k][c]) / len(acc[k][c]) if acc[k][c] else nan) for c in cols}
+    g = lambda c: m.get(c, nan)
+    n = max(len(v) for v in acc[k].values())
     print(f"{k},{n},{sum(dur[k]) / len(dur[k]):.1f}," + ",".join(f"{m[c]:.0f}" for c in cols) +
-          f",{m['SQ_INSTS_VALU'] / waves:.0f},{m['SQ_INSTS_LDS'] / waves:.0f},{m['SQ_INSTS_VALU'] * 4 / (1024 * 2.4e3):.1f},"
-          f"{m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.2f},{m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.2f}")
+          f",{g('SQ_INSTS_VALU') / g('SQ_WAVES'):.0f},{g('SQ_INSTS_VALU') * CYC / (1024 * GHZ * 1e3):.1f},{g('SQ_INSTS_VALU') * 2.0 / (1024 * 2.4e3):.1f},"
+          f"{g('SQ_THREAD_CYCLES_VALU') / (64 * g('SQ_ACTIVE_INST_VALU')):.2f},{g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.2f}")

@@ -30,6 +30,17 @@ def baseline_metric():
         return "MPM substeps/s (fwd+bwd) at 1M particles/128\u00b3 grid, 1/2/4/8 MI355X"
 
 
+_TABLES = {}
+
+
+def gripper_tables(dev=0):
+    """SURVEY 8(d)'s gripper: palm SDF = the reference's cached table, finger SDF = finger.obj through the library's voxeliser (once per process)"""
+    if dev not in _TABLES:
+        from softmac_amd import scenes
+        _TABLES[dev] = scenes.gripper_tables(os.path.join(ROOT, "tests", "golden"), dev)
+    return _TABLES[dev]
+
+
 def build_sim(args, rank, world, precision=None, frames=None):
     from softmac_amd import scenes
     from softmac_amd.config import CfgNode
@@ -38,15 +49,16 @@ def build_sim(args, rank, world, precision=None, frames=None):
     precision = precision or args.precision
     frames = frames or (args.warmup + args.steps + 2)
     dev = int(os.environ.get("SMAC_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0))) if world > 1 else 0
-    slab = None
+    slab = _own = None
+    tables = gripper_tables(dev) if args.workload == "s-grip" else None
     if args.workload == "s-grip" and world > 1 and args.scaling == "strong":
         # the metric's own case: ONE 1M-particle / 128^3 scene cut into `world` x-slabs of one global grid
-        cfg, env_dt, state, specs, s13, slab, _own = scenes.s_grip_strong(rank, world, args.particles, args.grid, frames, precision, dev)
+        cfg, env_dt, state, specs, s13, slab, _own = scenes.s_grip_strong(rank, world, args.particles, args.grid, frames, precision, dev, tables=tables)
     elif args.workload == "s-grip" and world > 1:
         cfg, env_dt, state, specs, s13, lh = scenes.s_grip_slab(rank, world, args.particles, args.grid, frames, precision, dev)
         slab = (lh[0], lh[1], 2)
     elif args.workload == "s-grip":
-        cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, frames, precision, dev, seed=1 + rank)
+        cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, frames, precision, dev, seed=1 + rank, tables=tables)
     else:
         cfg, env_dt, state, specs, s13 = scenes.s_elastic(args.particles, args.grid, frames, precision, dev, seed=rank)
     cfg.recompute_backward = args.recompute_backward
@@ -69,10 +81,18 @@ def build_sim(args, rank, world, precision=None, frames=None):
     sim.reset(state)
     runner = sim
     if slab is not None:                                   # slab decomposition: halo exchange of the shared x-planes over RCCL
-        from softmac_amd.parallel import HipSlabEngine, SlabRunner, contact_sides
+        from softmac_amd.parallel import HipSlabEngine, LibSlabRunner, SlabRunner, agree_contact_sides, contact_sides, rendezvous_unique_id
         traj = [np.stack([s13[i] + np.concatenate([f * cfg.dt * s13[i][7:10], np.zeros(10)]) for f in range(frames)]) for i in range(len(specs))]
         sides = contact_sides(specs, traj, args.grid, slab[0], slab[1], slab[2], rank, world)
-        runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=sides)
+        sides = agree_contact_sides(sides, rank, world)    # a boundary's two ranks must post the same exchanges
+        if args.slab_runner == "lib":
+            # the loop inside the library: ncclSend / ncclRecv on its own stream, no Python between the phases; the process group (gloo, CPU)
+            # only carries the RCCL id, the barriers and the max-over-ranks of the wall clock
+            tol = (slab[2] - 2) // 2                        # range of stencil bases this rank owns, from its shared planes (scenes.s_grip_strong)
+            own = (slab[0] + tol if rank > 0 else 0, slab[1] + tol if rank < world - 1 else args.grid)
+            runner = LibSlabRunner(sim, rank, world, slab[0], slab[1], slab[2], has_contact=sides, own=own, unique_id=rendezvous_unique_id(rank))
+        else:
+            runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=sides)
         runner.contact_sides_note = sides
     return sim, runner, cfg
 
@@ -100,7 +120,7 @@ def cpu_baseline(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
     from oracle import mpm_cpu
-    cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, "float64", 0, seed=1)
+    cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, "float64", 0, seed=1, tables=gripper_tables(0))
     P = H.oracle_params(cfg, env_dt)
     port = mpm_cpu.CpuPort(P, specs)
     N = args.particles
@@ -134,9 +154,9 @@ def env_loop_record(args, seed_gx):
     from softmac_amd.engine.primitive import Mesh, Primitives
     from softmac_amd.engine.taichi_env import TaichiEnv
     import torch
-    scfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, args.precision, 0, seed=1)
-    n_env = max(1, args.steps // 10)
-    w_env = max(1, (args.warmup + 9) // 10)
+    scfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, args.precision, 0, seed=1, tables=gripper_tables(0))
+    n_env = max(5, args.steps // 10)         # at least 5 env steps: an episode starts from the caller's particle order (reset), whose first binning
+    w_env = max(1, (args.warmup + 9) // 10)  # costs 3 x a re-sort of a binned frame - the reference's episodes have 400 env steps (demo_grip.py:189-191)
     cfg = get_cfg_defaults()
     cfg.control_mode = "rigid"
     cfg.rigid_velocity_control = True
@@ -212,6 +232,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
     ap.add_argument("--sort-interval", type=int, default=0, help="0: min(32, steps), so that every timed window holds a re-sort")
+    ap.add_argument("--slab-runner", default=os.environ.get("SMAC_SLAB_RUNNER", "lib"), choices=["lib", "python"],
+                    help="N > 1: lib = smac_substeps_slab (RCCL inside the library); python = parallel.SlabRunner on torch.distributed")
     ap.add_argument("--launch-check", action="store_true",
                     help="spawn the ranks, rendezvous (gloo), report - no simulator, no GPU call (CPU test of the launcher)")
     return ap.parse_args(argv)
@@ -315,7 +337,8 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("SMAC_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0))))
-        dist.init_process_group(os.environ.get("SMAC_DIST_BACKEND", "nccl"))      # "nccl" is RCCL on ROCm
+        # in-library runner: the data path's RCCL communicator lives in libsoftmac_hip; torch.distributed is the control plane only (gloo)
+        dist.init_process_group(os.environ.get("SMAC_DIST_BACKEND", "gloo" if args.slab_runner == "lib" else "nccl"))      # "nccl" is RCCL on ROCm
 
     sim, run, cfg = build_sim(args, rank, world)
     N_local, K, W = int(cfg.n_particles), args.steps, args.warmup
@@ -325,8 +348,8 @@ def main():
     seed_gx = rng.standard_normal((N_local, 3))
     reducer = None
     if world > 1:
-        from softmac_amd.parallel import PrimitiveReducer
-        reducer = PrimitiveReducer(sim)
+        from softmac_amd.parallel import LibSlabRunner, PrimitiveReducer
+        reducer = run if isinstance(run, LibSlabRunner) else PrimitiveReducer(sim)
 
     def barrier():
         sim.sync()
@@ -410,7 +433,8 @@ def main():
             "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",
             "config": {"workload": (f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
-                                    f"3 gripper SDF primitives (2 in forecast contact), fwd+bwd") if args.workload == "s-grip" else
+                                    f"3 gripper SDF primitives (2 in forecast contact; palm = the reference's cached SDF table, fingers = "
+                                    f"finger.obj through smac_mesh_to_sdf), fwd+bwd") if args.workload == "s-grip" else
                                    f"{args.workload}: {N} particles, {args.grid}^3 grid, elastic fixed-corotated, no primitives, fwd+bwd",
                        "particles_per_gpu": [c[0] for c in allc] if world > 1 else N, "n_grid": args.grid,
                        "touched_cells": Gsum if world > 1 else G_t, "contact_particles": sum(c[2] for c in allc),

@@ -222,6 +222,28 @@ int smac_substep_grad_phase(smac_handle h, int f, const double* ext_f_grad, int 
 int smac_halo_pack(smac_handle h, const char* field, int plane0, int nplanes, void* dev_out, int minus_mixed);
 int smac_halo_unpack_add(smac_handle h, const char* field, int plane0, int nplanes, const void* dev_in);
 
+/* ---- the same slab loop INSIDE the library, on RCCL (round 3; SURVEY 8e "Collective": ncclSend / ncclRecv inside ncclGroupStart/End with the two
+ * slab neighbours only, on a communication stream of the handle's own, ordered against the kernels with events; a small ncclAllReduce for the
+ * primitives' wrench sums and state adjoints, once per env step where the reference consumes them - rigid_simulator.py:92-93, 203-208).
+ * RCCL is resolved at run time (dlopen librccl.so.1; SMAC_RCCL_LIB overrides): a single-GPU user never loads it.
+ *   smac_comm_unique_id     rank 0 makes the 128-byte id (ncclGetUniqueId); the caller hands it to every rank (bench.py: torch.distributed gloo)
+ *   smac_comm_init          ncclCommInitRank on the handle's device
+ *   smac_comm_slab          this rank's geometry: first shared x-plane with the left / right neighbour (this rank's grid indexing), planes per side,
+ *                           whether a contact primitive can reach that side's planes (both neighbours must pass the same flag), the range of
+ *                           stencil bases (x) this rank's planes cover (a particle outside it raises an error at the next sync instead of losing
+ *                           its deposits); self_loop = 1 (world 1 only): left = right = this rank on periodic planes - the whole RCCL path on ONE GPU
+ *   smac_substeps_slab[_grad]   count substeps forward / backward with the 2 + 2 exchanges per substep pair, no host round trip in between
+ *   smac_comm_allreduce_ext_f   SUM of ext_f over the ranks in place; total_out (n_primitives, 6) or NULL; clear = the reference's clear_ext_f after the read
+ *   smac_comm_allreduce_prim_grad   SUM of the primitive-state adjoints of frames [f_begin, f_end) over the ranks, in place */
+int smac_comm_unique_id(char id128[128]);
+int smac_comm_init(smac_handle h, const char id128[128], int rank, int world);
+int smac_comm_slab(smac_handle h, int left_plane0, int right_plane0, int nplanes, int contact_left, int contact_right, int base_lo, int base_hi, int self_loop);
+int smac_substeps_slab(smac_handle h, int f0, int count);
+int smac_substeps_slab_grad(smac_handle h, int f0, int count, const double* ext_f_grad);
+int smac_comm_allreduce_ext_f(smac_handle h, double* total_out, int clear);
+int smac_comm_allreduce_prim_grad(smac_handle h, int f_begin, int f_end);
+int smac_comm_destroy(smac_handle h);
+
 #ifdef __cplusplus
 }
 #endif

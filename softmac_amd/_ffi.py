@@ -111,6 +111,14 @@ SIGNATURES = {
     "smac_substep_grad_phase": (C.c_int, [H, C.c_int, c_double_p, C.c_int]),
     "smac_halo_pack": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "smac_halo_unpack_add": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
+    "smac_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "smac_comm_init": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int]),
+    "smac_comm_slab": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "smac_substeps_slab": (C.c_int, [H, C.c_int, C.c_int]),
+    "smac_substeps_slab_grad": (C.c_int, [H, C.c_int, C.c_int, c_double_p]),
+    "smac_comm_allreduce_ext_f": (C.c_int, [H, c_double_p, C.c_int]),
+    "smac_comm_allreduce_prim_grad": (C.c_int, [H, C.c_int, C.c_int]),
+    "smac_comm_destroy": (C.c_int, [H]),
 }
 
 

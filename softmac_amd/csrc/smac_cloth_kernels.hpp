@@ -53,12 +53,49 @@ __global__ __launch_bounds__(BLOCK) void k_cloth_pairs(DevSim<R> D, int f, const
     if (valid) Cl.contact_id[(size_t)f * Cl.n_ids + id] = best;
 }
 
+// ---- broad phase (round 3): a uniform grid over the sheet's padded face boxes, at the granularity the particles are binned at (4^3-cell grid
+// blocks).  face_blocks(): the blocks whose particles can lie inside the face's padded box.  A particle of a chunk of block b had its stencil base
+// in the block's cells when it was binned (x in [(4b + 0.5) dx, (4b + 4.5) dx)) and may have drifted by one block's width since (beyond that the
+// drift flag stops the epoch), so block b must list every face whose padded box reaches [(4b - 3.5) dx, (4b + 8.5) dx) in all three dimensions.
+// Built per sheet frame by two passes over the faces (count, scan, fill); the lists are unordered, the query breaks distance ties by face id.
+struct FaceHash { int* count; int* start; int* list; int cap; int* overflow; };
+__device__ __forceinline__ void face_blocks(const ClothDev& Cl, const double* vpos, int q, int n, int nb, int* lo3, int* hi3) {
+    const double threshold = 1e-2 * Cl.par.scale, inv = (double)n / (4.0 * Cl.par.scale);     // physical length -> block units
+    for (int c = 0; c < 3; ++c) {
+        const double a = vpos[(size_t)Cl.faces[3 * q] * 3 + c], b = vpos[(size_t)Cl.faces[3 * q + 1] * 3 + c], d = vpos[(size_t)Cl.faces[3 * q + 2] * 3 + c];
+        const double flo = (min_(a, min_(b, d)) - threshold) * inv, fhi = (max_(a, max_(b, d)) + threshold) * inv;
+        int l = (int)floor(flo - 8.5 / 4.0) + 1, h = (int)ceil(fhi + 3.5 / 4.0) - 1;
+        lo3[c] = l < 0 ? 0 : l;
+        hi3[c] = h > nb - 1 ? nb - 1 : h;
+    }
+}
+template <bool FILL>
+__global__ void k_cloth_hash(ClothDev Cl, int f, int n, int nb, FaceHash H) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Cl.Fc) return;
+    int lo[3], hi[3];
+    face_blocks(Cl, Cl.pos + (size_t)f * Cl.V * 3, q, n, nb, lo, hi);
+    for (int i = lo[0]; i <= hi[0]; ++i)
+        for (int j = lo[1]; j <= hi[1]; ++j)
+            for (int k = lo[2]; k <= hi[2]; ++k) {
+                const int b = (i * nb + j) * nb + k;
+                const int slot = atomicAdd(H.count + b, 1);
+                if (FILL) {
+                    const int at = H.start[b] + slot;
+                    if (at < H.cap) H.list[at] = q;
+                    else *H.overflow = 1;                  // the list does not fit: the query falls back to the full scan (and the host grows the list)
+                }
+            }
+}
+
 // The same search for a frame in sorted order, one workgroup per chunk: the chunk's particles share a grid block, so the faces are
 // culled once per workgroup against the chunk's bounding box (taken from the particles themselves, drift included) and only the
 // survivors - compacted in face order, so the first-minimum rule is unchanged - reach the per-particle test.  A thin sheet leaves
 // most chunks without a single candidate.  A chunk that holds a particle flagged as penetrated keeps every face (:457).
-template <class R>
-__global__ __launch_bounds__(BLOCK) void k_cloth_pairs_chunk(DevSim<R> D, int f, const R* Sf) {
+// HASH: the faces come from the block's list of the broad phase instead of the whole mesh (bit-equal result: a superset of the faces that pass
+// the chunk cull, ties between equal distances go to the lower face id = "first minimum wins" of the in-order scan).
+template <class R, bool HASH>
+__global__ __launch_bounds__(BLOCK) void k_cloth_pairs_chunk(DevSim<R> D, int f, const R* Sf, FaceHash H) {
     __shared__ double fv[CLOTH_FACE_BATCH][9];
     __shared__ int fid[CLOTH_FACE_BATCH];
     __shared__ double red[2][4][3];
@@ -89,12 +126,15 @@ __global__ __launch_bounds__(BLOCK) void k_cloth_pairs_chunk(DevSim<R> D, int f,
     }
     __syncthreads();
     const bool keep_all = any_pen != 0;
+    const bool listed = HASH && !keep_all && *H.overflow == 0;        // (a chunk with a penetrated particle keeps every face, :457)
+    const int nfaces = listed ? H.count[ch.block] : Cl.Fc;
+    const int* flist = listed ? H.list + H.start[ch.block] : nullptr;
     const double threshold = 1e-2 * Cl.par.scale;
     double dmin = 1e10;
     int best = -1;
     const double* vpos = Cl.pos + (size_t)f * Cl.V * 3;
-    for (int base = 0; base < Cl.Fc; base += CLOTH_FACE_BATCH) {
-        const int q = base + t;
+    for (int base = 0; base < nfaces; base += CLOTH_FACE_BATCH) {
+        const int q = base + t < nfaces ? (listed ? flist[base + t] : base + t) : Cl.Fc;
         double v9[9];
         bool cand = false;
         if (q < Cl.Fc) {
@@ -121,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void k_cloth_pairs_chunk(DevSim<R> D, int f,
             for (int j = 0; j < ncand; ++j)
                 if (pen || cl_in_bbox(px, fv[j], fv[j] + 3, fv[j] + 6, threshold)) {
                     const double d = cl_distance(px, fv[j], fv[j] + 3, fv[j] + 6);
-                    if (d < dmin) { dmin = d; best = fid[j]; }
+                    if (d < dmin || (HASH && d == dmin && fid[j] < best)) { dmin = d; best = fid[j]; }
                 }
         __syncthreads();
     }

@@ -1,0 +1,60 @@
+// RCCL for the slab decomposition inside the library (no reference counterpart: the reference is single-device).
+//
+// The library does not LINK against librccl (573 MB, and a single-GPU user never needs it): the entry points are resolved with
+// dlopen / dlsym at smac_comm_init, typed from <rccl/rccl.h> so that a signature change is a compile error, not a crash.
+// Neighbour-only ncclSend / ncclRecv inside one ncclGroup (each GPU pair of an MI355X node has its own xGMI link; a ring all-reduce
+// of the grid would move G instead of 2 planes and be per-link bound) + a small ncclAllReduce for the primitives' wrench sums / adjoints.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <string>
+
+namespace smac {
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+
+    bool load() {
+        if (lib) return true;
+        // SMAC_RCCL_LIB: explicit path; else the ROCm install's library, then whatever the loader finds
+        const char* names[] = {getenv("SMAC_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return false; }
+        bool ok = true;
+        auto sym = [&](const char* name) { void* p = dlsym(lib, name); if (!p) { ok = false; err = std::string("RCCL symbol missing: ") + name; } return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { dlclose(lib); lib = nullptr; }
+        return ok;
+    }
+    static Rccl& get() { static Rccl r; return r; }
+};
+
+template <class R> struct nccl_type;
+template <> struct nccl_type<float> { static constexpr ncclDataType_t v = ncclFloat32; };
+template <> struct nccl_type<double> { static constexpr ncclDataType_t v = ncclFloat64; };
+
+}  // namespace smac

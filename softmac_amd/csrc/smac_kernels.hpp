@@ -121,6 +121,8 @@ template <class R> struct DevSim {
     int frame_shift;             // duplicate frames before this segment (smac_set_segment): physical substep = f - frame_shift
     int check_next;              // k_g2p: frame f+1 is processed with THIS binning too, so x[f+1] must still lie inside the halo
     int open_x;                  // slab decomposition: bit 0 / bit 1 = no wall at the low / high x end (neighbour slab there)
+    int slab_base_lo, slab_base_hi;   // slab decomposition: stencil bases (x) this rank's grid planes can take deposits for, drift tolerance included
+                                      // (a particle beyond them would scatter onto planes nobody exchanges: flagged by k_g2p, drift_flag[2]); lo > hi: no check
     const int* block_active;     // dense per-block flag of the current epoch (halo packing)
     // Grid checkpoint of the frame being processed, [active slot][vin | vmix | vout][64 cells], or nullptr.
     // Forward: k_grid_op / k_contact_hits write it directly (no copy kernel).  Backward: the kernels READ the forward grid
@@ -1068,6 +1070,7 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
         // the position just written is scattered by the NEXT substep's P2G: if that substep keeps this binning, the new
         // base must still lie in the blocks around the chunk's own (the only ones that are cleared, reduced and swept)
         int nbase = pos_base(xn, D.n);
+        if (c == 0 && D.slab_base_lo <= D.slab_base_hi && (nbase < D.slab_base_lo || nbase > D.slab_base_hi)) D.drift_flag[2] = 1;   // left the slab's shared planes
         nbase = nbase < 0 ? 0 : (nbase > D.n - 3 ? D.n - 3 : nbase);
         const int cbk = c == 0 ? ch.block / (D.nb * D.nb) : (c == 1 ? (ch.block / D.nb) % D.nb : ch.block % D.nb);
         leaves |= (nbase >> 2) < cbk - 1 || (nbase >> 2) > cbk + 1;
@@ -2100,6 +2103,37 @@ __global__ __launch_bounds__(BLOCK) void k_halo_unpack_add(DevSim<R> D, Vec4<R>*
     field[c] = v;
 }
 
+// both neighbours' planes in ONE launch (the in-library exchange, softmac_hip.hip `exchange`): blockIdx.y picks the entry of `hs`;
+// buffer slot 0 = left neighbour, 1 = right neighbour, each np * n * n records
+struct HaloSides { int count; int slot[2]; int plane0[2]; };
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_halo_pack2(DevSim<R> D, const Vec4<R>* field, const Vec4<R>* minus, HaloSides hs, int np, Vec4<R>* out) {
+    const int idx = blockIdx.x * BLOCK + threadIdx.x, total = np * D.n * D.n;
+    if (idx >= total) return;
+    const int s = blockIdx.y;
+    const int k = idx % D.n, j = (idx / D.n) % D.n, i = hs.plane0[s] + idx / (D.n * D.n);
+    Vec4<R> v = {R(0), R(0), R(0), R(0)};
+    if (D.block_active[block_of(D.nb, i, j, k)]) {
+        const size_t c = cell_of(D.nb, i, j, k);
+        v = field[c];
+        if (minus) { const Vec4<R> m = minus[c]; v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
+    }
+    out[(size_t)hs.slot[s] * total + idx] = v;
+}
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_halo_unpack_add2(DevSim<R> D, Vec4<R>* field, HaloSides hs, int np, const Vec4<R>* in) {
+    const int idx = blockIdx.x * BLOCK + threadIdx.x, total = np * D.n * D.n;
+    if (idx >= total) return;
+    const int s = blockIdx.y;
+    const int k = idx % D.n, j = (idx / D.n) % D.n, i = hs.plane0[s] + idx / (D.n * D.n);
+    if (!D.block_active[block_of(D.nb, i, j, k)]) return;
+    const size_t c = cell_of(D.nb, i, j, k);
+    const Vec4<R> a = in[(size_t)hs.slot[s] * total + idx];
+    Vec4<R> v = field[c];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    field[c] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------
@@ -2133,18 +2167,21 @@ __global__ void k_count_active(const R* gm, size_t G, unsigned long long* out) {
 }
 
 // forward_kinematics :280-283 and its adjoint (13 inputs -> 7 outputs, forward-mode duals)
+// `stride` scalars separate the primitives' state arrays; thread i advances primitive i (one launch for all of them, :329-331)
 template <class R>
-__global__ void k_prim_fk(R* state, int f, R dt) {      // instantiated with R = double: primitive state is f64 in both modes
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    R* s = state + (size_t)f * 13;
+__global__ void k_prim_fk(R* state, int f, R dt, int nprims = 1, size_t stride = 0) {      // instantiated with R = double: primitive state is f64 in both modes
+    if ((int)threadIdx.x >= nprims || blockIdx.x != 0) return;
+    R* s = state + threadIdx.x * stride + (size_t)f * 13;
     R o[7];
     forward_kinematics(s, dt, o);
     for (int i = 0; i < 7; ++i) s[13 + i] = o[i];
 }
 template <class R>
-__global__ void k_prim_fk_grad(const R* state, R* grad, int f, R dt) {
+__global__ void k_prim_fk_grad(const R* state, R* grad, int f, R dt, size_t stride = 0) {   // one workgroup per primitive (they do not interact: :367-369 in any order)
     const int dir = threadIdx.x;
-    if (dir >= 13 || blockIdx.x != 0) return;
+    if (dir >= 13) return;
+    state += blockIdx.x * stride;
+    grad += blockIdx.x * stride;
     const R* s = state + (size_t)f * 13;
     Dual<R> sd[13], o[7];
     for (int i = 0; i < 13; ++i) sd[i] = Dual<R>(s[i], i == dir ? R(1) : R(0));
@@ -2152,6 +2189,26 @@ __global__ void k_prim_fk_grad(const R* state, R* grad, int f, R dt) {
     R acc = R(0);
     for (int i = 0; i < 7; ++i) acc += grad[(size_t)(f + 1) * 13 + i] * o[i].d;
     grad[(size_t)f * 13 + dir] += acc;
+}
+
+
+// Velocity control on the device (primitive_base.py:285-319, rigid_simulator_vel.py:20-44): set_action writes the 6-D action (w, v) into the
+// action buffer and fans it out over the env step's frames; get_action_grad folds the frames' v / w adjoints back into action_buffer.grad.
+struct Act6 { double a[6]; };
+__global__ void k_prim_set_action(double* state, double* action_buf, int s, int n, Act6 a) {
+    const int j = threadIdx.x;
+    if (j < 6) action_buf[(size_t)s * 6 + j] = a.a[j];
+    if (j < n) {
+        double* st = state + (size_t)(s * n + j) * 13;
+        for (int k = 0; k < 3; ++k) { st[7 + k] = a.a[3 + k]; st[10 + k] = a.a[k]; }
+    }
+}
+__global__ void k_prim_action_grad(const double* grad, double* action_buf_grad, int s, int n) {
+    const int c = threadIdx.x;
+    if (c >= 6) return;
+    double acc = action_buf_grad[(size_t)s * 6 + c];
+    for (int j = 0; j < n; ++j) acc += grad[(size_t)(s * n + j) * 13 + (c < 3 ? 10 + c : 7 + (c - 3))];     // set_velocity_from_action_kernel.grad :315-319
+    action_buf_grad[(size_t)s * 6 + c] = acc;
 }
 
 }  // namespace smac

@@ -11,6 +11,7 @@
 
 #include "../../include/softmac_hip.h"
 #include "smac_kernels.hpp"
+#include "smac_comm.hpp"
 #include "smac_cloth_kernels.hpp"
 #include "smac_voxel.hpp"
 #include "smac_loss.hpp"
@@ -45,6 +46,9 @@ static const char* kDriftMessage =
 static const char* kHitOverflowMessage =
     "more than 1/8 of the particles were inside a contact band in one substep: its hit list does not fit the grid "
     "checkpoint, which the direct-checkpoint modes (SMAC_CK_MODE=1/2) walk in place (use the default mode, or flags bit 0 - recompute_backward)";
+static const char* kSlabLeftMessage =
+    "slab decomposition: a particle's stencil left the x-planes this rank shares with its neighbours (its deposits there would be lost): "
+    "migrate more often (SlabRunner.migrate at every re-sort) or widen the shared band (nplanes = 2 + 2 * drift tolerance)";
 static const char* kKernelNames[K_COUNT] = {"clear_grid", "grid_checkpoint", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
                                             "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint", "p2g_g2p_grad"};
 
@@ -108,6 +112,13 @@ struct ISim {
     virtual int halo_pack(const char* field, int plane0, int np, void* dev_out, int minus_mixed) = 0;
     virtual int halo_unpack_add(const char* field, int plane0, int np, const void* dev_in) = 0;
     virtual int set_stream(void* s) = 0;
+    virtual int comm_init(const char* id128, int rank, int world) = 0;
+    virtual int comm_slab(int left0, int right0, int nplanes, int contact_left, int contact_right, int base_lo, int base_hi, int self_loop) = 0;
+    virtual int substeps_slab(int f0, int count) = 0;
+    virtual int substeps_slab_grad(int f0, int count, const double* ext_f_grad) = 0;
+    virtual int comm_allreduce_ext_f(double* total_out, int clear) = 0;
+    virtual int comm_allreduce_prim_grad(int f0, int f1) = 0;
+    virtual int comm_destroy() = 0;
     virtual int stream_handle(void** s) = 0;
     virtual void hint_backward_next(int f) = 0;
     virtual int set_param(const char* name, double value) = 0;
@@ -211,6 +222,7 @@ template <class R> struct Sim final : ISim {
 
     ~Sim() override {
         if (stream) hipStreamSynchronize(stream);
+        comm_destroy();
         hipFree(D.S); hipFree(D.A); hipFree(grid_block); hipFree(D.prim_state); hipFree(D.prim_grad);
         hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);
         hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
@@ -222,6 +234,8 @@ template <class R> struct Sim final : ISim {
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(tmp_frame2); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
         hipFree(d_io); hipFree(ext_snap); hipFree(cloth_ext_snap);
+        hipFree(fhash.count); hipFree(fhash.start); hipFree(fhash.list); hipFree(fhash.overflow);
+        if (hash_total_host) hipHostFree(hash_total_host);
         hipFree(d_cloth_faces); hipFree(d_cloth_nbr); hipFree(d_cloth_nbr_dir); hipFree(d_cloth_warn); hipFree(d_cloth_ext_scratch);
         hipFree(D.cloth.pos); hipFree(D.cloth.vel); hipFree(D.cloth.pos_grad); hipFree(D.cloth.vel_grad); hipFree(D.cloth.ext_f);
         hipFree(D.cloth.ext_f_grad); hipFree(D.cloth.contact_id); hipFree(D.cloth.penetration); hipFree(D.cloth.contact_before);
@@ -349,8 +363,10 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&d_active_flag, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_active_start, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&tmp_frame, fs));
-        HIP_TRY(hipMalloc((void**)&d_drift, 2 * sizeof(int)));                  // [0]: a particle out-ran its binning; [1]: a contact hit list did not fit its checkpoint slot
-        HIP_TRY(hipMemsetAsync(d_drift, 0, 2 * sizeof(int), stream));
+        // [0]: a particle out-ran its binning; [1]: a contact hit list did not fit its checkpoint slot; [2]: a particle left its slab's shared planes
+        HIP_TRY(hipMalloc((void**)&d_drift, 4 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_drift, 0, 4 * sizeof(int), stream));
+        D.slab_base_lo = 1; D.slab_base_hi = 0;                        // no slab range check until smac_comm_slab / smac_set_slab_range says so
         D.drift_flag = d_drift;
         epochs.clear();
         epochs.emplace_back();
@@ -506,8 +522,11 @@ template <class R> struct Sim final : ISim {
         };
         if (cols != 24) HIP_TRY(hipMemsetAsync(fr, 0, frame_scalars() * sizeof(R), stream));   // v = 0, C = 0, F = I (stored as E = 0)
         rows(CX, 3, 0, 2);
+        if (cols == 24) rows(CV, 3, 3, 0);
+        if ((rc = check_launch())) return rc;
+        // bin the particles now (positions and speeds are on the device) and write every row from the caller's array in the binned order
+        if (!getenv("SMAC_RESET_UNSORTED")) return sort_frame(0, false, false, d_io, cols);
         if (cols == 24) {
-            rows(CV, 3, 3, 0);
             rows(CF, 9, 6, 1);
             rows(CC, 9, 15, 0);
         }
@@ -929,7 +948,10 @@ template <class R> struct Sim final : ISim {
     }
     int drift_repairs = 0;
 
-    int sort_frame(int f, bool read_drift = false, bool allow_repair = true) {
+    // `aos` (reset): the frame's x and v rows are already there in the caller's order; after the binning ALL rows are written straight from the
+    // caller's (N, cols) array in the new order (192 contiguous bytes per particle) instead of being moved row by row - an episode's first
+    // binning then costs no scattered frame move (411 us at 1M particles from a random order) and no copy-back.
+    int sort_frame(int f, bool read_drift = false, bool allow_repair = true, const double* aos = nullptr, int cols = 0) {
         const int e_old = frame_epoch[f];
         gc_epochs();
         const int e_new = new_epoch_slot();
@@ -950,9 +972,19 @@ template <class R> struct Sim final : ISim {
         hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot,
                            (const int*)d_bin_start, (const unsigned long long*)d_bin_mask, (const int*)d_over_prefix,
                            (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig);
-        hipLaunchKernelGGL(k_sort_move<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_dest, (const R*)Sf, tmp_frame,
-                           D.Npad, (int)NCOMP);
-        HIP_TRY(hipMemcpyAsync(Sf, tmp_frame, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        if (aos) {
+            auto rows = [&](int c0, int cnt, int offset, int ident) {
+                hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, aos, cols, offset, cnt, (const int*)ep.orig,
+                                   ident, Sf + rowbase(c0, D.Npad));
+            };
+            if (cols != 24) HIP_TRY(hipMemsetAsync(Sf, 0, frame_scalars() * sizeof(R), stream));   // v = 0, C = 0, F = I (stored as E = 0)
+            rows(CX, 3, 0, 2);
+            if (cols == 24) { rows(CV, 3, 3, 0); rows(CF, 9, 6, 1); rows(CC, 9, 15, 0); }
+        } else {
+            hipLaunchKernelGGL(k_sort_move<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_dest, (const R*)Sf, tmp_frame,
+                               D.Npad, (int)NCOMP);
+            HIP_TRY(hipMemcpyAsync(Sf, tmp_frame, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        }
         // block info, chunk list, active list
         HIP_TRY(hipMemsetAsync(d_active_flag, 0, (nblocks + 1) * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_block_chunks, 0, (nblocks + 1) * sizeof(int), stream));
@@ -965,13 +997,13 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemcpyAsync(&totals[0], d_chunk_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&totals[1], d_active_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&vbits, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        int flags2[2] = {0, 0};
-        if (read_drift) HIP_TRY(hipMemcpyAsync(flags2, d_drift, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        int flags2[4] = {0, 0, 0, 0};
+        if (read_drift) HIP_TRY(hipMemcpyAsync(flags2, d_drift, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         // a drift error of the epoch that ends here is reported AFTER the new epoch is committed: S[f] is already in the
         // new order, so frame_epoch[f] must name it or every later get_state / set_frame of this frame would be scrambled
         const int drifted = flags2[0];
-        if (flags2[0] || flags2[1]) HIP_TRY(hipMemsetAsync(d_drift, 0, 2 * sizeof(int), stream));
+        if (flags2[0] || flags2[1] || flags2[2]) HIP_TRY(hipMemsetAsync(d_drift, 0, 4 * sizeof(int), stream));
         {
             // A particle may move 4 cells (its block's halo) before the binning breaks; budget 2 cells for the fastest
             // particle at its current speed, which leaves a factor two for acceleration inside the interval.
@@ -1009,8 +1041,9 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMalloc((void**)&d_cand, slab_chunks * sizeof(int)));
         }
         if (flags2[1] && (rc = hit_overflow())) return rc;
+        REQUIRE(!flags2[2], kSlabLeftMessage);
         if (drifted) {
-            if (allow_repair && repair_drift(f, e_old) == SMAC_OK) return sort_frame(f, true, false);   // frame f is recomputed: bin it again
+            if (allow_repair && !aos && repair_drift(f, e_old) == SMAC_OK) return sort_frame(f, true, false);   // frame f is recomputed: bin it again
             err = kDriftMessage;
             return SMAC_ERR_INVALID;
         }
@@ -1081,13 +1114,19 @@ template <class R> struct Sim final : ISim {
         ++hit_overflows;
         return SMAC_OK;
     }
+    // the flags can only change when kernels ran: a second check at the same point of the tape (clear_ext_f / ext_f of the NEXT primitive at an
+    // env-step boundary) costs no device round trip
+    long long launches_seen = -1, launch_counter = 0;
     int check_drift() {
-        int h[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(h, d_drift, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (launches_seen == launch_counter) return SMAC_OK;
+        launches_seen = launch_counter;
+        int h[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(h, d_drift, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (h[0] || h[1]) HIP_TRY(hipMemsetAsync(d_drift, 0, 2 * sizeof(int), stream));
+        if (h[0] || h[1] || h[2]) HIP_TRY(hipMemsetAsync(d_drift, 0, 4 * sizeof(int), stream));
         int rc;
         if (h[1] && (rc = hit_overflow())) return rc;
+        REQUIRE(!h[2], kSlabLeftMessage);
         if (h[0]) {
             if (fwd_head > 0 && frame_epoch[fwd_head] > 0 && repair_drift(fwd_head, frame_epoch[fwd_head]) == SMAC_OK) {
                 int h2[2] = {0, 0};                           // the replay (re-binning before every substep) must itself come out clean
@@ -1133,13 +1172,18 @@ template <class R> struct Sim final : ISim {
         } else if (!strcmp(name, "cloth_pairs_flat")) {
             cloth_pairs_by_chunk = value != 0.0 ? 0 : 1;   // 1: the flat contact-face search (every particle over every face) also on sorted frames
             return SMAC_OK;
-        } else REQUIRE(false, "set_param: unknown parameter (plasticity | yield_ratio | mass_eps | cloth_pairs_flat)");
+        } else if (!strcmp(name, "cloth_hash")) {
+            cloth_hash_on = value != 0.0 ? 1 : 0;          // 0: per-chunk search over the whole mesh (round 2), 1: over the broad phase's per-block face lists
+            return SMAC_OK;
+        } else REQUIRE(false, "set_param: unknown parameter (plasticity | yield_ratio | mass_eps | cloth_pairs_flat | cloth_hash)");
         ++config_gen;                                   // the forward grids on file were made with the old value
         return SMAC_OK;
     }
     int get_param(const char* name, double* value) override {
         REQUIRE(name && value, "get_param: null argument");
         if (!strcmp(name, "drift_repairs")) *value = (double)drift_repairs;             // epochs recomputed because a particle out-ran its binning
+        else if (!strcmp(name, "cloth_hash_entries")) *value = hash_total_host ? (double)*hash_total_host : 0.0;   // (face, block) pairs of the last broad-phase build
+        else if (!strcmp(name, "exchanges")) *value = (double)exchanges_done;          // halo exchanges run by smac_substeps_slab[_grad] so far
         else if (!strcmp(name, "hit_overflows")) *value = (double)hit_overflows;      // times a contact hit list did not fit its checkpoint slot (backward then repeats the band test)
         else if (!strcmp(name, "plasticity")) *value = (double)D.mat.plast;
         else if (!strcmp(name, "yield_ratio")) *value = (double)D.mat.yield_c;
@@ -1185,6 +1229,45 @@ template <class R> struct Sim final : ISim {
         ++config_gen;
         return SMAC_OK;
     }
+    // ---- broad phase of the contact-face search (smac_cloth_kernels.hpp FaceHash): per grid block the faces whose padded box can hold one of its
+    // particles; rebuilt when the sheet's frame or state changed.  The total is read back one call late (no host sync on the substep's path):
+    // a list that does not fit raises the device flag, that search scans every face, and the next build has a larger list.
+    FaceHash fhash = {nullptr, nullptr, nullptr, 0, nullptr};
+    int cloth_hash_on = getenv("SMAC_CLOTH_HASH") ? atoi(getenv("SMAC_CLOTH_HASH")) : 1;
+    int hash_frame = -1;
+    long long hash_gen = -1, cloth_state_gen = 0;
+    int* hash_total_host = nullptr;              // pinned: total list length of the last build
+    int cloth_hash_build(int f) {
+        const ClothDev& C = D.cloth;
+        if (!fhash.count) {
+            HIP_TRY(hipMalloc((void**)&fhash.count, ((size_t)nblocks + 1) * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&fhash.start, ((size_t)nblocks + 1) * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&fhash.overflow, sizeof(int)));
+            HIP_TRY(hipHostMalloc((void**)&hash_total_host, sizeof(int)));
+            *hash_total_host = 0;
+        }
+        if (hash_frame == f && hash_gen == cloth_state_gen) return SMAC_OK;
+        const int want = *hash_total_host > 96 * C.Fc + 4096 ? *hash_total_host + *hash_total_host / 4 : 96 * C.Fc + 4096;   // (the previous build's total: read one call late)
+        if (want > fhash.cap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            hipFree(fhash.list);
+            fhash.list = nullptr;
+            HIP_TRY(hipMalloc((void**)&fhash.list, (size_t)want * sizeof(int)));
+            fhash.cap = want;
+        }
+        const int fb = (C.Fc + 255) / 256;
+        HIP_TRY(hipMemsetAsync(fhash.count, 0, ((size_t)nblocks + 1) * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(fhash.overflow, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_cloth_hash<false>, dim3(fb), dim3(256), 0, stream, C, f, D.n, D.nb, fhash);
+        int rc = scan(fhash.count, fhash.start, nblocks + 1);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(hash_total_host, fhash.start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemsetAsync(fhash.count, 0, ((size_t)nblocks + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_cloth_hash<true>, dim3(fb), dim3(256), 0, stream, C, f, D.n, D.nb, fhash);
+        hash_frame = f;
+        hash_gen = cloth_state_gen;
+        return check_launch();
+    }
     int cloth_need() { REQUIRE(D.cloth.present, "this handle has no cloth primitive (smac_cloth_create)"); return SMAC_OK; }
     int cloth_set_state(int f0, int f1, const double* pos, const double* vel) override {            // set_all_states :348-354, frames [f0, f1)
         int rc;
@@ -1197,6 +1280,7 @@ template <class R> struct Sim final : ISim {
         }
         HIP_TRY(hipStreamSynchronize(stream));
         ++config_gen;
+        ++cloth_state_gen;
         return SMAC_OK;
     }
     int cloth_get_state(int f, double* pos, double* vel, int grad) override {                         // get_all_states :320-324 / get_all_states_grad :334-338
@@ -1247,9 +1331,11 @@ template <class R> struct Sim final : ISim {
         const R* Sf = D.S + (size_t)f * frame_scalars();
         if (op == 0) {
             const int e = frame_epoch[f];
-            if (e > 0 && cloth_pairs_by_chunk) {              // sorted frame: per-chunk face culling
+            if (e > 0 && cloth_pairs_by_chunk) {              // sorted frame: per-chunk face culling, faces from the broad phase's per-block lists
                 if ((rc = bind_epoch(e))) return rc;
-                hipLaunchKernelGGL(k_cloth_pairs_chunk<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f, Sf);
+                if (cloth_hash_on && (rc = cloth_hash_build(f))) return rc;
+                if (cloth_hash_on) hipLaunchKernelGGL((k_cloth_pairs_chunk<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f, Sf, fhash);
+                else hipLaunchKernelGGL((k_cloth_pairs_chunk<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f, Sf, fhash);
             } else
                 hipLaunchKernelGGL(k_cloth_pairs<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f, Sf, e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr);
         } else if (op == 1) {
@@ -1383,9 +1469,11 @@ template <class R> struct Sim final : ISim {
                 else hipLaunchKernelGGL((k_p2g<R, false, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
             }
             prof_end();
-            if (!is_recompute && cfg.rigid_velocity_control) {                    // :329-331
-                for (int i = 0; i < D.P; ++i)
-                    if ((rc = prim_fk(i, f))) return rc;
+            if (!is_recompute && cfg.rigid_velocity_control && D.P > 0) {         // :329-331, every primitive in one launch
+                REQUIRE(f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");
+                prof_begin(K_FK);
+                hipLaunchKernelGGL(k_prim_fk<double>, dim3(1), dim3(64), 0, stream, D.prim_state, f, D.dt64, D.P, (size_t)cfg.max_frames * 13);
+                prof_end();
             }
         }
         prof_begin(K_GRID_OP);
@@ -1440,6 +1528,7 @@ template <class R> struct Sim final : ISim {
     // exchanges halo planes (after 0: {m,p}; after 1: the contact corrections of v_out).
     int substep_phase(int f, const double* action, int phase) {
         int rc;
+        ++launch_counter;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
         if (phase <= 0) {
@@ -1536,6 +1625,7 @@ template <class R> struct Sim final : ISim {
     }
     int substep_grad_phase(int f, const double* action, const double* ext_f_grad, double* action_grad_out, int phase) {
         int rc;
+        ++launch_counter;
         if ((rc = need_grad())) return rc;
         if (phase <= 0 && !bwd_since_fwd) {                 // first backward substep after a forward pass: a drifted epoch is repaired (or reported) now
             if ((rc = check_drift())) return rc;
@@ -1656,9 +1746,12 @@ template <class R> struct Sim final : ISim {
                     hipLaunchKernelGGL((k_grid_op_grad<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
             }
-            if (cfg.rigid_velocity_control)                                       // :367-369
-                for (int i = D.P - 1; i >= 0; --i)
-                    if ((rc = prim_fk_grad(i, f))) return rc;
+            if (cfg.rigid_velocity_control && D.P > 0) {                          // :367-369 (the primitives do not interact: one launch)
+                prof_begin(K_FK);
+                hipLaunchKernelGGL(k_prim_fk_grad<double>, dim3(D.P), dim3(64), 0, stream, (const double*)D.prim_state, D.prim_grad, f, D.dt64,
+                                   (size_t)cfg.max_frames * 13);
+                prof_end();
+            }
             if (D.nchunks > 0 && can_fuse_prev(f, e, phase, action_grad_out)) {
                 R* Af_prev = adj_ptr(f - 1);
                 REQUIRE(Af_prev, kPoolMessage);
@@ -1739,6 +1832,191 @@ template <class R> struct Sim final : ISim {
         const int total = np * D.n * D.n;
         hipLaunchKernelGGL(k_halo_unpack_add<R>, dim3(nblk(total)), dim3(BLOCK), 0, stream, D, fp, plane0, np, (const Vec4<R>*)dev_in);
         return check_launch();
+    }
+
+    // ---- slab decomposition INSIDE the library: per substep the neighbour-only exchanges of the shared x-planes run on RCCL
+    // (ncclSend / ncclRecv in one group per exchange) on their own stream, ordered against the kernels' stream with events - no host
+    // round trip, no Python between the phases.  parallel.SlabRunner (torch.distributed) remains as the logic oracle of the CPU tests.
+    ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_kernels = nullptr, ev_comm = nullptr;
+    int c_rank = 0, c_world = 1;
+    struct SlabCfg { bool on = false; int left0 = 0, right0 = 0, np = 2, peer_l = -1, peer_r = -1; bool contact_l = false, contact_r = false, self_loop = false; } sc;
+    Vec4<R>* halo_buf = nullptr;        // [send L | send R | recv L | recv R], np * n * n records each
+    size_t halo_records = 0;
+    int comm_stub = getenv("SMAC_COMM_STUB") ? atoi(getenv("SMAC_COMM_STUB")) : 0;   // 1: pack / events / unpack without the RCCL calls (host-enqueue measurements on one GPU)
+    // 0 (default): the RCCL group is enqueued on the kernels' own stream - in order, no event hand-off.  1: on the communication stream behind
+    // two events.  Measured on one GPU (tools/exchange_overhead.py, profiles/r03_h_exchange_overhead.txt): a cross-stream hand-off costs more than
+    // the 2 x 0.5 MB exchange itself, and until interior chunks are launched beside it there is nothing for the second stream to overlap with.
+    int comm_own_stream = getenv("SMAC_COMM_STREAM") ? atoi(getenv("SMAC_COMM_STREAM")) : 0;
+    long long exchanges_done = 0;
+#define NCCL_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) {                                                                            \
+            this->err = std::string(#expr) + " failed: " + Rccl::get().GetErrorString(_r);                 \
+            return SMAC_ERR_HIP;                                                                            \
+        }                                                                                                   \
+    } while (0)
+    int comm_init(const char* id128, int rank, int world) override {
+        REQUIRE(id128 && world >= 1 && rank >= 0 && rank < world, "comm_init: bad rank / world / id");
+        REQUIRE(!comm, "comm_init: this handle already has a communicator");
+        Rccl& L = Rccl::get();
+        if (!L.load()) { err = L.err; return SMAC_ERR_INVALID; }
+        ncclUniqueId id;
+        static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes (rccl.h NCCL_UNIQUE_ID_BYTES)");
+        memcpy(&id, id128, sizeof id);
+        HIP_TRY(hipSetDevice(cfg.device));
+        NCCL_TRY(L.CommInitRank(&comm, world, id, rank));
+        HIP_TRY(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_kernels, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
+        c_rank = rank; c_world = world;
+        return SMAC_OK;
+    }
+    // Geometry of this rank's slab: the first shared plane with the left / right neighbour in THIS rank's grid indexing, `nplanes` planes each;
+    // contact_*: can a contact primitive reach those planes (parallel.contact_sides, agreed with the neighbour); base_lo..base_hi: stencil bases
+    // this rank may hold (own range widened by the drift tolerance).  self_loop (world 1 only): left = right = this rank - what goes out on the
+    // left comes in on the right and vice versa (periodic planes): the RCCL path exercised end to end on ONE GPU.
+    int comm_slab(int left0, int right0, int nplanes, int contact_left, int contact_right, int base_lo, int base_hi, int self_loop) override {
+        REQUIRE(nplanes >= 2 && left0 >= 0 && right0 >= 0 && left0 + nplanes <= D.n && right0 + nplanes <= D.n, "comm_slab: bad plane range");
+        REQUIRE(comm || comm_stub, "comm_slab: no communicator (smac_comm_init)");
+        REQUIRE(!self_loop || c_world == 1, "comm_slab: self_loop is the world-1 test mode");
+        sc.on = true; sc.left0 = left0; sc.right0 = right0; sc.np = nplanes; sc.self_loop = self_loop != 0;
+        sc.peer_l = self_loop ? c_rank : (c_rank > 0 ? c_rank - 1 : -1);
+        sc.peer_r = self_loop ? c_rank : (c_rank < c_world - 1 ? c_rank + 1 : -1);
+        sc.contact_l = contact_left != 0 && sc.peer_l >= 0;
+        sc.contact_r = contact_right != 0 && sc.peer_r >= 0;
+        D.slab_base_lo = base_lo; D.slab_base_hi = base_hi;
+        const size_t rec = (size_t)nplanes * D.n * D.n;
+        if (rec != halo_records) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            hipFree(halo_buf);
+            halo_buf = nullptr;
+            HIP_TRY(hipMalloc((void**)&halo_buf, 4 * rec * sizeof(Vec4<R>)));
+            halo_records = rec;
+        }
+        if (!comm_stream) {                                   // (stub mode without a communicator)
+            HIP_TRY(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_kernels, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
+        }
+        return SMAC_OK;
+    }
+    // SUM the partials of `field` (minus `minus`) on the shared planes with both neighbours
+    int exchange(Vec4<R>* field, const Vec4<R>* minus, bool contact_only) {
+        HaloSides hs;
+        hs.count = 0;
+        int peers[2] = {-1, -1};
+        if (sc.peer_l >= 0 && (sc.contact_l || !contact_only)) { hs.slot[hs.count] = 0; hs.plane0[hs.count] = sc.left0; peers[hs.count++] = sc.peer_l; }
+        if (sc.peer_r >= 0 && (sc.contact_r || !contact_only)) { hs.slot[hs.count] = 1; hs.plane0[hs.count] = sc.right0; peers[hs.count++] = sc.peer_r; }
+        if (hs.count == 0) return SMAC_OK;
+        REQUIRE(grid_epoch > 0, "exchange: no epoch bound");
+        const size_t rec = halo_records;
+        Vec4<R>* send = halo_buf;
+        Vec4<R>* recv = halo_buf + 2 * rec;
+        hipLaunchKernelGGL(k_halo_pack2<R>, dim3(nblk(rec), hs.count), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)field, minus, hs, sc.np, send);   // every side BEFORE any unpack: partials, not totals
+        hipStream_t cs = comm_own_stream ? comm_stream : stream;
+        if (comm_own_stream) {
+            HIP_TRY(hipEventRecord(ev_kernels, stream));
+            HIP_TRY(hipStreamWaitEvent(comm_stream, ev_kernels, 0));
+        }
+        if (!comm_stub) {
+            Rccl& L = Rccl::get();
+            const size_t count = rec * 4;
+            NCCL_TRY(L.GroupStart());
+            for (int s = 0; s < hs.count; ++s) NCCL_TRY(L.Send(send + (size_t)hs.slot[s] * rec, count, nccl_type<R>::v, peers[s], comm, cs));
+            // self loop: sends and receives between one pair match in order - the first message (sent "to the left") is what a left-hand
+            // neighbour's right side would have sent: it arrives in the RIGHT slot, the second in the left one
+            for (int s = 0; s < hs.count; ++s) {
+                const int into = sc.self_loop ? hs.slot[hs.count - 1 - s] : hs.slot[s];
+                NCCL_TRY(L.Recv(recv + (size_t)into * rec, count, nccl_type<R>::v, peers[s], comm, cs));
+            }
+            NCCL_TRY(L.GroupEnd());
+        } else {
+            // stub: each side receives what the other side of THIS rank sent (the self-loop's data movement as a device copy)
+            for (int s = 0; s < hs.count; ++s)
+                HIP_TRY(hipMemcpyAsync(recv + (size_t)hs.slot[hs.count - 1 - s] * rec, send + (size_t)hs.slot[s] * rec, rec * sizeof(Vec4<R>), hipMemcpyDeviceToDevice, cs));
+        }
+        if (comm_own_stream) {
+            HIP_TRY(hipEventRecord(ev_comm, comm_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, ev_comm, 0));
+        }
+        hipLaunchKernelGGL(k_halo_unpack_add2<R>, dim3(nblk(rec), hs.count), dim3(BLOCK), 0, stream, D, field, hs, sc.np, (const Vec4<R>*)recv);
+        ++exchanges_done;
+        return check_launch();
+    }
+    int substeps_slab(int f0, int count) override {
+        REQUIRE(sc.on, "substeps_slab: no slab geometry (smac_comm_slab)");
+        const bool contact = sc.contact_l || sc.contact_r;
+        int rc;
+        for (int f = f0; f < f0 + count; ++f) {
+            if ((rc = substep_phase(f, nullptr, 0))) return rc;
+            if ((rc = exchange(D.vin, nullptr, false))) return rc;                       // {m, p} partials after P2G
+            if ((rc = substep_phase(f, nullptr, 1))) return rc;
+            if (contact && any_contact() && (rc = exchange(D.vout, D.vmix, true))) return rc;   // contact corrections v_out - v_mixed
+            if ((rc = substep_phase(f, nullptr, 2))) return rc;
+        }
+        return SMAC_OK;
+    }
+    int substeps_slab_grad(int f0, int count, const double* ext_f_grad) override {
+        REQUIRE(sc.on, "substeps_slab_grad: no slab geometry (smac_comm_slab)");
+        const bool contact = sc.contact_l || sc.contact_r;
+        int rc;
+        for (int f = f0 + count - 1; f >= f0; --f) {
+            if ((rc = substep_grad_phase(f, nullptr, f == f0 + count - 1 ? ext_f_grad : nullptr, nullptr, 0))) return rc;
+            if ((rc = exchange(D.aout, nullptr, false))) return rc;                      // grid_v_out.grad partials after g2p.grad
+            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 1))) return rc;
+            if (contact && any_contact() && (rc = exchange(D.amix, nullptr, true))) return rc;   // grid_v_mixed.grad partials after the contact adjoint
+            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 2))) return rc;
+        }
+        return SMAC_OK;
+    }
+    // SUM over the ranks of the per-rank partial wrench sums / primitive-state adjoints, in place - once per env step, where the reference
+    // consumes them (rigid_simulator.py:92-93, 203-208): 6 P and 13 P substeps scalars, not grid traffic
+    int comm_allreduce(double* buf, size_t n) {
+        if (comm_stub || c_world == 1 || n == 0) return SMAC_OK;
+        REQUIRE(comm, "no communicator (smac_comm_init)");
+        Rccl& L = Rccl::get();
+        NCCL_TRY(L.AllReduce(buf, buf, n, ncclFloat64, ncclSum, comm, stream));      // on the kernels' stream: ordered with them, nothing to hand over
+        return SMAC_OK;
+    }
+    int comm_allreduce_ext_f(double* total_out, int clear) override {
+        const size_t n = (size_t)D.P * 6;
+        int rc = comm_allreduce(D.ext_f, n);
+        if (rc) return rc;
+        if (total_out && n) HIP_TRY(hipMemcpyAsync(total_out, D.ext_f, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (clear && n) HIP_TRY(hipMemsetAsync(D.ext_f, 0, n * sizeof(double), stream));
+        // the sheet's per-vertex force (soft_cloth primitive_cloth.py:274-278) is a per-rank partial sum too; it stays on the device (read with
+        // smac_cloth_get_ext_f, cleared with smac_cloth_clear_ext_f as in the single-domain loop)
+        if (D.cloth.present && (rc = comm_allreduce(D.cloth.ext_f, (size_t)D.cloth.V * 3))) return rc;
+        if (total_out) HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int comm_allreduce_prim_grad(int f0, int f1) override {
+        REQUIRE(f0 >= 0 && f0 < f1 && f1 <= cfg.max_frames, "comm_allreduce_prim_grad: bad frame range");
+        for (int i = 0; i < D.P; ++i) {
+            int rc = comm_allreduce(pgrad(i) + (size_t)f0 * 13, (size_t)(f1 - f0) * 13);
+            if (rc) return rc;
+        }
+        if (D.cloth.present && D.cloth.pos_grad) {             // the sheet's vertex adjoints of those frames
+            const size_t at = (size_t)f0 * D.cloth.V * 3, n = (size_t)(f1 - f0) * D.cloth.V * 3;
+            int rc;
+            if ((rc = comm_allreduce(D.cloth.pos_grad + at, n)) || (rc = comm_allreduce(D.cloth.vel_grad + at, n))) return rc;
+        }
+        return SMAC_OK;
+    }
+    int comm_destroy() override {
+        if (stream) HIP_TRY(hipStreamSynchronize(stream));
+        if (comm_stream) HIP_TRY(hipStreamSynchronize(comm_stream));
+        if (comm) { Rccl::get().CommDestroy(comm); comm = nullptr; }
+        if (comm_stream) { hipStreamDestroy(comm_stream); comm_stream = nullptr; }
+        if (ev_kernels) { hipEventDestroy(ev_kernels); ev_kernels = nullptr; }
+        if (ev_comm) { hipEventDestroy(ev_comm); ev_comm = nullptr; }
+        hipFree(halo_buf); halo_buf = nullptr; halo_records = 0;
+        sc = SlabCfg();
+        D.slab_base_lo = 1; D.slab_base_hi = 0;
+        return SMAC_OK;
     }
     bool own_stream = true;
     int set_stream(void* s) override {
@@ -1853,7 +2131,7 @@ template <class R> struct Sim final : ISim {
         if (rc) return rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");
         prof_begin(K_FK);
-        hipLaunchKernelGGL(k_prim_fk<double>, dim3(1), dim3(64), 0, stream, pstate(prim), f, D.dt64);
+        hipLaunchKernelGGL(k_prim_fk<double>, dim3(1), dim3(64), 0, stream, pstate(prim), f, D.dt64, 1, (size_t)0);
         prof_end();
         return check_launch();
     }
@@ -1862,7 +2140,7 @@ template <class R> struct Sim final : ISim {
         if (rc) return rc;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "forward_kinematics.grad: frame out of range");
         prof_begin(K_FK);
-        hipLaunchKernelGGL(k_prim_fk_grad<double>, dim3(1), dim3(64), 0, stream, (const double*)pstate(prim), pgrad(prim), f, D.dt64);
+        hipLaunchKernelGGL(k_prim_fk_grad<double>, dim3(1), dim3(64), 0, stream, (const double*)pstate(prim), pgrad(prim), f, D.dt64, (size_t)0);
         prof_end();
         return check_launch();
     }
@@ -1887,34 +2165,24 @@ template <class R> struct Sim final : ISim {
     int prim_set_action(int prim, int s, int n, const double* a6) override {
         int rc = check_prim(prim);
         if (rc) return rc;
-        REQUIRE(a6 && s >= 0 && n >= 1 && (s + 1) * n <= cfg.max_frames, "prim_set_action: frames out of range");
+        REQUIRE(a6 && s >= 0 && n >= 1 && n <= 1024 && (s + 1) * n <= cfg.max_frames, "prim_set_action: frames out of range");
         for (int f = s * n; f < (s + 1) * n; ++f) ck_epoch[f] = -1;
-        HIP_TRY(hipMemcpyAsync(action_buf + ((size_t)prim * cfg.max_frames + s) * 6, a6, 6 * sizeof(double), hipMemcpyHostToDevice, stream));
-        std::vector<double> cur((size_t)n * 13);
-        HIP_TRY(hipMemcpyAsync(cur.data(), pstate(prim) + (size_t)s * n * 13, cur.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (int j = 0; j < n; ++j)
-            for (int k = 0; k < 3; ++k) { cur[(size_t)j * 13 + 7 + k] = a6[3 + k]; cur[(size_t)j * 13 + 10 + k] = a6[k]; }
-        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)s * n * 13, cur.data(), cur.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        return SMAC_OK;
+        Act6 a;
+        for (int c = 0; c < 6; ++c) a.a[c] = a6[c];
+        // on the device, the action in the kernel's argument block: no staging copy, no stream sync per primitive and env step
+        hipLaunchKernelGGL(k_prim_set_action, dim3(1), dim3(n < 64 ? 64 : (n + 63) / 64 * 64), 0, stream, pstate(prim),
+                           action_buf + (size_t)prim * cfg.max_frames * 6, s, n, a);
+        return check_launch();
     }
     int prim_get_action_grad(int prim, int s, int n, double* g6) override {
         int rc = check_prim(prim);
         if (rc) return rc;
         REQUIRE(g6 && s >= 0 && n >= 1 && (s + 1) * n <= cfg.max_frames, "prim_get_action_grad: frames out of range");
-        std::vector<double> g((size_t)n * 13);
-        double acc[6];
-        HIP_TRY(hipMemcpyAsync(g.data(), pgrad(prim) + (size_t)s * n * 13, g.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(acc, action_buf_grad + ((size_t)prim * cfg.max_frames + s) * 6, sizeof acc, hipMemcpyDeviceToHost, stream));
+        double* abg = action_buf_grad + (size_t)prim * cfg.max_frames * 6;
+        hipLaunchKernelGGL(k_prim_action_grad, dim3(1), dim3(64), 0, stream, (const double*)pgrad(prim), abg, s, n);
+        HIP_TRY(hipMemcpyAsync(g6, abg + (size_t)s * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        // set_velocity_from_action_kernel.grad accumulates into action_buffer.grad[s] (:315-319)
-        for (int j = 0; j < n; ++j)
-            for (int k = 0; k < 3; ++k) { acc[3 + k] += g[(size_t)j * 13 + 7 + k]; acc[k] += g[(size_t)j * 13 + 10 + k]; }
-        HIP_TRY(hipMemcpyAsync(action_buf_grad + ((size_t)prim * cfg.max_frames + s) * 6, acc, sizeof acc, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (int c = 0; c < 6; ++c) g6[c] = acc[c];
-        return SMAC_OK;
+        return check_launch();
     }
     int prim_reset(int prim) override {                                       // :271-275
         int rc = check_prim(prim);
@@ -2160,6 +2428,25 @@ int smac_stream_handle(smac_handle h, void** hip_stream) { return FWD(stream_han
 int smac_set_stream(smac_handle h, void* hip_stream) { return FWD(set_stream(hip_stream)); }
 int smac_substep_phase(smac_handle h, int f, int phase) { return FWD(substep_phase_v(f, phase)); }
 int smac_substep_grad_phase(smac_handle h, int f, const double* ext_f_grad, int phase) { return FWD(substep_grad_phase_v(f, ext_f_grad, phase)); }
+int smac_comm_unique_id(char id128[128]) {
+    if (!id128) { g_create_error = "null argument"; return SMAC_ERR_INVALID; }
+    Rccl& L = Rccl::get();
+    if (!L.load()) { g_create_error = L.err; return SMAC_ERR_INVALID; }
+    ncclUniqueId id;
+    ncclResult_t r = L.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId failed: ") + L.GetErrorString(r); return SMAC_ERR_HIP; }
+    memcpy(id128, &id, 128);
+    return SMAC_OK;
+}
+int smac_comm_init(smac_handle h, const char id128[128], int rank, int world) { return FWD(comm_init(id128, rank, world)); }
+int smac_comm_slab(smac_handle h, int left_plane0, int right_plane0, int nplanes, int contact_left, int contact_right, int base_lo, int base_hi, int self_loop) {
+    return FWD(comm_slab(left_plane0, right_plane0, nplanes, contact_left, contact_right, base_lo, base_hi, self_loop));
+}
+int smac_substeps_slab(smac_handle h, int f0, int count) { return FWD(substeps_slab(f0, count)); }
+int smac_substeps_slab_grad(smac_handle h, int f0, int count, const double* ext_f_grad) { return FWD(substeps_slab_grad(f0, count, ext_f_grad)); }
+int smac_comm_allreduce_ext_f(smac_handle h, double* total_out, int clear) { return FWD(comm_allreduce_ext_f(total_out, clear)); }
+int smac_comm_allreduce_prim_grad(smac_handle h, int f_begin, int f_end) { return FWD(comm_allreduce_prim_grad(f_begin, f_end)); }
+int smac_comm_destroy(smac_handle h) { return FWD(comm_destroy()); }
 int smac_halo_pack(smac_handle h, const char* field, int plane0, int nplanes, void* dev_out, int minus_mixed) {
     return FWD(halo_pack(field, plane0, nplanes, dev_out, minus_mixed));
 }

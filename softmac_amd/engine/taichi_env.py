@@ -105,6 +105,19 @@ class TaichiEnv:
 
     def backward(self):                                          # :139-151
         total_steps = self.simulator.cur // self.substeps
+        if self.control_mode == "rigid" and self.rigid_velocity_control and total_steps > 0:
+            # Velocity control: RigidSimulatorVelocityControl.step_grad only READS the primitives' adjoints of an env step's frames
+            # (get_action_grad, rigid_simulator_vel.py:34-44) and hands no ext_f.grad back, so the reverse loop over env steps is one sweep over
+            # all substeps followed by the reads - same numbers, no host round trip per env step, and the library's fused backward step is
+            # not interrupted at every env-step boundary.  (step_grad remains for callers that walk the env steps themselves.)
+            cur = self.simulator.cur
+            self.simulator.run_substeps_grad(0, cur)
+            grads = []
+            for s in range(total_steps):
+                g, _ = self.rigid_simulator.step_grad(s, self.action_list[s])
+                grads.append(g)
+            self.simulator.cur = 0
+            return torch.vstack(grads)
         action_grad = []
         for s in range(total_steps - 1, -1, -1):
             action_grad = [self.step_grad(self.action_list[s])] + action_grad

@@ -245,6 +245,85 @@ class SlabRunner:
         return f
 
 
+def comm_unique_id():
+    """128-byte RCCL id made by the library on the calling rank (ncclGetUniqueId through the C ABI)."""
+    from . import _ffi
+    lib = _ffi.load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.smac_comm_unique_id(buf)
+    if rc != 0:
+        msg = lib.smac_last_error(None)
+        raise _ffi.SmacError(f"smac_comm_unique_id failed ({rc}): {msg.decode() if msg else ''}")
+    return buf.raw
+
+
+def rendezvous_unique_id(rank, group=None):
+    """rank 0 makes the id, every rank of the (CPU, gloo) process group receives it"""
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
+
+
+def agree_contact_sides(sides, rank, world, group=None):
+    """`contact_sides` is evaluated per rank; a boundary's two ranks must take the same decision or one of them posts an exchange the other
+    does not: every rank learns every rank's flags and a boundary uses the OR of its two sides."""
+    allf = [None] * world
+    dist.all_gather_object(allf, (bool(sides[0]), bool(sides[1])), group=group)
+    left = rank > 0 and (allf[rank][0] or allf[rank - 1][1])
+    right = rank < world - 1 and (allf[rank][1] or allf[rank + 1][0])
+    return bool(left), bool(right)
+
+
+class LibSlabRunner:
+    """The slab loop inside the library (smac_substeps_slab[_grad]): RCCL send / recv between neighbours on the library's own communication
+    stream, the phases and the plane pack / unpack enqueued from C++ - the per-substep Python of `SlabRunner` is gone (round 2 measured 62 us of
+    host time per backward substep in it).  Same `run_substeps / run_substeps_grad` surface, plus the primitives' reductions."""
+
+    def __init__(self, sim, rank, world, left_plane0, right_plane0, nplanes=2, has_contact=(True, True), own=None, unique_id=None, self_loop=False,
+                 drift_tol=None):
+        self.sim, self.rank, self.world = sim, rank, world
+        if unique_id is None:
+            unique_id = comm_unique_id()
+        sim._h.call("smac_comm_init", unique_id, int(rank), int(world))
+        cl, cr = (bool(has_contact), bool(has_contact)) if not isinstance(has_contact, (tuple, list)) else (bool(has_contact[0]), bool(has_contact[1]))
+        tol = (nplanes - 2) // 2 if drift_tol is None else int(drift_tol)
+        if own is None:
+            lo, hi = 1, 0                                     # no range check
+        else:
+            lo = int(own[0]) - (tol if (rank > 0 or self_loop) else 10 ** 6)
+            hi = int(own[1]) - 1 + (tol if (rank < world - 1 or self_loop) else 10 ** 6)
+        sim._h.call("smac_comm_slab", int(left_plane0), int(right_plane0), int(nplanes), int(cl), int(cr), int(lo), int(hi), 1 if self_loop else 0)
+
+    def run_substeps(self, f0, count):
+        self.sim._push_contact_flags()
+        self.sim._h.call("smac_substeps_slab", int(f0), int(count))
+
+    def run_substeps_grad(self, f0, count, ext_f_grad=None):
+        from . import _ffi
+        self.sim._push_contact_flags()
+        e = None
+        if ext_f_grad is not None:
+            e = _ffi.as_f64(np.stack([np.asarray(g, dtype=np.float64).reshape(6) for g in ext_f_grad]))
+        self.sim._h.call("smac_substeps_slab_grad", int(f0), int(count), _ffi.dptr(e))
+
+    # the primitives' reductions (PrimitiveReducer's surface)
+    def allreduce_ext_f(self, clear=False):
+        from . import _ffi
+        P = len(self.sim.primitives)
+        out = np.zeros((max(P, 1), 6))
+        self.sim._h.call("smac_comm_allreduce_ext_f", _ffi.dptr(out), 1 if clear else 0)
+        return out[:P]
+
+    def allreduce_state_grad(self, f0, f1):
+        self.sim._h.call("smac_comm_allreduce_prim_grad", int(f0), int(f1))
+
+    def exchanges(self):
+        return int(self.sim.get_param("exchanges"))
+
+    def close(self):
+        self.sim._h.call("smac_comm_destroy")
+
+
 def contact_sides(specs, states, n_grid, left_plane0, right_plane0, nplanes, rank, world, band=5e-3, drift_cells=2.0):
     """(left, right): can a contact primitive put a correction on the x-planes shared with that neighbour?  Conservative: the primitive's
     SDF table box, rotated by its pose, at (a sample of) the frames of `states` ([frame][13] per primitive, or one 13-vector), grown

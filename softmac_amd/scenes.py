@@ -76,15 +76,30 @@ def sim_namespace(**kw):
     return types.SimpleNamespace(**base)
 
 
+def table_spec(t):
+    """SDF table in the layout a primitive spec carries, from either layout in use: the reference's cache dict (`position` = (lower, upper),
+    `dx` a 3-vector: what `engine.primitive.voxelize.mesh_to_sdf` returns and `mesh.py:214-241` pickles) or lower / upper / scalar dx."""
+    if "position" in t:
+        return dict(sdf=np.asarray(t["sdf"]), normal=np.asarray(t["normal"]), lower=np.asarray(t["position"][0], dtype=np.float64),
+                    upper=np.asarray(t["position"][1], dtype=np.float64), dx=float(np.asarray(t["dx"]).reshape(-1)[0]), res=np.asarray(t["res"]))
+    return dict(sdf=np.asarray(t["sdf"]), normal=np.asarray(t["normal"]), lower=np.asarray(t["lower"], dtype=np.float64),
+                upper=np.asarray(t["upper"], dtype=np.float64), dx=float(t["dx"]), res=np.asarray(t["res"]))
+
+
 def s_grip(n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
-           substeps=10, x_offset=0.0):
-    """Returns (cfg namespace, env_dt, state24, primitive specs, primitive state13 at frame 0)."""
+           substeps=10, x_offset=0.0, tables=None):
+    """Returns (cfg namespace, env_dt, state24, primitive specs, primitive state13 at frame 0).
+
+    tables = (palm, finger): the gripper's SDF tables as SURVEY 8(d) asks for them - the palm from the reference's own cache
+    (assets/gripper/6895...c4d5), the finger voxelised from assets/gripper/finger.obj by the library's mesh -> SDF kernel (row f3); bench.py
+    passes them (`gripper_tables`).  None: tables built analytically with the reference voxeliser's sampling rule (the tests' default: no
+    fixture files, no GPU call before the simulator exists; the palm table equals the cache to 2e-16, the finger is a true cylinder instead
+    of finger.obj's 32-sided prism)."""
     center = (0.5 + x_offset, 0.3, 0.5)
     state, lo, side = block_cloud(n_particles, n_grid, center, ppc=8, seed=seed, v_std=0.05, C_std=0.5, F_std=5e-3)
     cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=dt, max_steps=max_steps, precision=precision,
                         device=device)
-    finger = cylinder_sdf()
-    palm = box_sdf()
+    palm, finger = (box_sdf(), cylinder_sdf()) if tables is None else (table_spec(tables[0]), table_spec(tables[1]))
     specs = [dict(palm, friction=0.001, softness=666.0, contact=False),     # demo_grip.py:117 [False, True, True]
              dict(finger, friction=0.001, softness=666.0, contact=True),
              dict(finger, friction=0.001, softness=666.0, contact=True)]
@@ -159,13 +174,26 @@ def balanced_slab_bounds(base_x, world, n_grid, min_width=2):
     return bounds
 
 
+def gripper_tables(fixture_dir, device=0):
+    """(palm, finger) for `s_grip(tables=...)`: the palm table is the reference's cached SDF as shipped in its tree (tests/golden/palm_sdf.npz,
+    made from the pickle by tools/make_fixtures.py); the finger table is computed HERE from finger.obj's vertex / face arrays
+    (tests/golden/grip_scene.npz) by smac_mesh_to_sdf with the reference's sampling box (mesh.py:170-176, 190-233) - the finger's cache blob is
+    one of the three missing from the reference checkout (.MISSING_LARGE_BLOBS)."""
+    import os
+    from .engine.primitive import voxelize
+    palm = np.load(os.path.join(fixture_dir, "palm_sdf.npz"))
+    grip = np.load(os.path.join(fixture_dir, "grip_scene.npz"))
+    finger = voxelize.mesh_to_sdf(grip["finger_vertices"], grip["finger_faces"], device=device)
+    return dict(sdf=palm["sdf"], normal=palm["normal"], lower=palm["lower"], upper=palm["upper"], dx=float(palm["dx"]), res=palm["res"]), finger
+
+
 def s_grip_strong(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
-                  substeps=10, drift_tol=1):
+                  substeps=10, drift_tol=1, tables=None):
     """Strong-scaling form of S-grip (the metric's "1M particles / 128^3 on 1/2/4/8 GPUs"): the SAME scene as `s_grip`
     - one block, one global grid, the shared gripper primitives - cut into `world` x-slabs balanced by particle count.
     Every rank works in global coordinates on its own copy of the block-sparse grid (only its slab's blocks are active).
     Returns (cfg, env_dt, state of the owned particles, specs, s13, (left_plane0, right_plane0, nplanes), owned ids)."""
-    cfg, env_dt, state, specs, s13 = s_grip(n_particles, n_grid, max_steps, precision, device, seed=seed, dt=dt, substeps=substeps)
+    cfg, env_dt, state, specs, s13 = s_grip(n_particles, n_grid, max_steps, precision, device, seed=seed, dt=dt, substeps=substeps, tables=tables)
     base = (state[:, 0] * n_grid - 0.5).astype(np.int64)
     bounds = balanced_slab_bounds(base, world, n_grid, min_width=2 + 2 * drift_tol)
     lo, hi = bounds[rank], bounds[rank + 1]

@@ -25,7 +25,7 @@ class MPMSimulator(_Base):
         s = self.scale = float(scale)
         unit = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("dim", "dtype", "quality", "yield_stress", "n_particles", "dt", "ptype",
                                                                      "material_model", "nu", "max_steps", "n_controllers", "collision_type")})
-        for k in ("n_grid", "precision", "device", "grad_enabled", "sort_interval", "recompute_backward", "adjoint_frames"):
+        for k in ("n_grid", "precision", "device", "grad_enabled", "sort_interval", "recompute_backward", "adjoint_frames", "slab_flags"):
             if getattr(cfg, k, None) is not None:
                 setattr(unit, k, getattr(cfg, k))
         unit.E = cfg.E / (s * s)

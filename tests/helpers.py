@@ -85,9 +85,25 @@ def c_tol(tol_state, n_grid, v, C):
     return max(tol_state, 5e-7 * 4.0 * n_grid * vmax / max(cmax, 1e-300))
 
 
-def clamp_zone(orc, P, nsteps, width=4e-6, neighbours=False):
-    """bool mask over particles: inside (or within rounding of) the reference's SVD-adjoint clamp at some frame < nsteps.
+def gx_tol(tol_grad, n_grid, v, gv, gC, gx_ref):
+    """tolerance for x.grad in float32 mode for a cloud that moves fast compared with its velocity gradient (the adjoint's twin of `c_tol`).
+
+    g2p.grad adds sum_n (dw_n/dx) (v_n . gv' + 4 n_grid v_n^T gC' (x_n - x_p)) to x.grad.  sum_n dw_n/dx = 0, so for grid velocities
+    v_n = V + small the V part cancels analytically; what is left of the float32 products is their rounding: a 27-term sum keeps
+    ~5e-7 (3 sigma, as in c_tol) of its largest term n_grid |V| (|gv'| + 4 |gC'|).  Relative to the field's max."""
+    vmax = float(np.abs(np.asarray(v)).max())
+    seed = float(np.abs(np.asarray(gv)).max()) + 4.0 * float(np.abs(np.asarray(gC)).max())
+    return max(tol_grad, 5e-7 * n_grid * vmax * seed / max(float(np.abs(np.asarray(gx_ref)).max()), 1e-300))
+
+
+def clamp_zone(orc, P, nsteps, margin=3e-6, neighbours=False):
+    """bool mask over particles: inside the reference's SVD-adjoint clamp |s_j^2 - s_i^2| < 1e-6 (mpm_simulator.py:184-192) at some frame < nsteps,
+    or within `margin` of it.  The margin is what the DEVICE's singular values may differ from the oracle's by: a particle the oracle sees just
+    outside the clamp is inside it on the device when its F differs by dF (s^2 differs by 2 dF, a gap by 4 dF) - then one of them multiplies by the
+    constant 1e6 and the other by 1 / gap.  `_compare_rollout` passes 4 x the F difference it has just MEASURED (+ 1e-7 for the float32 rounding of
+    s^2 itself); the default, for callers without a device state at hand, is 4 x the largest F difference measured on the suite's scenes (7e-7).
     neighbours=True: also the mask of the particles whose 3^3 stencil shares a node with such a particle's in such a frame (F32_TOL 'near')."""
+    width = 1e-6 + margin
     N = orc.frames[0][0].shape[0]
     mask = np.zeros(N, dtype=bool)
     near = np.zeros(N, dtype=bool)

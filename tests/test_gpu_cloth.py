@@ -257,7 +257,12 @@ def test_cloth_path_at_full_size():
     sim.get_contact_pair(3)
     ids_flat, _ = sim.get_contact(3)
     sim._h.call("smac_set_param", b"cloth_pairs_flat", C.c_double(0.0))
-    assert (ids_chunk == ids_flat).all() and (ids_chunk >= 0).sum() > N // 100
+    sim._h.call("smac_set_param", b"cloth_hash", C.c_double(0.0))       # round 2's per-chunk search over the whole mesh (no broad phase)
+    sim.get_contact_pair(3)
+    ids_nohash, _ = sim.get_contact(3)
+    sim._h.call("smac_set_param", b"cloth_hash", C.c_double(1.0))
+    assert (ids_chunk == ids_flat).all() and (ids_nohash == ids_flat).all() and (ids_chunk >= 0).sum() > N // 100
+    assert sim.get_param("cloth_hash_entries") > len(F)                 # the broad phase was built (every face sits in several blocks' lists)
     assert sim.check_penetration(3) == int((pen == 1).sum()) and sim.tracing_warnings == 0
     ext = prim.ext_f.to_numpy()
     assert np.isfinite(ext).all() and np.abs(ext).max() > 0
@@ -280,6 +285,68 @@ def test_cloth_path_at_full_size():
         ref = 2.0 * ga - 0.5 * gb
         assert np.abs(gc - ref).max() < 2e-4 * max(np.abs(ref).max(), 1e-30)
     assert np.abs(a[2]).max() > 0 and np.abs(b[3]).max() > 0        # the sheet does receive adjoints
+
+
+def test_c5_slice_16m_particles_256_grid_on_a_fine_sheet():
+    """BASELINE config C5 on ONE GPU: 16,777,216 particles on a 256^3 grid resting on a sheet of 13,824 faces (1.6 GB per
+    frame).  The oracle cannot follow; size-independent properties: the broad phase (per-block face lists) gives the contact faces of the search
+    over the whole mesh bit for bit, also after substeps have moved the particles out of their binning cells and after the sheet has moved; the
+    adjoint is linear in its seeds; no tracing warnings.  Prints what the broad phase buys at this size."""
+    import ctypes as C
+    import time
+    from softmac_amd import scenes
+    from softmac_amd.config import CfgNode
+    from softmac_amd.soft_cloth.engine.mpm_simulator import MPMSimulator
+    from softmac_amd.soft_cloth.engine.primitive import Primitive_Cloth
+    N = 1 << 24
+    cfg, env_dt, scale, state, V, F, prim_cfg = scenes.s_taco(N, 256, max_steps=4, precision="float32", rings=48)
+    assert len(F) == 13824
+    prim = Primitive_Cloth(CfgNode(prim_cfg), max_timesteps=cfg.max_steps, mpm_scale=scale, vertices=V, faces=F)
+    sim = MPMSimulator(cfg, prim, env_dt, scale)
+    prim.initialize()
+    Vv = np.zeros_like(V); Vv[:, 1] = 0.2
+    for f in range(cfg.max_steps):
+        prim.set_all_states(f, V + f * cfg.dt * Vv, Vv, f_end=f + 1)           # the sheet moves up: a new broad phase per frame
+    sim.reset(state)
+    del state
+    sim.get_contact_pair(0)
+    for s in range(2):
+        sim.substep(s)
+        sim.get_contact_pair(s + 1)
+        sim.trace_penetration_after_mpm(s + 1)
+
+    def search(hash_on, reps=3):
+        sim._h.call("smac_set_param", b"cloth_hash", C.c_double(1.0 if hash_on else 0.0))
+        sim.get_contact_pair(2); sim.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sim.get_contact_pair(2)
+        sim.sync()
+        return sim.get_contact(2)[0].copy(), (time.perf_counter() - t0) / reps
+
+    ids_hash, t_hash = search(True)
+    ids_full, t_full = search(False)
+    sim._h.call("smac_set_param", b"cloth_hash", C.c_double(1.0))
+    print(f"\n[C5 slice] contact-face search at 16M particles x 13,824 faces: {1e3 * t_hash:.2f} ms with the broad phase, {1e3 * t_full:.2f} ms per-chunk over "
+          f"the whole mesh; {int((ids_hash >= 0).sum())} particles hold a face; {int(sim.get_param('cloth_hash_entries'))} (face, block) pairs")
+    assert (ids_hash == ids_full).all() and (ids_hash >= 0).sum() > N // 200
+    sim.check_penetration(2)
+    assert sim.tracing_warnings == 0
+    ext = prim.ext_f.to_numpy()
+    assert np.isfinite(ext).all() and np.abs(ext).max() > 0
+    rng = np.random.default_rng(9)
+    s1 = rng.standard_normal((N, 3))
+
+    def grad(seed, k):
+        sim.clear_grads()
+        sim.add_grad(2, gx=k * seed)
+        sim.substep_grad(1)
+        sim.substep_grad(0)
+        return sim.get_grad(0)[0], prim.get_all_states_grad(1)[0]
+    a, b = grad(s1, 1.0), grad(s1, -2.0)
+    for ga, gb in zip(a, b):
+        assert np.abs(gb + 2.0 * ga).max() < 2e-4 * max(np.abs(ga).max(), 1e-30)
+    assert np.abs(a[1]).max() > 0
 
 
 @pytest.mark.parametrize("name", ["taco", "hit", "hit_penalty"])

@@ -130,59 +130,93 @@ def test_fullsize_adjoint_dot_product_and_linearity(ptype, model, tol):
     assert H.rel_err(g3, 2.5 * g + g2) < 1e-11
 
 
-def _rebinning_outputs(precision, si, nsub=20, with_zone=True):
+def _rebinning_outputs(precision, si, nsub=20, branches=True):
     cfg, env_dt, state, specs, pst, sim, prm = _engine(precision, max_steps=nsub + 4, sort_interval=si)
     N = cfg.n_particles
     sim.reset(state)
     sim.run_substeps(0, nsub)
     st = sim.get_state(nsub)
-    # particles that enter the reference's SVD-adjoint clamp at some frame of the window (helpers.F32_TOL "clamp"); the window is 4x the
-    # clamp's own 1e-6, so the zone of ONE rollout covers the other two (their states differ by 1e-6 at most) - 20 batched SVDs of 1M
-    # matrices per rollout are most of this test's time
-    zone = np.zeros(N, dtype=bool)
-    for f in range(nsub if with_zone else 0):
+    # Which side of each discontinuity of the reference's function every particle is on, per frame, from the rollout's own states (the batched
+    # SVDs of 1M matrices per frame are most of this test's time):
+    #   bits 0-5  yield clip :226-229: singular value k (sorted) above 1 + 3e-3 / below 1 - 2e-3 - the clip's adjoint is a step there
+    #   bit  6    inside the SVD-adjoint clamp |s_j^2 - s_i^2| < 1e-6 (mpm_simulator.py:184-192): K = 1e6 multiplies the difference itself
+    #   bits 8-11 collide_mixed's branches per finger (primitive_base.py:152 inside the 5e-3 band, :168 forecast position inside the body)
+    side = np.zeros((nsub, N), dtype=np.uint16) if branches else None
+    base0 = None
+    for f in range(nsub if branches else 0):
         s = sim.get_state(f)
+        if base0 is None:
+            base0 = np.floor(s[:, 0:3] * cfg.n_grid - 0.5).astype(np.int64)
         Ft = (np.eye(3)[None] + cfg.dt * s[:, 15:24].reshape(N, 3, 3)) @ s[:, 6:15].reshape(N, 3, 3)
-        s2 = np.linalg.svd(Ft, compute_uv=False) ** 2
-        zone |= np.minimum(np.abs(s2[:, 0] - s2[:, 1]), np.minimum(np.abs(s2[:, 1] - s2[:, 2]), np.abs(s2[:, 0] - s2[:, 2]))) < 4e-6
+        sv = np.linalg.svd(Ft, compute_uv=False)
+        s2 = sv ** 2
+        gap = np.minimum(np.abs(s2[:, 0] - s2[:, 1]), np.minimum(np.abs(s2[:, 1] - s2[:, 2]), np.abs(s2[:, 0] - s2[:, 2])))
+        b = np.zeros(N, dtype=np.uint16)
+        for k in range(3):
+            b |= ((sv[:, k] - 1.0 > 3e-3).astype(np.uint16) << (2 * k)) | ((sv[:, k] - 1.0 < -2e-3).astype(np.uint16) << (2 * k + 1))
+        b |= (gap < 1e-6).astype(np.uint16) << 6
+        j = 0
+        for i, sp in enumerate(specs):
+            if not sp["contact"]:
+                continue
+            c = pst[f][i][:3]
+            xx, xf = s[:, 0:3], s[:, 0:3] + cfg.dt * s[:, 3:6]                  # x and the forecast position x + v dt (:166); finger = y-axis cylinder
+            d0 = np.maximum(np.hypot(xx[:, 0] - c[0], xx[:, 2] - c[2]) - 0.05, np.abs(xx[:, 1] - c[1]) - 0.1)
+            d1 = np.maximum(np.hypot(xf[:, 0] - c[0], xf[:, 2] - c[2]) - 0.05, np.abs(xf[:, 1] - c[1]) - 0.1)
+            b |= ((d0 < 5e-3).astype(np.uint16) << (8 + 2 * j)) | ((d1 < 0).astype(np.uint16) << (9 + 2 * j))
+            j += 1
+        side[f] = b
     rng = np.random.default_rng(3)
     sim.clear_grads()
     sim.add_grad(nsub, gx=rng.standard_normal((N, 3)), gv=rng.standard_normal((N, 3)))
     sim.run_substeps_grad(0, nsub)
     gx, gv, gF, gC = sim.get_grad_full(0)
     ext = np.array([m.ext_f.to_numpy() for m in prm])
-    return st, np.hstack([gx, gv]), gF, ext, zone
+    return st, np.hstack([gx, gv]), gF, ext, dict(side=side, base=base0, n_grid=cfg.n_grid)
 
 
 @pytest.mark.parametrize("precision", ["float64", "float32"])
 def test_fullsize_rebinning_invariance(precision):
     """A 20-substep S-grip rollout and its backward pass must not depend on how often the particles are re-binned
     (sort_interval 1 / 16 / never): only the summation order changes.  Max-norm PER PARTICLE (r1's relative L2 hid a 6.7 %
-    outlier in one particle's F adjoint).  Its cause, found with tools/prec_probe.py: particles whose F_tmp has two singular
-    values within the reference's backward_svd clamp (|s_j^2 - s_i^2| < 1e-6, mpm_simulator.py:184-192), where K = 1e6
-    multiplies the difference itself - a 3e-10 change of F moves the reference's own f64 gradient of such a particle by up to
-    1e-4 per substep.  f64 rollouts agree to 1e-8 for every particle (deterministic check of the re-ordering code); in f32
-    the clamp-zone particles (~0.1 % per frame) are bounded separately, all others in max-norm."""
-    outs = [_rebinning_outputs(precision, si, with_zone=(si == 1)) for si in (1, 16, 1000)]
+    outlier in one particle's F adjoint).  f64 rollouts agree to 1e-8 for every particle (a deterministic check of the re-ordering code).
+    In f32 two rollouts are a rounding apart in state, and the reference's function is DISCONTINUOUS in places: the SVD-adjoint clamp
+    (K = 1e6 times the singular-value difference itself inside |s_j^2 - s_i^2| < 1e-6), the yield clip of sigma (its adjoint switches between
+    ma_ii and 0; plasticity PUTS particles on that boundary every substep) and the contact branches.  Round 2 counted the particles over the
+    bound and compared the count with a number picked afterwards.  Here every particle over the bound has to be EXPLAINED: the two rollouts'
+    own states, frame by frame, must put some particle within its stencil reach on DIFFERENT sides of one of those discontinuities (or inside
+    the clamp) - and such neighbourhoods must remain a small part of the cloud, so that the explanation is not "everywhere"."""
+    f32 = precision == "float32"
+    outs = [_rebinning_outputs(precision, si, branches=f32) for si in (1, 16, 1000)]
     N = outs[0][0].shape[0]
     per = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).reshape(N, -1).max(1) / np.abs(np.asarray(b)).max()
-    # f32: two 20-substep rollouts that differ only in summation order - a 1e-7 perturbation per substep, carried through
-    # plastic yield and contact - agree to 1e-5 on every particle's state; adjoints to 1e-3 outside the clamp zone
-    ts, tg, tz = (1e-9, 1e-8, 1e-8) if precision == "float64" else (1e-5, 1e-3, 1e-1)
-    zone = outs[0][4] | outs[1][4] | outs[2][4]
-    assert zone.mean() < 0.05
+    # f32: two 20-substep rollouts that differ only in summation order agree to 1e-5 on every particle's state; adjoints to 1e-3 away from
+    # the flipped branches, 1e-1 next to them (a flipped branch changes that particle's adjoint by O(1) of ITS size)
+    ts, tg, tz = (1e-9, 1e-8, 1e-8) if not f32 else (1e-5, 1e-3, 1e-1)
+    info = outs[0][4]
     for o in outs[1:]:
         es, eg, ef = per(o[0], outs[0][0]), per(o[1], outs[0][1]), per(o[2], outs[0][2])
-        # f32: the reference's function also has KINKS - the yield clip of sigma (:226-229, its adjoint switches between ma_ii and
-        # 0), the contact branches (primitive_base.py:152, 161, 168).  Two rollouts 1e-7 apart put a handful of the 2e7
-        # particle-substeps on different sides of one (expected count N * frames * density * 1e-7 ~ 20); they are counted, not hidden.
-        # The count is a draw, not a constant: 9, 32, 35, 35, 37, 41, 54, 72 over eight builds of round 2 that differ only in rounding (particles just
-        # outside the clamp window, where 1 / (s_j^2 - s_i^2) is still 1e4 ... 2e5, are most of them).  Bound: 1.2e-4 of the particles.
-        kinks = int(((eg > tg) | (ef > tg))[~zone].sum())
-        print(f"[{precision}] state {es.max():.1e}  gx,gv {eg.max():.1e}  gF outside {ef[~zone].max():.1e} inside {ef[zone].max() if zone.any() else 0:.1e}"
-              f"  zone {int(zone.sum())}  kink particles {kinks}")
         assert es.max() < ts
-        assert kinks <= (0 if precision == "float64" else 128)
+        over = (eg > tg) | (ef > tg)
+        if not f32:
+            assert not over.any()
+            print(f"[float64] state {es.max():.1e}  gx,gv {eg.max():.1e}  gF {ef.max():.1e}")
+            continue
+        a, b = info["side"], o[4]["side"]
+        flipped = ((a != b) | (((a | b) >> 6) & 1).astype(bool)).any(axis=0)       # a branch taken differently in some frame, or the clamp active
+        n = info["n_grid"]
+        occ = np.zeros((n, n, n), dtype=bool)
+        c = np.clip(info["base"][flipped], 0, n - 1)
+        occ[c[:, 0], c[:, 1], c[:, 2]] = True
+        import scipy.ndimage
+        occ = scipy.ndimage.binary_dilation(occ, structure=np.ones((3, 3, 3), dtype=bool), iterations=2)   # shares a grid node: within 2 cells
+        ba = np.clip(info["base"], 0, n - 1)
+        explained = occ[ba[:, 0], ba[:, 1], ba[:, 2]]
+        stray = over & ~explained
+        print(f"[float32] state {es.max():.1e}  gx,gv {eg.max():.1e}  gF {ef.max():.1e};  particles that take a branch differently in the two rollouts "
+              f"(or sit in the clamp) {int(flipped.sum())}, their neighbourhoods {explained.mean():.2%} of the cloud;  over 1e-3: {int(over.sum())}, unexplained {int(stray.sum())}")
+        assert not stray.any(), np.nonzero(stray)[0][:10]
+        assert explained.mean() < 0.05                      # the explanation must not be "everywhere"
         assert eg.max() < tz and ef.max() < tz
         assert H.rel_err(o[3], outs[0][3]) < max(100 * ts, 1e-8)
 

@@ -35,9 +35,11 @@ def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None
     tol = tol or TOL[cfg.precision]
     N = cfg.n_particles
     errs = {}
+    dF = 0.0                                                    # largest absolute difference of F between device and oracle (sizes the clamp zone below)
     for f in (1, nsteps):
         st = sim.get_state(f)
         x, v, C, F = orc.frames[f]
+        dF = max(dF, float(np.abs(st[:, 6:15] - F.reshape(N, 9).numpy()).max()))
         errs[f"x[{f}]"] = H.rel_err(st[:, 0:3], x.numpy())
         errs[f"v[{f}]"] = H.rel_err(st[:, 3:6], v.numpy())
         errs[f"F[{f}]"] = H.rel_err(st[:, 6:15], F.reshape(N, 9).numpy())
@@ -77,7 +79,7 @@ def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None
         for f in range(nsteps - 1, -1, -1):
             got_ag.append(sim.substep_grad(f, None if actions is None else actions[f], ext_f_grad))
         got_ag = got_ag[::-1]
-    zone, near = H.clamp_zone(orc, P, nsteps, neighbours=True)
+    zone, near = H.clamp_zone(orc, P, nsteps, margin=4 * dF + 1e-7, neighbours=True)
     gerrs, nerrs, zerrs = {}, {}, {}
     # adjoint frame 0 (the end of the sweep); the batched leg also reads a frame from the middle of the window - the fused kernel
     # writes every adjoint frame although it hands the rows on in registers

@@ -97,6 +97,14 @@ def build_sim(args, rank, world, precision=None, frames=None):
     return sim, runner, cfg
 
 
+def kernel_sources_sha1():
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("smac_kernels.hpp", "smac_math.hpp", "smac_sort.hpp"):
+        h.update(open(os.path.join(ROOT, "softmac_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
 def algorithmic_bytes(N, G_t, s):
     """per substep, fwd = 48 s N + 20 s G_t ; bwd = 72 s N + 40 s G_t."""
     return dict(fwd=48 * s * N + 20 * s * G_t, bwd=72 * s * N + 40 * s * G_t)
@@ -113,36 +121,70 @@ KERNEL_BYTES = {
 }
 
 
-def cpu_baseline(args):
-    """The plain C++/OpenMP f64 oracle port (oracle/mpm_cpu.cpp: the reference's decomposition - dense grid,
-    one pass per Taichi kernel, atomics) timed on this box's host cores on a bounded sample of the SAME workload."""
-    from softmac_amd import scenes
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import helpers as H
-    from oracle import mpm_cpu
-    cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, "float64", 0, seed=1, tables=gripper_tables(0))
-    P = H.oracle_params(cfg, env_dt)
-    port = mpm_cpu.CpuPort(P, specs)
-    N = args.particles
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_window(port, cfg, state, s13, nsub, N):
+    """nsub forward then nsub backward substeps of the C++ port; returns seconds"""
     x, v = state[:, 0:3].copy(), state[:, 3:6].copy()
     F, C = state[:, 6:15].reshape(N, 3, 3).copy(), state[:, 15:24].reshape(N, 3, 3).copy()
-    nsub = args.cpu_steps
     rng = np.random.default_rng(0)
-    frames = [(x, v, C, F)]
-    psts = []
+    frames, psts = [(x, v, C, F)], []
     t0 = time.perf_counter()
     for f in range(nsub):
-        pst = np.array([a + np.concatenate([f * cfg.dt * a[7:10], np.zeros(10)]) for a in s13])
+        pst = np.array([a + np.concatenate([f * cfg.dt * a[7:10], np.zeros(10)]) for a in s13]) if len(s13) else None
         psts.append(pst)
         nx, nv, nC, nF, _ = port.substep(f, *frames[-1], pst)
         frames.append((nx, nv, nC, nF))
     g = [rng.standard_normal((N, 3)), np.zeros((N, 3)), np.zeros((N, 3, 3)), np.zeros((N, 3, 3))]
     for f in range(nsub - 1, -1, -1):
         g = list(port.substep_grad(f, *frames[f], *g, pst=psts[f])[:4])
-    dt = time.perf_counter() - t0
-    return {"value": nsub / dt, "unit": "substeps/s (fwd+bwd)", "cores": port.threads(), "kind": "port",
-            "sample": f"{nsub} forward + {nsub} backward substeps of the full workload ({N} particles, {args.grid}^3, 3 primitives), "
-                      f"f64 C++/OpenMP restatement of the reference's kernel decomposition (not Taichi), {dt:.1f} s on {port.threads()} threads"}
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(args):
+    """The plain C++/OpenMP f64 oracle port (oracle/mpm_cpu.cpp: the reference's decomposition - dense grid, one pass per Taichi kernel,
+    atomics; NOT Taichi) timed on this box's host cores on bounded samples of the workload (SURVEY 8d "CPU baseline beside it"):
+      value      the full S-grip workload (C3), `cpu_steps` forward + backward substeps, all host threads;
+      c2_window  S-elastic (C2: 262,144 particles, 64^3), the survey's 64 + 64 window (shortened to fit ~12 s), all host threads;
+      single_thread  the same C2 workload on ONE thread, 1 + 1 substeps."""
+    from softmac_amd import scenes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from oracle import mpm_cpu
+    cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, "float64", 0, seed=1, tables=gripper_tables(0))
+    port = mpm_cpu.CpuPort(H.oracle_params(cfg, env_dt), specs)
+    N = args.particles
+    threads = port.threads()
+    nsub = args.cpu_steps
+    dt = _cpu_window(port, cfg, state, s13, nsub, N)
+    out = {"value": nsub / dt, "unit": "substeps/s (fwd+bwd)", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"{nsub} forward + {nsub} backward substeps of the full workload ({N} particles, {args.grid}^3, 3 primitives), "
+                     f"f64 C++/OpenMP restatement of the reference's kernel decomposition (not Taichi), {dt:.1f} s on {threads} threads"}
+    try:
+        c2, env2, st2, sp2, s2 = scenes.s_elastic(1 << 18, 64, 8, "float64", 0, seed=0)
+        port2 = mpm_cpu.CpuPort(H.oracle_params(c2, env2), sp2)
+        t1 = _cpu_window(port2, c2, st2, s2, 1, 1 << 18)                 # one pair to size the window
+        n2 = int(max(2, min(64, 12.0 / max(t1, 1e-3))))
+        t2 = _cpu_window(port2, c2, st2, s2, n2, 1 << 18)
+        out["c2_window"] = {"value": n2 / t2, "unit": "substeps/s (fwd+bwd)", "cores": threads,
+                            "sample": f"S-elastic (C2: 262,144 particles, 64^3, no primitives), {n2} forward + {n2} backward substeps "
+                                      f"(the survey's window is 64 + 64; shortened to fit the bench's time budget), {t2:.1f} s"}
+        port2.set_threads(1)
+        t3 = _cpu_window(port2, c2, st2, s2, 1, 1 << 18)
+        port2.set_threads(threads)
+        out["single_thread"] = {"value": 1.0 / t3, "unit": "substeps/s (fwd+bwd)", "cores": 1,
+                                "sample": f"S-elastic (C2) on ONE thread, 1 forward + 1 backward substep, {t3:.1f} s"}
+    except Exception as e:                                               # noqa: BLE001
+        out["c2_error"] = f"{type(e).__name__}: {e}"[:200]
+    return out
 
 
 def env_loop_record(args, seed_gx):
@@ -408,11 +450,18 @@ def main():
         ab = algorithmic_bytes(sum(c[0] for c in allc), Gsum, sbytes)
         steps_per_s_dev = K / (dev_ms * 1e-3)
         sub_gbs = (ab["fwd"] + ab["bwd"]) * steps_per_s_dev / 1e9 / world            # per GPU (all ranks' bytes / ranks)
-        traffic = None
+        # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py; separate --pmc runs as the guide prescribes): a committed
+        # measurement, so it is only quoted while the kernels it was taken on are the kernels that just ran (hash of the kernel sources)
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                if tj.get("kernel_sources_sha1") == kernel_sources_sha1():
+                    traffic = tj.get(dom)
+                    traffic_note = tj.get("measured", "profiles/traffic_latest.json")
+                else:
+                    traffic_note = "stale: the kernel sources changed since profiles/traffic_latest.json was measured - dropped"
             except Exception:
                 traffic = None
         if world == 1:
@@ -442,11 +491,13 @@ def main():
                        else "forward grid restored from the per-frame checkpoint saved by substep",
                        "resort_interval": args.sort_interval, "resorts_in_window": int(kern.get("sort", (0, 0))[1]),
                        "parallelism": par},
+            "multi_gpu_note": None if world == 1 else ("the in-library RCCL slab loop has run on ONE GPU only (world-1 self exchange, tests/test_gpu_slab_lib.py) "
+                                                         "and the Python SlabRunner under gloo; no N > 1 result existed when this code was committed"),
             "repeats": len(walls), "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
             "spread": (max(walls) - min(walls)) / wall,
             "device_ms_per_step": dev_ms / K,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
             "roofline_substep": {"algorithmic_bytes_fwd_bwd": ab["fwd"] + ab["bwd"], "achieved": sub_gbs,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sub_gbs / PEAK_HBM_GBS},

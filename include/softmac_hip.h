@@ -243,6 +243,17 @@ int smac_substeps_slab_grad(smac_handle h, int f0, int count, const double* ext_
 int smac_comm_allreduce_ext_f(smac_handle h, double* total_out, int clear);
 int smac_comm_allreduce_prim_grad(smac_handle h, int f_begin, int f_end);
 int smac_comm_destroy(smac_handle h);
+/* Particle migration between slabs on the device (SURVEY 8e "Particle migration"; round 2 went through the host with get_state / set_state).
+ * smac_migrate: the particles of frame f whose stencil base (x) left [base_lo, base_hi) go to the neighbour on that side (rows and global ids over
+ * RCCL, neighbour-only); frame f + 1 starts the next segment = kept particles, arrivals from the left, arrivals from the right (the caller goes on
+ * from frame f + 1; smac_set_segment's bookkeeping is done here).  out3 = {live particles now, sent away, received}.  Called at a re-sort /
+ * env-step boundary, never inside a substep.  smac_migrate_grad undoes the most recent one in the backward sweep: the adjoint of frame f + 1 is
+ * added into frame f's, across the slab boundary for the particles that crossed it.  smac_set_ids / smac_get_ids: the global particle ids of the
+ * current segment in its caller order (default 0 .. n_particles - 1); they travel with the particles. */
+int smac_migrate(smac_handle h, int f, int base_lo, int base_hi, int32_t out3[3]);
+int smac_migrate_grad(smac_handle h);
+int smac_set_ids(smac_handle h, const int64_t* ids);
+int smac_get_ids(smac_handle h, int64_t* ids);
 
 #ifdef __cplusplus
 }

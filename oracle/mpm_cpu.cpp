@@ -460,6 +460,7 @@ static std::vector<Prim> to_prims(const mc_params* m, const mc_prim* pr) {
 }
 
 int mc_threads(void) { return omp_get_max_threads(); }
+void mc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }   // bench.py's single-thread figure
 
 // One forward substep (substep :320-337).  Arrays AOS f64: x,v (N,3); C,F (N,3,3).  ext_f (P,6) is ACCUMULATED.
 void mc_substep(const mc_params* m, const mc_prim* pr, const double* pst, int f, const double* x, const double* v, const double* C,

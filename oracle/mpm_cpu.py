@@ -76,6 +76,9 @@ class CpuPort:
     def threads(self):
         return self.lib.mc_threads()
 
+    def set_threads(self, n):
+        self.lib.mc_set_threads(int(n))
+
     def substep(self, f, x, v, Cm, F, pst=None):
         N = len(x)
         self.m.N = N

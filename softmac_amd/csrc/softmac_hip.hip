@@ -12,6 +12,7 @@
 #include "../../include/softmac_hip.h"
 #include "smac_kernels.hpp"
 #include "smac_comm.hpp"
+#include "smac_migrate.hpp"
 #include "smac_cloth_kernels.hpp"
 #include "smac_voxel.hpp"
 #include "smac_loss.hpp"
@@ -119,6 +120,10 @@ struct ISim {
     virtual int comm_allreduce_ext_f(double* total_out, int clear) = 0;
     virtual int comm_allreduce_prim_grad(int f0, int f1) = 0;
     virtual int comm_destroy() = 0;
+    virtual int migrate(int f, int base_lo, int base_hi, int32_t* out3) = 0;
+    virtual int migrate_grad() = 0;
+    virtual int set_ids(const int64_t* ids) = 0;
+    virtual int get_ids(int64_t* ids) = 0;
     virtual int stream_handle(void** s) = 0;
     virtual void hint_backward_next(int f) = 0;
     virtual int set_param(const char* name, double value) = 0;
@@ -234,6 +239,9 @@ template <class R> struct Sim final : ISim {
         hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(tmp_frame2); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
         hipFree(d_io); hipFree(ext_snap); hipFree(cloth_ext_snap);
+        for (auto& m : migs) { hipFree(m.src_slot); hipFree(m.ids_old); }
+        hipFree(d_ids); hipFree(mig_flags); hipFree(mig_pos); hipFree(mig_counts);
+        for (char* b : mig_buf) hipFree(b);
         hipFree(fhash.count); hipFree(fhash.start); hipFree(fhash.list); hipFree(fhash.overflow);
         if (hash_total_host) hipHostFree(hash_total_host);
         hipFree(d_cloth_faces); hipFree(d_cloth_nbr); hipFree(d_cloth_nbr_dir); hipFree(d_cloth_warn); hipFree(d_cloth_ext_scratch);
@@ -1279,7 +1287,7 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMemcpyAsync(D.cloth.vel + (size_t)f * D.cloth.V * 3, vel, b, hipMemcpyHostToDevice, stream));
         }
         HIP_TRY(hipStreamSynchronize(stream));
-        ++config_gen;
+        for (int f = f0; f < f1; ++f) ck_epoch[f] = -1;   // the sheet's frame f enters substep f only
         ++cloth_state_gen;
         return SMAC_OK;
     }
@@ -1347,8 +1355,8 @@ template <class R> struct Sim final : ISim {
             if ((rc = frame_inverse(f, &ic)) || (rc = frame_inverse(f - 1, &ip))) return rc;
             hipLaunchKernelGGL(k_cloth_trace<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D, f, op == 3 ? 1 : 0, Sf, Sf - frame_scalars(), ic, ip, d_cloth_warn);
         } else REQUIRE(false, "cloth_contact: unknown op");
-        ++config_gen;                                   // the contact faces are inputs of the forward grid
-        return check_launch();
+        ck_epoch[f] = -1;                               // the contact faces / penetration flags of frame f are inputs of THAT frame's forward grid only
+        return check_launch();                          // (a global invalidation made every slab-phase backward pass fail: its checkpoints are mandatory)
     }
     int cloth_get_contact(int f, int32_t* ids, int8_t* pen) override {
         int rc;
@@ -1369,7 +1377,7 @@ template <class R> struct Sim final : ISim {
         }
         if (pen) HIP_TRY(hipMemcpyAsync(D.cloth.penetration + at, pen, (size_t)D.N, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        ++config_gen;
+        ck_epoch[f] = -1;
         return SMAC_OK;
     }
     int cloth_check_penetration(int f, int32_t* total, int32_t* warnings) override {           // check_penetration :555-561
@@ -2018,6 +2026,189 @@ template <class R> struct Sim final : ISim {
         D.slab_base_lo = 1; D.slab_base_hi = 0;
         return SMAC_OK;
     }
+
+    // ---- particle migration between slabs, on the device (smac_migrate.hpp) ------------------------------------------------------
+    struct MigRec { int frame, epoch, n_old, nk, nl_out, nr_out, nl_in, nr_in; int* src_slot; long long* ids_old; };
+    std::vector<MigRec> migs;
+    long long* d_ids = nullptr;         // global particle ids of the current segment, in its caller (identity) order
+    int *mig_flags = nullptr, *mig_pos = nullptr, *mig_counts = nullptr;     // 3 x Npad flags, 3 x Npad positions, counts exchanged with the neighbours
+    char* mig_buf[4] = {nullptr, nullptr, nullptr, nullptr};                 // send L, send R, recv L, recv R
+    int mig_cap[4] = {0, 0, 0, 0};
+    size_t mig_bytes(int cap) const { return (size_t)cap * (sizeof(long long) + NCOMP * sizeof(R)); }
+    int mig_reserve(int which, int cap) {
+        if (cap <= mig_cap[which]) return SMAC_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        hipFree(mig_buf[which]);
+        mig_buf[which] = nullptr;
+        cap = cap + cap / 4 + 1024;
+        HIP_TRY(hipMalloc((void**)&mig_buf[which], mig_bytes(cap)));
+        mig_cap[which] = cap;
+        return SMAC_OK;
+    }
+    int ensure_ids() {
+        if (d_ids) return SMAC_OK;
+        HIP_TRY(hipMalloc((void**)&d_ids, (size_t)D.Npad * sizeof(long long)));
+        std::vector<long long> h(D.Npad);
+        for (int i = 0; i < D.Npad; ++i) h[i] = i;
+        HIP_TRY(hipMemcpy(d_ids, h.data(), h.size() * sizeof(long long), hipMemcpyHostToDevice));
+        return SMAC_OK;
+    }
+    int set_ids(const int64_t* ids) override {
+        REQUIRE(ids, "null argument");
+        int rc = ensure_ids();
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)D.N * sizeof(long long), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    int get_ids(int64_t* ids) override {
+        REQUIRE(ids, "null argument");
+        int rc = ensure_ids();
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ids, d_ids, (size_t)D.N * sizeof(long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    // pairwise exchange with the two neighbours in one RCCL group: `bytes_out[s]` from send[s], `bytes_in[s]` into recv[s] (s = 0 left, 1 right);
+    // self loop: what leaves on the left arrives on the right and vice versa (the stub moves it with device copies)
+    int neighbour_exchange(const void* const send[2], const size_t bytes_out[2], void* const recv[2], const size_t bytes_in[2]) {
+        const int peers[2] = {sc.peer_l, sc.peer_r};
+        if (comm_stub) {
+            for (int s = 0; s < 2; ++s)
+                if (peers[s] >= 0 && bytes_out[s]) HIP_TRY(hipMemcpyAsync(recv[1 - s], send[s], bytes_out[s], hipMemcpyDeviceToDevice, stream));
+            return SMAC_OK;
+        }
+        REQUIRE(comm, "no communicator (smac_comm_init)");
+        Rccl& L = Rccl::get();
+        NCCL_TRY(L.GroupStart());
+        for (int s = 0; s < 2; ++s)
+            if (peers[s] >= 0 && bytes_out[s]) NCCL_TRY(L.Send(send[s], bytes_out[s], ncclUint8, peers[s], comm, stream));
+        for (int s = 0; s < 2; ++s) {
+            const int into = sc.self_loop ? 1 - s : s;
+            if (peers[s] >= 0 && bytes_in[into]) NCCL_TRY(L.Recv(recv[into], bytes_in[into], ncclUint8, peers[s], comm, stream));
+        }
+        NCCL_TRY(L.GroupEnd());
+        return SMAC_OK;
+    }
+    // Hand the particles of frame f whose stencil base left [base_lo, base_hi) to the neighbour on that side; frame f + 1 starts the next segment
+    // (kept particles, then the arrivals from the left, then from the right).  out3: {live particles now, sent away, received}.
+    int migrate(int f, int base_lo, int base_hi, int32_t* out3) override {
+        int rc;
+        REQUIRE(sc.on, "migrate: no slab geometry (smac_comm_slab)");
+        REQUIRE(f >= 0 && f + 1 < cfg.max_frames && frame_epoch[f] >= 0, "migrate: frame f holds no state or f + 1 exceeds max_frames");
+        REQUIRE(!rolling(), "migrate: not with rolling adjoint storage");
+        if ((rc = check_drift()) || (rc = ensure_ids())) return rc;
+        if (!mig_flags) {
+            HIP_TRY(hipMalloc((void**)&mig_flags, 3 * (size_t)D.Npad * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&mig_pos, 3 * (size_t)D.Npad * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&mig_counts, 8 * sizeof(int)));
+        }
+        const int e = frame_epoch[f], N = D.N, Npad = D.Npad;
+        const R* Sf = D.S + (size_t)f * frame_scalars();
+        R* Sn = D.S + (size_t)(f + 1) * frame_scalars();
+        int *keep = mig_flags, *left = mig_flags + Npad, *right = mig_flags + 2 * Npad;
+        int *kpos = mig_pos, *lpos = mig_pos + Npad, *rpos = mig_pos + 2 * Npad;
+        hipLaunchKernelGGL(k_mig_classify<R>, dim3(nblk(N)), dim3(BLOCK), 0, stream, N, Npad, D.n, Sf, base_lo, base_hi, sc.peer_l >= 0 ? 1 : 0, sc.peer_r >= 0 ? 1 : 0,
+                           keep, left, right);
+        if ((rc = scan(keep, kpos, N)) || (rc = scan(left, lpos, N)) || (rc = scan(right, rpos, N))) return rc;
+        int last[6];                                                        // last flag + last position of each class -> the three totals
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(hipMemcpyAsync(&last[2 * k], mig_flags + (size_t)k * Npad + (N - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&last[2 * k + 1], mig_pos + (size_t)k * Npad + (N - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        const int nk = last[0] + last[1], nl = last[2] + last[3], nr = last[4] + last[5];
+        // counts to / from the neighbours
+        int out_counts[2] = {nl, nr}, in_counts[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(mig_counts, out_counts, 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(mig_counts + 2, 0, 2 * sizeof(int), stream));
+        {
+            const void* snd[2] = {mig_counts, mig_counts + 1};
+            void* rcv[2] = {mig_counts + 2, mig_counts + 3};
+            const size_t four[2] = {sizeof(int), sizeof(int)};
+            if ((rc = neighbour_exchange(snd, four, rcv, four))) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(in_counts, mig_counts + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const int n_new = nk + in_counts[0] + in_counts[1];
+        REQUIRE(n_new >= 1, "migrate: this slab lost all its particles");
+        REQUIRE(n_new <= cfg.n_particles, "migrate: more particles arrive than the handle's capacity (n_particles) holds");
+        if ((rc = mig_reserve(0, nl)) || (rc = mig_reserve(1, nr)) || (rc = mig_reserve(2, in_counts[0])) || (rc = mig_reserve(3, in_counts[1]))) return rc;
+        MigRec rec = {f, e, N, nk, nl, nr, in_counts[0], in_counts[1], nullptr, nullptr};
+        HIP_TRY(hipMalloc((void**)&rec.src_slot, (size_t)(N > 0 ? N : 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&rec.ids_old, (size_t)Npad * sizeof(long long)));
+        HIP_TRY(hipMemcpyAsync(rec.ids_old, d_ids, (size_t)Npad * sizeof(long long), hipMemcpyDeviceToDevice, stream));
+        long long* ids_new = (long long*)tmp_frame;                      // (scratch: Npad x 8 bytes fit a frame of 24 x Npad scalars)
+        hipLaunchKernelGGL(k_mig_pack<R>, dim3(nblk(N)), dim3(BLOCK), 0, stream, N, Npad, Sf, Sn, (const long long*)rec.ids_old, ids_new,
+                           e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, (const int*)keep, (const int*)kpos, (const int*)lpos, (const int*)rpos,
+                           (const int*)left, mig_buf[0], mig_buf[1], nl > 0 ? nl : 1, nr > 0 ? nr : 1, nk, nl, rec.src_slot);   // (buffer layout [ids: count x 8][rows: 24 x count])
+        {
+            const void* snd[2] = {mig_buf[0], mig_buf[1]};
+            void* rcv[2] = {mig_buf[2], mig_buf[3]};
+            const size_t bo[2] = {mig_bytes(nl), mig_bytes(nr)}, bi[2] = {mig_bytes(in_counts[0]), mig_bytes(in_counts[1])};
+            if ((rc = neighbour_exchange(snd, bo, rcv, bi))) return rc;
+        }
+        if (in_counts[0]) hipLaunchKernelGGL(k_mig_unpack<R>, dim3(nblk(in_counts[0])), dim3(BLOCK), 0, stream, in_counts[0], in_counts[0], Npad, (const char*)mig_buf[2], Sn, ids_new, nk);
+        if (in_counts[1]) hipLaunchKernelGGL(k_mig_unpack<R>, dim3(nblk(in_counts[1])), dim3(BLOCK), 0, stream, in_counts[1], in_counts[1], Npad, (const char*)mig_buf[3], Sn, ids_new,
+                                             nk + in_counts[0]);
+        hipLaunchKernelGGL(k_mig_pad<R>, dim3(nblk(Npad - n_new + 1)), dim3(BLOCK), 0, stream, n_new, Npad, Sn);
+        HIP_TRY(hipMemcpyAsync(d_ids, ids_new, (size_t)n_new * sizeof(long long), hipMemcpyDeviceToDevice, stream));
+        migs.push_back(rec);
+        D.N = n_new;
+        D.frame_shift += 1;
+        frame_epoch[f + 1] = 0;                                            // the new segment's caller order; binned at its first substep
+        ck_epoch[f + 1] = -1;
+        fwd_head = f + 1;
+        if (out3) { out3[0] = n_new; out3[1] = nl + nr; out3[2] = in_counts[0] + in_counts[1]; }
+        return check_launch();
+    }
+    // Backward of the most recent migrate: the adjoint of the later segment's first frame goes back to the frame it was copied from - across the
+    // slab boundary for the particles that crossed it - and is ADDED there (frame f may carry seeds of its own).
+    int migrate_grad() override {
+        int rc;
+        REQUIRE(!migs.empty(), "migrate_grad: no migration on record");
+        if ((rc = need_grad())) return rc;
+        MigRec rec = migs.back();
+        const int f = rec.frame, Npad = D.Npad;
+        // adjoint of frame f + 1 in the segment's identity order
+        const R* G = nullptr;
+        if (adj_epoch[f + 1] < 0 && (rc = adj_make_zero(f + 1))) return rc;
+        if ((rc = adjoint_in_order(f + 1, 0, &G))) return rc;
+        // frame f's adjoint in the order of frame f's state (epoch rec.epoch); frame f belongs to the EARLIER segment
+        D.N = rec.n_old;
+        D.frame_shift -= 1;
+        if (adj_epoch[f] < 0) {
+            if ((rc = adj_make_zero(f))) return rc;
+        } else if (adj_epoch[f] != rec.epoch) {
+            const R* tmp = nullptr;
+            if (!tmp_frame2) HIP_TRY(hipMalloc((void**)&tmp_frame2, frame_scalars() * sizeof(R)));
+            if ((rc = adjoint_in_order(f, rec.epoch, &tmp, G == tmp_frame ? tmp_frame2 : tmp_frame))) return rc;
+            HIP_TRY(hipMemcpyAsync(adj_ptr(f), tmp, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        }
+        adj_epoch[f] = rec.epoch;
+        adj_stale[f] = 0;
+        R* Af = adj_ptr(f);
+        if (rec.nk) hipLaunchKernelGGL(k_mig_grad_keep<R>, dim3(nblk(rec.nk)), dim3(BLOCK), 0, stream, rec.nk, Npad, G, Af, (const int*)rec.src_slot);
+        // the arrivals' adjoint rows go back to their senders; the rows of the particles this rank sent away come back
+        if ((rc = mig_reserve(0, rec.nl_in)) || (rc = mig_reserve(1, rec.nr_in)) || (rc = mig_reserve(2, rec.nl_out)) || (rc = mig_reserve(3, rec.nr_out))) return rc;
+        if (rec.nl_in) hipLaunchKernelGGL(k_mig_grad_pack<R>, dim3(nblk(rec.nl_in)), dim3(BLOCK), 0, stream, rec.nl_in, rec.nl_in, Npad, G, rec.nk, mig_buf[0]);
+        if (rec.nr_in) hipLaunchKernelGGL(k_mig_grad_pack<R>, dim3(nblk(rec.nr_in)), dim3(BLOCK), 0, stream, rec.nr_in, rec.nr_in, Npad, G, rec.nk + rec.nl_in, mig_buf[1]);
+        {
+            const void* snd[2] = {mig_buf[0], mig_buf[1]};
+            void* rcv[2] = {mig_buf[2], mig_buf[3]};
+            const size_t bo[2] = {mig_bytes(rec.nl_in), mig_bytes(rec.nr_in)}, bi[2] = {mig_bytes(rec.nl_out), mig_bytes(rec.nr_out)};
+            if ((rc = neighbour_exchange(snd, bo, rcv, bi))) return rc;
+        }
+        if (rec.nl_out) hipLaunchKernelGGL(k_mig_grad_unpack<R>, dim3(nblk(rec.nl_out)), dim3(BLOCK), 0, stream, rec.nl_out, rec.nl_out, Npad, (const char*)mig_buf[2], Af,
+                                           (const int*)(rec.src_slot + rec.nk));
+        if (rec.nr_out) hipLaunchKernelGGL(k_mig_grad_unpack<R>, dim3(nblk(rec.nr_out)), dim3(BLOCK), 0, stream, rec.nr_out, rec.nr_out, Npad, (const char*)mig_buf[3], Af,
+                                           (const int*)(rec.src_slot + rec.nk + rec.nl_out));
+        HIP_TRY(hipMemcpyAsync(d_ids, rec.ids_old, (size_t)Npad * sizeof(long long), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        hipFree(rec.src_slot); hipFree(rec.ids_old);
+        migs.pop_back();
+        return check_launch();
+    }
     bool own_stream = true;
     int set_stream(void* s) override {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -2447,6 +2638,10 @@ int smac_substeps_slab_grad(smac_handle h, int f0, int count, const double* ext_
 int smac_comm_allreduce_ext_f(smac_handle h, double* total_out, int clear) { return FWD(comm_allreduce_ext_f(total_out, clear)); }
 int smac_comm_allreduce_prim_grad(smac_handle h, int f_begin, int f_end) { return FWD(comm_allreduce_prim_grad(f_begin, f_end)); }
 int smac_comm_destroy(smac_handle h) { return FWD(comm_destroy()); }
+int smac_migrate(smac_handle h, int f, int base_lo, int base_hi, int32_t out3[3]) { return FWD(migrate(f, base_lo, base_hi, out3)); }
+int smac_migrate_grad(smac_handle h) { return FWD(migrate_grad()); }
+int smac_set_ids(smac_handle h, const int64_t* ids) { return FWD(set_ids(ids)); }
+int smac_get_ids(smac_handle h, int64_t* ids) { return FWD(get_ids(ids)); }
 int smac_halo_pack(smac_handle h, const char* field, int plane0, int nplanes, void* dev_out, int minus_mixed) {
     return FWD(halo_pack(field, plane0, nplanes, dev_out, minus_mixed));
 }

@@ -293,6 +293,7 @@ class LibSlabRunner:
             lo = int(own[0]) - (tol if (rank > 0 or self_loop) else 10 ** 6)
             hi = int(own[1]) - 1 + (tol if (rank < world - 1 or self_loop) else 10 ** 6)
         sim._h.call("smac_comm_slab", int(left_plane0), int(right_plane0), int(nplanes), int(cl), int(cr), int(lo), int(hi), 1 if self_loop else 0)
+        self._counts = []
 
     def run_substeps(self, f0, count):
         self.sim._push_contact_flags()
@@ -319,6 +320,30 @@ class LibSlabRunner:
 
     def exchanges(self):
         return int(self.sim.get_param("exchanges"))
+
+    # ---- migration on the device (smac_migrate / smac_migrate_grad); the tape of migrations lives in the library
+    def set_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        assert ids.shape == (self.sim.n_particles,)
+        self.sim._h.call("smac_set_ids", ids.ctypes.data_as(C.POINTER(C.c_int64)))
+
+    def ids(self):
+        out = np.zeros(self.sim.n_particles, dtype=np.int64)
+        self.sim._h.call("smac_get_ids", out.ctypes.data_as(C.POINTER(C.c_int64)))
+        return out
+
+    def migrate(self, f, own):
+        """particles of frame f whose stencil base left own = [lo, hi) change hands; the next segment starts at frame f + 1 (returned)"""
+        out = np.zeros(3, dtype=np.int32)
+        self._counts.append(self.sim.n_particles)
+        self.sim._h.call("smac_migrate", int(f), int(own[0]), int(own[1]), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        self.sim.n_particles = int(out[0])
+        self.moved = getattr(self, "moved", 0) + int(out[1])
+        return f + 1
+
+    def migrate_grad(self):
+        self.sim._h.call("smac_migrate_grad")
+        self.sim.n_particles = self._counts.pop()
 
     def close(self):
         self.sim._h.call("smac_comm_destroy")

@@ -19,10 +19,14 @@ class KinematicCloth:
         self.motion_grad = motion_grad
         self.x = self.v = None
         self.ext_f_log = []
+        self.dL_dx = np.zeros_like(self.x_init)            # adjoint of the sheet's state carried backwards (cloth_simulator.py:83-86, 127-128 of taichi_env.py)
+        self.dL_dv = np.zeros_like(self.x_init)
 
     def initialize(self):                                  # :129-135
         self.x, self.v = self.x_init.copy(), self.v_init.copy()
         self.ext_f_log = []
+        self.dL_dx[:] = 0.0
+        self.dL_dv[:] = 0.0
         self.primitive.set_all_states(0, self.x, self.v, f_end=self.substeps + 1)
 
     def step(self, s, action=None):                        # :60-81

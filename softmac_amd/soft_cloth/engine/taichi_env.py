@@ -24,6 +24,14 @@ class TaichiEnv:
         self.cloth_simulator = KinematicCloth(self.primitive, self.substeps, self.env_dt, motion=motion, motion_grad=motion_grad)
         self.control_mode = getattr(cfg, "control_mode", "mpm")
         self.action_list = []
+        self._is_copy = False
+
+    def set_copy(self, is_copy: bool):                     # :40-41
+        self._is_copy = is_copy
+
+    def set_control_mode(self, mode):                      # :133-135
+        assert mode in ("mpm", "cloth")
+        self.control_mode = mode
 
     def initialize(self):                                  # :46-63
         self.primitive.initialize()
@@ -35,7 +43,7 @@ class TaichiEnv:
 
     def step(self, action=None):                           # :86-106
         sim = self.simulator
-        start = sim.cur
+        start = 0 if self._is_copy else sim.cur
         sim.cur = start + self.substeps
         mpm_action = action if self.control_mode == "mpm" else None
         cloth_action = action if self.control_mode == "cloth" else None
@@ -48,6 +56,9 @@ class TaichiEnv:
         sim.backup_contact_pair(sim.cur)
         sim.get_contact_pair(sim.cur)
         sim.trace_penetration_after_cloth(sim.cur)
+        if self._is_copy:                                  # :92-95 copy to the first frame for rendering (the sheet's frames and the contact columns go along: smac_copy_frame)
+            sim.copyframe(sim.cur, 0)
+            sim.cur = 0
 
     def step_grad(self, action=None):                      # :108-127
         sim = self.simulator
@@ -71,6 +82,9 @@ class TaichiEnv:
         grads = []
         for s in range(total - 1, -1, -1):
             grads = [self.step_grad(self.action_list[s])] + grads
+        gx, gv = self.cloth_simulator.get_ext_state_grad(0)     # :126-128 what reaches the sheet's initial state through the first env step's frames
+        self.cloth_simulator.dL_dx += gx
+        self.cloth_simulator.dL_dv += gv
         return grads
 
     @property

@@ -178,3 +178,98 @@ class OracleSlabEngine:
             gr = torch.autograd.grad(L, leaves)
             for i in range(4):
                 a0[i] = a0[i] + gr[i]
+
+
+class ClothOracleSlabEngine(OracleSlabEngine):
+    """The soft <-> cloth substep (oracle/cloth_oracle.py) cut into the same three phases: the sheet's forecast contact takes the place of the SDF
+    primitives' (its v_out corrections and grid_v_mixed.grad partials cross the slab boundary the same way), contact faces and penetration flags are
+    per-particle inputs of each frame (rank-local).  Test infrastructure for tests/test_slabs.py (world-2 gloo, CPU)."""
+
+    def __init__(self, P, state24, cloth_frames, faces, prim_kw, contact):
+        """cloth_frames[f] = (pos (V,3), vel (V,3)); contact[f] = (contact_id (N,), penetration (N,)) of THIS rank's particles"""
+        super().__init__(P, state24)
+        from oracle import cloth_oracle as CO
+        self.CO, self.cloth, self.faces, self.kw, self.contact = CO, cloth_frames, faces, prim_kw, contact
+        V = np.asarray(cloth_frames[0][0]).shape[0]
+        self.ext = torch.zeros(V, 3, dtype=O.DT)                 # per-vertex force (this rank's partial sum)
+        self.cgrad = {}                                          # frame -> (position.grad, velocity.grad) partial sums
+        self.ext_f_grad = None                                   # (V,3) seed on the sheet's force
+
+    def _prim(self, f, leaves=False):
+        pos = torch.as_tensor(np.asarray(self.cloth[f][0]), dtype=O.DT).clone()
+        vel = torch.as_tensor(np.asarray(self.cloth[f][1]), dtype=O.DT).clone()
+        if leaves:
+            pos.requires_grad_(True); vel.requires_grad_(True)
+        return self.CO.ClothPrim(pos, vel, torch.as_tensor(np.asarray(self.faces).astype(np.int64)), mpm_scale=self.P.scale, **self.kw)
+
+    def _cloth_contact(self, x, vmix, gm, prim, f):
+        CO, P = self.CO, self.P
+        cid, pen = self.contact[f]
+        sel = torch.as_tensor(np.nonzero(np.asarray(cid) >= 0)[0], dtype=torch.int64)
+        v_tmp = O.grid_op_mixed2(x, vmix, P)
+        v_tgt, ext = v_tmp, torch.zeros_like(prim.position)
+        if len(sel):
+            life = 1.0 / (P.substeps - (f - self.shift) % P.substeps)
+            vt, ext = CO.collide_mixed(prim, x[sel], v_tmp[sel], P.p_mass, P.dt, life, torch.as_tensor(np.asarray(cid), dtype=torch.int64)[sel],
+                                       torch.as_tensor(np.asarray(pen), dtype=torch.int64)[sel])
+            v_tgt = v_tmp.index_put((sel,), vt)
+        corr = O.grid_op_mixed4(x, v_tmp, v_tgt, gm, torch.zeros_like(vmix), P)
+        return corr, ext
+
+    def _p2g(self, x, v, C, F):
+        CO, P = self.CO, self.P
+        Ft = O.compute_F_tmp(C, F, P.dt)
+        U, sig, V = O.svd3(Ft) if P.material_model == 0 else (None, None, None)
+        return CO.p2g(x, v, C, Ft, U, sig, V, P, torch.zeros_like(x))
+
+    def phase(self, f, k):
+        P = self.P
+        x, v, C, F = self.frames[f]
+        if k == 0:
+            self.newF, gv, gm = self._p2g(x, v, C, F)
+            self.fields["grid_in"] = torch.cat([gm[..., None], gv], -1)
+        elif k == 1:
+            gin = self.fields["grid_in"]
+            vmix = O.grid_op_mixed1(gin[..., 0], gin[..., 1:], P)
+            corr, ext = self._cloth_contact(x, vmix, gin[..., 0], self._prim(f), f)
+            self.ext = self.ext + ext.detach()
+            pad = torch.zeros(self.n, self.n, self.n, 1, dtype=O.DT)
+            self.fields["grid_mixed"] = torch.cat([vmix, pad], -1)
+            self.fields["grid_out"] = torch.cat([vmix + corr, pad], -1)
+        else:
+            super().phase(f, 2)
+
+    def grad_phase(self, f, k, ext_f_grad=None):
+        P = self.P
+        x, v, C, F = self.frames[f]
+        a1, a0 = self.get_adj(f + 1), self.get_adj(f)
+        if k == 0:
+            super().grad_phase(f, 0, None)
+        elif k == 1:
+            prim = self._prim(f, leaves=True)
+            xl = x.clone().requires_grad_(True)
+            vm = self.fields["grid_mixed"][..., :3].clone().requires_grad_(True)
+            corr, ext = self._cloth_contact(xl, vm, self.fields["grid_in"][..., 0], prim, f)
+            L = (corr * self.fields["grid_out.grad"][..., :3]).sum()
+            if self.ext_f_grad is not None:
+                L = L + (ext * torch.as_tensor(self.ext_f_grad, dtype=O.DT)).sum()
+            inputs = [xl, vm, prim.position, prim.velocity]
+            gr = torch.autograd.grad(L, inputs, allow_unused=True)
+            gr = [torch.zeros_like(i) if g is None else g for g, i in zip(gr, inputs)]
+            a0[0] = a0[0] + gr[0]
+            self.fields["grid_mixed.grad"][..., :3] = gr[1]
+            self.cgrad[f] = (gr[2].numpy(), gr[3].numpy())
+        else:
+            gin = self.fields["grid_in"]
+            gm = gin[..., 0].clone().requires_grad_(True)
+            gv = gin[..., 1:].clone().requires_grad_(True)
+            vmix = O.grid_op_mixed1(gm, gv, P)
+            up = self.fields["grid_out.grad"][..., :3] + self.fields["grid_mixed.grad"][..., :3]
+            agm, agv = torch.autograd.grad((vmix * up).sum(), [gm, gv], allow_unused=True)
+            agm = torch.zeros_like(gm) if agm is None else agm
+            leaves = [t.clone().requires_grad_(True) for t in (x, v, C, F)]
+            nF, pgv, pgm = self._p2g(*leaves)
+            L = (nF * a1[3]).sum() + (pgv * agv).sum() + (pgm * agm).sum()
+            gr = torch.autograd.grad(L, leaves)
+            for i in range(4):
+                a0[i] = a0[i] + gr[i]

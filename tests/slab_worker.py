@@ -29,6 +29,8 @@ def main():
         return moving(a)
     if a.scene == "grip_strong":
         return grip_strong(a)
+    if a.scene == "cloth":
+        return cloth(a)
     sc = S.build(a.precision)
     idx = S.owned(sc, a.rank, a.world)
     state = sc["state"][idx]
@@ -70,6 +72,53 @@ def main():
                    ext=np.array([m.ext_f.to_numpy() for m in prims]) if sc["specs"] else np.zeros((0, 6)),
                    pgrad=np.array([[m.get_all_states_grad(f) for m in prims] for f in range(nsteps)]))
     np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=idx, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def cloth_scene(n=3):
+    """the taco scene of tests/scenes_cloth.py (von-Mises plasticine on the sticky tortilla, scale 5) cut at the disc's centre plane; contact faces
+    searched per frame on the particles the oracle rollout puts there, 15 % of the contact particles flagged as penetrated (push-out branch)"""
+    import scenes_cloth as SC
+    from oracle import cloth_oracle as CO
+    sc = SC.build("taco", "float64", n_env_steps=1, N=1500)
+    P = SC.oracle_params(sc)
+    cloth = [sc["motion"](f * sc["cfg"].dt) for f in range(n + 1)]
+    N = len(sc["state"])
+    rng = np.random.default_rng(91)
+    x, v, C, F = H.O.state24_split(sc["state"])
+    ids0 = CO.get_contact_pair(x, torch.as_tensor(cloth[0][0]), torch.as_tensor(sc["faces"].astype(np.int64)), np.zeros(N, dtype=np.int64), sc["scale"])
+    ids0 = np.asarray(ids0)
+    contact = []
+    for f in range(n):
+        pen = ((rng.uniform(size=N) < 0.15) & (ids0 >= 0)).astype(np.int64)
+        contact.append((ids0.copy(), pen))
+    seeds = (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), 0.01 * rng.standard_normal((N, 3, 3)), 0.01 * rng.standard_normal((N, 3, 3)))
+    eg = 1e-2 * rng.standard_normal((len(sc["vertices"]), 3))
+    return sc, P, cloth, contact, seeds, eg, n
+
+
+def cloth(a):
+    import slab_engines as E
+    sc, P, cloth_fr, contact, seeds, eg, n = cloth_scene()
+    split = P.n_grid // 2                                          # the disc is centred at x = 2.5 of 5
+    base = np.floor(sc["state"][:, 0] * P.inv_dx - 0.5).astype(int)
+    idx = np.nonzero(base < split if a.rank == 0 else base >= split)[0]
+    eng = E.ClothOracleSlabEngine(P, sc["state"][idx], cloth_fr, sc["faces"], dict(friction=sc["prim"]["friction"], softness=sc["prim"]["softness"],
+                                  cloth_force_scale=sc["prim"]["cloth_force_scale"], sticky=sc["prim"]["sticky"]), [(c[idx], p[idx]) for c, p in contact])
+    eng.ext_f_grad = eg
+    run = SlabRunner(eng, a.rank, a.world, split, split, 2, has_contact=True)
+    run.run_substeps(0, n)
+    adj = eng.get_adj(n)
+    for k in range(4):
+        adj[k] = adj[k] + torch.as_tensor(seeds[k][idx]).reshape(adj[k].shape)
+    run.run_substeps_grad(0, n)
+    x, v, C, F = eng.frames[n]
+    g = eng.get_adj(0)
+    V = len(sc["vertices"])
+    cg = np.array([[eng.cgrad.get(f, (np.zeros((V, 3)), np.zeros((V, 3))))[k] for k in range(2)] for f in range(n)])
+    np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=idx, x=x.numpy(), v=v.numpy(), C=C.numpy(), F=F.numpy(), gx=g[0].numpy(), gv=g[1].numpy(),
+             gC=g[2].numpy(), gF=g[3].numpy(), ext=eng.ext.numpy(), cgrad=cg, hits=int((contact[0][0][idx] >= 0).sum()))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -168,6 +168,43 @@ def test_contact_exchange_shortcut_keeps_the_single_domain_result_gpu(tmp_path):
     assert H.rel_err(ext, np.array([m.ext_f.to_numpy() for m in prims])) < 1e-9
 
 
+def test_cloth_variant_in_two_slabs_matches_single_domain_cpu(tmp_path):
+    """the soft <-> cloth substep under the slab decomposition (world 2, gloo, oracle stand-in engine behind the same
+    SlabRunner) against the single-domain cloth oracle: states, adjoints, and the two per-rank partial sums the reductions add up - the force on
+    the sheet's vertices and the sheet's vertex adjoints."""
+    import slab_worker as W
+    from oracle import cloth_oracle as CO
+    import scenes_cloth as SC
+    import torch
+    parts = _run_ranks("oracle", "float64", tmp_path, 2, "cloth")
+    sc, P, cloth_fr, contact, seeds, eg, n = W.cloth_scene()
+    N, V = len(sc["state"]), len(sc["vertices"])
+    x, v, C, F = H.O.state24_split(sc["state"])
+    frames, ext = [(x, v, C, F)], torch.zeros(V, 3, dtype=CO.DT)
+    for f in range(n):
+        prim = SC.oracle_prim(sc, *cloth_fr[f])
+        x, v, C, F, e = CO.substep(*frames[-1], P, prim, contact[f][0], contact[f][1], f)
+        frames.append((x.detach(), v.detach(), C.detach(), F.detach()))
+        ext = ext + e.detach()
+    g = [torch.as_tensor(s_) for s_ in seeds]
+    cg = []
+    for f in range(n - 1, -1, -1):
+        out = CO.substep_grad(*frames[f], P, SC.oracle_prim(sc, *cloth_fr[f]), contact[f][0], contact[f][1], f, g[0], g[1], g[2], g[3], ext_f_grad=eg)
+        g = [out["gx"], out["gv"], out["gC"], out["gF"]]
+        cg.append((out["cloth_pos"].numpy(), out["cloth_vel"].numpy()))
+    cg = np.array(cg[::-1])
+    assert sum(len(p["idx"]) for p in parts) == N and min(int(p["hits"]) for p in parts) > 20      # both slabs touch the sheet
+    ref = dict(zip("xvCF", [t.numpy() for t in frames[n]]))
+    refg = dict(gx=g[0].numpy(), gv=g[1].numpy(), gC=g[2].numpy(), gF=g[3].numpy())
+    for p in parts:
+        for k in "xvCF":
+            assert H.rel_err(p[k], ref[k][p["idx"]]) < 1e-11, k
+        for k in refg:
+            assert np.abs(p[k] - refg[k][p["idx"]]).max() < 1e-9 * np.abs(refg[k]).max(), k
+    assert np.abs(ext.numpy()).max() > 0 and H.rel_err(sum(p["ext"] for p in parts), ext.numpy()) < 1e-10
+    assert np.abs(cg).max() > 0 and H.rel_err(sum(p["cgrad"] for p in parts), cg) < 1e-9
+
+
 def test_contact_sides_predicate(monkeypatch):
     from softmac_amd.parallel import contact_sides
     spec = dict(lower=[-0.06, -0.11, -0.06], upper=[0.06, 0.11, 0.06], contact=True)

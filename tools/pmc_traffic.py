@@ -34,6 +34,18 @@ for k, short in NAMES.items():
         b = (2 * fetch[k] + write[k]) * 1024
         out[short] = b
         rows.append((short, fetch[k], write[k], b))
+# bench.py quotes these numbers only while the kernel sources are the ones they were measured on
+import hashlib, os, subprocess
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha1()
+for name in ("smac_kernels.hpp", "smac_math.hpp", "smac_sort.hpp"):
+    h.update(open(os.path.join(root, "softmac_amd", "csrc", name), "rb").read())
+out["kernel_sources_sha1"] = h.hexdigest()
+try:
+    out["measured"] = "PMC passes on commit " + subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() + \
+        (" (" + sys.argv[4] + ")" if len(sys.argv) > 4 else "")
+except Exception:
+    out["measured"] = sys.argv[4] if len(sys.argv) > 4 else "unknown"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("kernel,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_per_launch(2F+W)")
 for r in rows:

@@ -28,13 +28,23 @@ struct Rccl {
 
     bool load() {
         if (lib) return true;
-        // SMAC_RCCL_LIB: explicit path; else the ROCm install's library, then whatever the loader finds
-        const char* names[] = {getenv("SMAC_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-        for (const char* n : names) {
-            if (!n || !*n) continue;
-            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
+        // ONE RCCL per process.  A host that already carries one (a PyTorch process: libtorch_hip.so depends on its bundled librccl.so, loaded whether
+        // or not torch.distributed ever uses it) gets THAT instance: RTLD_NOLOAD by the names it is known under.  Otherwise the ROCm install's
+        // library is loaded with RTLD_DEEPBIND, so that its internal calls bind to itself whatever other copy a later import brings into the
+        // process (without it, round 3's first run printed torch's library path from inside /opt/rocm's RCCL: symbols of two copies had mixed).
+        // SMAC_RCCL_LIB: explicit path, taken as given.
+        const char* forced = getenv("SMAC_RCCL_LIB");
+        if (forced && *forced) lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        if (!lib)
+            for (const char* n : {"librccl.so", "librccl.so.1"}) {
+                lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+                if (lib) break;
+            }
+        if (!lib)
+            for (const char* n : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+                lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+                if (lib) break;
+            }
         if (!lib) { err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return false; }
         bool ok = true;
         auto sym = [&](const char* name) { void* p = dlsym(lib, name); if (!p) { ok = false; err = std::string("RCCL symbol missing: ") + name; } return p; };

@@ -228,6 +228,43 @@ SMAC_HD void prim_normal(const PrimTable<R>& T, const S* st13, const S* pos, S* 
     qrot(st13 + 3, n, n_out);
 }
 
+// Primitive.sdf AND Primitive.normal at the same point in one go: one inverse transform, one cell lookup, and the 8 + 24 table taps issued together
+// (the forecast-contact chain is a sequence of dependent memory round trips - sdf(x), normal(x), sdf(x'), normal(x') - for a handful of particles:
+// fetching the normal's taps with the distance's halves it; same arithmetic as prim_sdf / prim_normal, value for value)
+template <class S, class R>
+SMAC_HD S prim_sdf_normal(const PrimTable<R>& T, const S* st13, const S* pos, S* n_out) {
+    S local[3];
+    inv_trans(pos, st13, st13 + 3, local);
+    int b[3]; S fx[3];
+    S n[3] = {S(R(0)), S(R(1)), S(R(0))};
+    S out = S(R(1e10));
+    if (sdf_cell(T, local, b, fx)) {
+        n[1] = S(R(0));
+        out = S(R(0));
+        const int sy = T.res[2], sx = T.res[1] * T.res[2];
+        R ts[8], tn[24];
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    const int c = (b[0] + i) * sx + (b[1] + j) * sy + (b[2] + k), q = 4 * i + 2 * j + k;
+                    ts[q] = T.sdf[c];
+                    tn[3 * q] = T.normal[3 * c]; tn[3 * q + 1] = T.normal[3 * c + 1]; tn[3 * q + 2] = T.normal[3 * c + 2];
+                }
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    const int q = 4 * i + 2 * j + k;
+                    S w = (i ? fx[0] : R(1) - fx[0]) * (j ? fx[1] : R(1) - fx[1]) * (k ? fx[2] : R(1) - fx[2]);
+                    out = out + w * ts[q];
+                    n[0] = n[0] + w * tn[3 * q]; n[1] = n[1] + w * tn[3 * q + 1]; n[2] = n[2] + w * tn[3 * q + 2];
+                }
+        S l = sqrt_(dot3(n, n));                       // .normalized(), mesh.py:110
+        n[0] = n[0] / l; n[1] = n[1] / l; n[2] = n[2] / l;
+    }
+    qrot(st13 + 3, n, n_out);
+    return out;
+}
+
 // collider_v, primitive_base.py:63-70
 template <class S> SMAC_HD void collider_v(const S* st13, const S* r, S* o) {
     const S* rot = st13 + 3;
@@ -247,12 +284,11 @@ template <class S> SMAC_HD void collider_v(const S* st13, const S* r, S* o) {
 template <class S, class R>
 SMAC_HD bool collide_mixed(const PrimTable<R>& T, const S* st13, const S* p_pos, S* v_io,
                            R p_mass, R dt, R life, S* ext6) {
-    S dist = prim_sdf(T, st13, p_pos);
+    S D[3], r[3], cv[3], in[3];
+    S dist = prim_sdf_normal(T, st13, p_pos, D);                       // :141, :145 (the normal's taps travel with the distance's)
     if (!(val(dist) <= R(5e-3))) return false;                         // :142-143
     S p_v_in[3] = {v_io[0], v_io[1], v_io[2]};
     S p_v[3] = {v_io[0], v_io[1], v_io[2]};
-    S D[3], r[3], cv[3], in[3];
-    prim_normal(T, st13, p_pos, D);                                    // :145
     for (int i = 0; i < 3; ++i) r[i] = p_pos[i] - st13[i];             // :146
     collider_v(st13, r, cv);                                           // :147
     for (int i = 0; i < 3; ++i) in[i] = p_v[i] - cv[i];                // :149
@@ -272,10 +308,9 @@ SMAC_HD bool collide_mixed(const PrimTable<R>& T, const S* st13, const S* p_pos,
         }
     }
     S xn[3] = {p_v[0] * dt + p_pos[0], p_v[1] * dt + p_pos[1], p_v[2] * dt + p_pos[2]};   // :166
-    S sdf2 = prim_sdf(T, st13, xn);                                    // :167
+    S n2[3];
+    S sdf2 = prim_sdf_normal(T, st13, xn, n2);                         // :167, :169
     if (val(sdf2) < R(0)) {                                            // :168-170
-        S n2[3];
-        prim_normal(T, st13, xn, n2);
         S k = (sdf2 / dt) * life;
         for (int i = 0; i < 3; ++i) p_v[i] = p_v[i] - k * n2[i];
     }

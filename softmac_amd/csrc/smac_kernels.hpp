@@ -56,6 +56,15 @@ namespace smac {
 #ifndef SMAC_GFN_STASH
 #define SMAC_GFN_STASH 0         // 1: k_p2g_grad parks F.grad[f+1] in the LDS stash (48 KB per workgroup) instead of 9 registers: 100 vs 92 us
 #endif
+#ifndef SMAC_P2G_EARLY_ROWS
+#define SMAC_P2G_EARLY_ROWS 0    // 1: k_p2g issues its particle rows before the barrier that publishes the primitive states (A/B: profiles/scripts/r03_q.sh)
+#endif
+#ifndef SMAC_PGG_EARLY_ROWS
+#define SMAC_PGG_EARLY_ROWS 0    // 1: k_p2g_grad / k_p2g_g2p_grad issue their 33 particle rows before the tile barrier
+#endif
+#ifndef SMAC_PHASE_CLOCK
+#define SMAC_PHASE_CLOCK 0       // 1 (tools/phase_clock.sh only): 1 workgroup in 16 of the particle kernels files s_memtime at its phase boundaries
+#endif
 #ifndef SMAC_GFX_FROM_A
 #define SMAC_GFX_FROM_A 1        // k_p2g_grad: dpos adjoint from a0,a1,a2 (live anyway) instead of the 9 affine entries
 #endif
@@ -309,6 +318,21 @@ template <class R> __device__ __forceinline__ void f_tmp(const R* C, const R* E,
 // ------------------------------------------------------------------------------------------
 // chunk prologue shared by the particle kernels
 // ------------------------------------------------------------------------------------------
+#if SMAC_PHASE_CLOCK
+// [marker][slot]: sums of timestamps (mod 2^64: differences of sums are sums of differences) and hit counts; markers 0-15 backward, 16-31 forward kernels
+__device__ unsigned long long smac_phase_sum[32 * 64];
+__device__ unsigned long long smac_phase_cnt[32 * 64];
+#define SMAC_PHASE(i, cond)                                                                          \
+    do {                                                                                             \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 3 && (cond)) {                           \
+            const int slot_ = (i) * 64 + (int)((blockIdx.x >> 4) & 63);                              \
+            atomicAdd(&smac_phase_sum[slot_], (unsigned long long)__builtin_readcyclecounter());     \
+            atomicAdd(&smac_phase_cnt[slot_], 1ull);                                                 \
+        }                                                                                            \
+    } while (0)
+#else
+#define SMAC_PHASE(i, cond) do { } while (0)
+#endif
 #define SMAC_CHUNK_PROLOGUE_AT(ci)                            \
     const Chunk ch = D.chunks[ci];                            \
     const int t = threadIdx.x;                                \
@@ -559,31 +583,56 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     if (D.n < 0) lds_pad[threadIdx.x] = 1;
     if (D.n < -1) D.pmask[0] = lds_pad[(threadIdx.x * 7) % (SMAC_P2G_LDS_PAD / 4)];
 #endif
+    SMAC_PHASE(22, true);                // (entry, every wave)
+#if !SMAC_P2G_EARLY_ROWS
     if (D.any_contact) {                 // (uniform) primitive states of this frame, converted once per workgroup for the band test
         if (threadIdx.x < D.P * 13)
             ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];
         __syncthreads();
     }
+#endif
     SMAC_CHUNK_PROLOGUE
+    SMAC_PHASE(23, ch.count >= 0);       // (descriptor in, every wave)
     W* const tile = (W*)tile_raw;
     double* const tile64 = tile_raw;
     const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;       // workgroup-uniform: f64 words instead of fixed point
     if (sparse) { for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
     else { for (int i = t; i < 4 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }     // (made visible by the barrier inside tile_scale)
     int cmask = 0;
+    SMAC_PHASE(16, valid);
     typedef typename pos_of<R>::type PX;
     PX x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
     R pv[3] = {R(0), R(0), R(0)}, aff[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) aff[i] = R(0);
     R bound = R(0);                       // no single scattered momentum component of this particle exceeds it
+#if SMAC_P2G_EARLY_ROWS
+    // the chunk descriptor first, then the particle rows AND the primitive states in one round trip, then the barrier that publishes the latter
+    // (entry -> primitive states -> barrier -> descriptor -> rows were three dependent round trips at the head of every workgroup)
+    R v[3] = {R(0), R(0), R(0)}, C[9], E[9];
     if (valid) {
         const R* Sf = frame(D.S, f, D.Npad);
-        R v[3], C[9], E[9], Et[9], En[9], stress[9];
         load_pos(Sf, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
+    }
+    if (D.any_contact) {
+        if (threadIdx.x < D.P * 13)
+            ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];
+        __syncthreads();
+    }
+#endif
+    if (valid) {
+        R Et[9], En[9], stress[9];
+#if !SMAC_P2G_EARLY_ROWS
+        const R* Sf = frame(D.S, f, D.Npad);
+        R v[3], C[9], E[9];
+        load_pos(Sf, D.Npad, p, x);
+        load_vec(Sf, CV, 3, D.Npad, p, v);
+        load_vec(Sf, CC, 9, D.Npad, p, C);
+        load_vec(Sf, CF, 9, D.Npad, p, E);
+#endif
         int cloth_face = -1;
         if (PCON && D.cloth.present) {                             // cloth primitive, penalty contact: the contact face was searched before the substep
             const size_t at = (size_t)f * D.cloth.n_ids + D.orig_id[p];
@@ -665,7 +714,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     }
     // tile units: momentum by the chunk's bound, mass by p_mass (w <= 1); one barrier (all threads)
     R to_tile, from_tile;
+    SMAC_PHASE(17, valid);                     // rows loaded, SVD + stress done
     tile_scale<R>(bound, smax, to_tile, from_tile);
+    SMAC_PHASE(18, valid);                     // barrier
     const R mass_unit = sizeof(R) == 4 ? R(FIX_RANGE / W_MAX) : D.p_mass;    // w <= W_MAX
     if (valid) {
         Stencil<R> st;
@@ -751,9 +802,12 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         }
     }
     if (PCON && D.any_contact && valid) D.pmask[p] = cmask;   // read back by p2g.grad
+    SMAC_PHASE(19, valid);                     // scatter issued
     __syncthreads();
+    SMAC_PHASE(20, valid);
     if (sparse) tile_store<R, 4>(D, tile64, R(1), R(1));
     else tile_store<R, 4>(D, tile, sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1), from_tile);
+    SMAC_PHASE(21, valid);
 }
 
 // boundary_condition :268-281 on a velocity; returns mask bits of the components that were zeroed
@@ -1091,11 +1145,14 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
     const R* Sf = frame(D.S, f, D.Npad);
     R* Sn = frame(D.S, f + 1, D.Npad);
     typename pos_of<R>::type x[3];
+    SMAC_PHASE(24, valid);
     load_pos(Sf, D.Npad, p, x);                     // issued before the tile load's barrier: one round trip, not two
     gather_tile_load(D, D.vout, ch.block, gt);
     __syncthreads();
+    SMAC_PHASE(25, valid);
     if (!valid) return;
     g2p_particle(D, ch, p, x, gt, Sn);
+    SMAC_PHASE(26, true);
 }
 
 // Persistent, software-pipelined form: a workgroup walks several chunks of its XCD's range; while it computes chunk k from LDS
@@ -1205,7 +1262,10 @@ __device__ __forceinline__ void g2p_grad_chunk(const DevSim<R>& D, const Chunk& 
             bound = maxc(bound, R(W_MAX) * abs_(gnv[c]) + R(WD_MAX) * (abs_(gC1[3 * c]) + abs_(gC1[3 * c + 1]) + abs_(gC1[3 * c + 2])));
     }
     R to_tile, from_tile;
+    const bool fused_ = Af == D.Af_prev;
+    (void)fused_;
     tile_scale<R>(bound, smax, to_tile, from_tile);                                        // one barrier (all threads)
+    SMAC_PHASE(6, valid && fused_);
     if (valid) {
         Stencil<R> st;
         Nodes nd;
@@ -1292,9 +1352,12 @@ __device__ __forceinline__ void g2p_grad_chunk(const DevSim<R>& D, const Chunk& 
             else Af[rowoff(CX + d, p, D.Npad)] = g;
         }
     }
+    SMAC_PHASE(7, valid && fused_);            // 27-node gather + scatter of the G2P adjoint
     __syncthreads();
+    SMAC_PHASE(8, valid && fused_);
     if (sparse) tile_store<R, 3>(D, tile64, R(1), R(1));
     else tile_store<R, 3>(D, tile, from_tile, from_tile);
+    SMAC_PHASE(9, valid && fused_);
 }
 
 
@@ -1787,9 +1850,22 @@ template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SM
 // p2g.grad + svd_grad + compute_F_tmp.grad of one particle (mpm_simulator.py:371-374): `gt` is the staged grid_v_in.grad / grid_m.grad tile, `stash` the
 // workgroup's LDS parking space.  Writes the adjoint of frame f to D.Af; KEEP: also hands x.grad, v.grad, C.grad of frame f back in registers
 // (k_p2g_g2p_grad feeds them to the G2P adjoint of the substep before) - only with ACC_VCF = false, i.e. when frame f carried no seed.
+// the rows p2g.grad reads first (frame f: x, v, C, E; adjoint frame f + 1: F.grad), fetched by the kernel BEFORE its tile barrier when SMAC_PGG_EARLY_ROWS
+template <class R> struct PggRows {
+    typename pos_of<R>::type x[3];
+    R v[3], C[9], E[9], gFn[9];
+    __device__ __forceinline__ void load(const DevSim<R>& D, int f, int p) {
+        const R* Sf = frame(D.S, f, D.Npad);
+        load_vec(Sf, CC, 9, D.Npad, p, C);
+        load_vec(Sf, CF, 9, D.Npad, p, E);
+        load_pos(Sf, D.Npad, p, x);
+        load_vec(Sf, CV, 3, D.Npad, p, v);
+        load_vec(D.An, CF, 9, D.Npad, p, gFn);
+    }
+};
 template <class R, bool ACC_VCF, bool PCON, bool KEEP>
 __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, const Chunk& ch, int p, int t, typename const_t<R>::type* stash, const Vec4<R>* gt,
-                                                  R* gx_o, R* gv_o, R* gC_o) {
+                                                  R* gx_o, R* gv_o, R* gC_o, const PggRows<R>* pre = nullptr) {
     constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
     typedef typename const_t<R>::type CT;
     const R* Sf = frame(D.S, f, D.Npad);
@@ -1805,6 +1881,12 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
     {
         R C[9], E[9];
         CT Et[9], En[9], stress[9];
+#if SMAC_PGG_EARLY_ROWS
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { C[i] = pre->C[i]; E[i] = pre->E[i]; gFn[i] = pre->gFn[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { x[i] = pre->x[i]; v[i] = pre->v[i]; }
+#else
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
         load_pos(Sf, D.Npad, p, x);
@@ -1813,6 +1895,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         R gFn[9];
 #endif
         load_vec(An, CF, 9, D.Npad, p, gFn);       // F.grad[f+1]: fetched with the rest (parked in LDS until the constitutive adjoint)
+#endif
         ConstState<CT> cs;
         {
             CT Cc[9], Ec[9];
@@ -1839,6 +1922,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         for (int i = 0; i < 9; ++i) stash[(34 + i) * BLOCK + t] = (CT)gFn[i];
 #endif
     }
+    SMAC_PHASE(2, KEEP);                       // rows loaded, forward constitutive model recomputed and parked
     R imp[3] = {R(0), R(0), R(0)};
     int ci = -1;
     if (D.n_control > 0) {
@@ -1900,11 +1984,17 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
     }
     R M0[3] = {R(0), R(0), R(0)}, Mx[3] = {R(0), R(0), R(0)}, My[3] = {R(0), R(0), R(0)}, Mz[3] = {R(0), R(0), R(0)};
     const R wz1 = st.w[1][2], wz2 = R(2) * st.w[2][2];
+    // Two copies of the loop, chosen per WAVE (as in k_g2p / g2p_grad_chunk): written once with a per-lane "LDS record, overridden from global memory for a
+    // drifted lane", the compiler folds the two sources into ONE flat_load through a selected generic pointer - 27 flat_load_dwordx4 per particle
+    // also for the waves that never leave the tile (found in the ISA, round 3; the LDS-only copy compiles to ds_read_b128).
+    auto gather = [&](auto mixed_tag) __attribute__((always_inline)) {
+    constexpr bool MIXED = decltype(mixed_tag)::value;
+    // (the plane's x-weight / offsets rotate through three registers: a select on i becomes an indexed read of a stack copy of the stencil here)
+    R wi = st.w[0][0], wi1 = st.w[1][0], wi2 = st.w[2][0];
+    int cxi = nd.cx[0], cxi1 = nd.cx[1], cxi2 = nd.cx[2];
+    int txi = nd.tx[0], txi1 = nd.tx[1], txi2 = nd.tx[2];
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {
-        const R wi = i == 0 ? st.w[0][0] : (i == 1 ? st.w[1][0] : st.w[2][0]);
-        const int cxi = i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2]);
-        const int txi = i == 0 ? nd.tx[0] : (i == 1 ? nd.tx[1] : nd.tx[2]);
         const R fi = R(i);
         const R mi[3] = {m0[0] + fi * a0[0], m0[1] + fi * a0[1], m0[2] + fi * a0[2]};
         R s0[3] = {R(0), R(0), R(0)}, sy[3] = {R(0), R(0), R(0)}, sz[3] = {R(0), R(0), R(0)};
@@ -1917,8 +2007,8 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
             R r0[3] = {R(0), R(0), R(0)}, r1[3] = {R(0), R(0), R(0)};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                Vec4<R> a = gt[all_in ? txi + nd.ty[j] + nd.tz[k] : 0];      // unconditional LDS read (see k_g2p)
-                if (!all_in) a = gld(D.ain, (unsigned)(cxi + nd.cy[j] + nd.cz[k]));
+                Vec4<R> a = gt[(!MIXED || all_in) ? txi + nd.ty[j] + nd.tz[k] : 0];      // unconditional LDS read (see k_g2p)
+                if (MIXED && !all_in) a = gld(D.ain, (unsigned)(cxi + nd.cy[j] + nd.cz[k]));
                 const R Q = a.x * D.p_mass + a.y * (mj[0] + R(k) * a2[0]) + a.z * (mj[1] + R(k) * a2[1]) + a.w * (mj[2] + R(k) * a2[2]);
                 aq += Q * st.w[k][2];
                 wg.g[k][2] += Q * wij;
@@ -1937,7 +2027,12 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         wg.g[2][0] += i == 2 ? gxi : R(0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { M0[c] += wi * s0[c]; My[c] += wi * sy[c]; Mz[c] += wi * sz[c]; Mx[c] += fi * wi * s0[c]; }
+        wi = wi1; wi1 = wi2; cxi = cxi1; cxi1 = cxi2; txi = txi1; txi1 = txi2;
     }
+    };
+    if (__all(all_in)) gather(std::false_type{});
+    else gather(std::true_type{});
+    SMAC_PHASE(3, KEEP);                       // 27-node gather of grid_v_in.grad
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         gvp[c] = M0[c];
@@ -1992,6 +2087,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
 #pragma unroll
         for (int i = 0; i < 9; ++i) gEt[i] = (R)gEc[i];
     }
+    SMAC_PHASE(4, KEEP);                       // constitutive adjoint
     // compute_F_tmp.grad: F_tmp = (I + dt C)(I + E)
     R gC[9], gE[9], Ft[9], A1[9];
     if (STASH_CE) {
@@ -2019,6 +2115,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         }
         if (KEEP) gC_o[i] = gc;
     }
+    SMAC_PHASE(5, KEEP);                       // F_tmp adjoint, 18 rows stored
 }
 
 template <class R, bool ACC_VCF, bool PCON>
@@ -2028,9 +2125,17 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     gather_tile_load(D, D.ain, ch.block, gt);
+#if SMAC_PGG_EARLY_ROWS
+    PggRows<R> rows;
+    if (valid) rows.load(D, f, p);
+    __syncthreads();
+    if (!valid) return;
+    p2g_grad_particle<R, ACC_VCF, PCON, false>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr, &rows);
+#else
     __syncthreads();
     if (!valid) return;
     p2g_grad_particle<R, ACC_VCF, PCON, false>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr);
+#endif
 }
 
 // k_p2g_grad of substep f and k_g2p_grad of substep f - 1 in one launch.  Between two re-sorts a particle keeps its chunk, and the adjoint of
@@ -2047,22 +2152,34 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? occ<R>::heavy : 1)) void k
     __shared__ double tile_raw[3 * TILE_WORDS];  // scatter tile of grid_v_out.grad of substep f - 1
     __shared__ Vec4<R> gtv[TILE_WORDS];         // grid_v_out of substep f - 1
     __shared__ R smax[4];
+    SMAC_PHASE(10, true);
     SMAC_CHUNK_PROLOGUE
+    SMAC_PHASE(11, ch.count >= 0);
     W* const tile = (W*)tile_raw;
     double* const tile64 = tile_raw;
+    SMAC_PHASE(0, valid);
     if (sizeof(R) == 4 && ch.count <= SPARSE_MAX) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
     else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
     gather_tile_load(D, D.ain, ch.block, gt);
     gather_tile_load_fwd(D, 2, ch.block, gtv);
     typename pos_of<R>::type xp[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
     if (valid) load_pos(frame(D.S, f - 1, D.Npad), D.Npad, p, xp);
+#if SMAC_PGG_EARLY_ROWS
+    PggRows<R> rows;
+    if (valid) rows.load(D, f, p);
+#endif
     __syncthreads();
+    SMAC_PHASE(1, valid);                      // both gather tiles staged
     R gx[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) gC1[c] = R(0);
     if (valid) {
         R gv[3];
+#if SMAC_PGG_EARLY_ROWS
+        p2g_grad_particle<R, false, true, true>(D, f, ch, p, t, stash, gt, gx, gv, gC1, &rows);
+#else
         p2g_grad_particle<R, false, true, true>(D, f, ch, p, t, stash, gt, gx, gv, gC1);
+#endif
         const R four_inv_dx = R(4) * D.inv_dx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) gnv[c] = gv[c] + D.dt * gx[c];                           // x' = x + dt v'

@@ -227,6 +227,21 @@ template <class R> struct Sim final : ISim {
 
     ~Sim() override {
         if (stream) hipStreamSynchronize(stream);
+#if SMAC_PHASE_CLOCK
+        if (const char* path = getenv("SMAC_PHASE_DUMP")) {          // tools/phase_clock.sh: per marker, sum of timestamps (mod 2^64) and hits
+            static unsigned long long hs[32 * 64], hc[32 * 64];
+            (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(smac::smac_phase_sum), sizeof(hs));
+            (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(smac::smac_phase_cnt), sizeof(hc));
+            if (FILE* fp = fopen(path, "a")) {
+                for (int m = 0; m < 32; ++m) {
+                    unsigned long long a = 0, c = 0;
+                    for (int k = 0; k < 64; ++k) { a += hs[m * 64 + k]; c += hc[m * 64 + k]; }
+                    fprintf(fp, "%d %llu %llu\n", m, a, c);
+                }
+                fclose(fp);
+            }
+        }
+#endif
         comm_destroy();
         hipFree(D.S); hipFree(D.A); hipFree(grid_block); hipFree(D.prim_state); hipFree(D.prim_grad);
         hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);

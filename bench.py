@@ -112,6 +112,7 @@ def algorithmic_bytes(N, G_t, s):
 
 # compulsory bytes of each kernel taken alone (DESIGN.md "kernels"): scalars per particle, scalars per touched cell
 KERNEL_BYTES = {
+    # (g2p: its launch also carries the frame's checkpoint save since round 3 - "grid_checkpoint"'s 20 G_t, of which the save is 14 - priced apart as before)
     "p2g": (24 + 9, 4), "grid_op": (0, 4 + 6), "contact": (0, 0), "g2p": (3 + 15, 3),
     "g2p_grad": (3 + 15 + 3, 3 + 3), "contact_grad": (0, 0), "grid_op_grad": (0, 4 + 6 + 4), "p2g_grad": (24 + 9 + 3 + 24, 4),
     "clear_grid": (0, 10), "grid_checkpoint": (0, 20), "reduce_agvout": (0, 6), "forward_kinematics": (0, 0),

@@ -56,12 +56,6 @@ namespace smac {
 #ifndef SMAC_GFN_STASH
 #define SMAC_GFN_STASH 0         // 1: k_p2g_grad parks F.grad[f+1] in the LDS stash (48 KB per workgroup) instead of 9 registers: 100 vs 92 us
 #endif
-#ifndef SMAC_P2G_EARLY_ROWS
-#define SMAC_P2G_EARLY_ROWS 0    // 1: k_p2g issues its particle rows before the barrier that publishes the primitive states (A/B: profiles/scripts/r03_q.sh)
-#endif
-#ifndef SMAC_PGG_EARLY_ROWS
-#define SMAC_PGG_EARLY_ROWS 0    // 1: k_p2g_grad / k_p2g_g2p_grad issue their 33 particle rows before the tile barrier
-#endif
 #ifndef SMAC_PHASE_CLOCK
 #define SMAC_PHASE_CLOCK 0       // 1 (tools/phase_clock.sh only): 1 workgroup in 16 of the particle kernels files s_memtime at its phase boundaries
 #endif
@@ -141,6 +135,14 @@ template <class R> struct DevSim {
     struct Hit* hit_ck;          // forward: where k_grid_op files the frame's contact hit list (with its length), or nullptr
     int* nhit_ck;
     int hit_cap;
+    // k_g2p<R, true>: the frame's checkpoint save rides in the same launch (its first `save_blocks` workgroups, a multiple of 8) - own names, so that
+    // nothing takes them for the direct-checkpoint modes of `ck` above
+    Vec4<R>* save_ck;
+    struct Hit* save_hits;
+    int* save_nhits;
+    int save_hit_cap;
+    int save_blocks;
+    int* nhits_next;             // the hit counter of the NEXT substep (two counters alternate by frame parity): emptied here while this frame's is still read
     ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
 };
 
@@ -185,9 +187,20 @@ template <> __device__ __forceinline__ void tile_scale<double>(double, double*, 
     to_tile = from_tile = 1.0;
     __syncthreads();
 }
+// max of a non-negative float over the wave, on the DPP crossbar: the bit pattern of a non-negative float orders like an integer, a butterfly of
+// two quad permutes and the two row mirrors leaves each row's maximum in all of its 16 lanes, four v_readlane + s_max join the rows.  (__shfl_xor
+// compiled to six ds_bpermute_b32, each followed by s_waitcnt lgkmcnt(0): six LDS round trips in front of the barrier of every workgroup.)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = __float_as_int(v);
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));   // row_mirror
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return __int_as_float(max(max(a, b), max(c, d)));
+}
 template <> __device__ __forceinline__ void tile_scale<float>(float bound, float* scratch4, float& to_tile, float& from_tile) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+    bound = wave_max_nonneg(bound);
     if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = bound;
     __syncthreads();
     const float B = fmaxf(fmaxf(scratch4[0], scratch4[1]), fmaxf(scratch4[2], scratch4[3]));
@@ -341,11 +354,11 @@ __device__ unsigned long long smac_phase_cnt[32 * 64];
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the XCD group).  Chunks are listed in block
 // order, so giving XCD g the contiguous range [g*n/8, (g+1)*n/8) keeps spatially adjacent chunks - which re-read the
 // same grid records and slabs - behind ONE L2 instead of spreading every grid line over all eight.  Speed only.
-__device__ __forceinline__ int xcd_chunk(int nchunks) {
+__device__ __forceinline__ int xcd_chunk_at(int bid, int nchunks) {
     const int per = (nchunks + 7) >> 3;
-    const int c = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    return c;
+    return (bid & 7) * per + (bid >> 3);
 }
+__device__ __forceinline__ int xcd_chunk(int nchunks) { return xcd_chunk_at((int)blockIdx.x, nchunks); }
 // The per-cell grid kernels give every wave one active block (4 per workgroup), in the order of the active list.  (XCD-contiguous ranges, as for
 // the chunks, were measured and made k_grid_op / k_reduce_* 0.5 us slower each: profiles/r02_ad_g2p_lds_gather.txt.)
 template <class R> __device__ __forceinline__ int active_slot(const DevSim<R>&) { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
@@ -527,8 +540,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
 // of substep_grad instead of recomputing compute_F_tmp/svd/p2g/grid_op (mpm_simulator.py:352-359).
 // hit_ck / nhit_ck (optional): the frame's contact hit list travels with the checkpoint, so the backward pass
 // does not have to repeat the band test over all particles (k_contact_mask)
+// (`nblocks` workgroups share the work: the whole launch for k_grid_save, the first D.save_blocks workgroups of k_g2p<R, true>)
 template <class R>
-__global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
+__device__ __forceinline__ void grid_save_block(const DevSim<R>& D, int nblocks, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
     if (hit_ck) {
         int nh = *D.nhits;
         if (nh > hit_cap) {                  // more particles in contact bands than a checkpoint slot holds: never truncated silently - the host is
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, H
             nh = 0;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) *nhit_ck = nh;
-        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += gridDim.x * BLOCK) hit_ck[i] = D.hits[i];
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += nblocks * BLOCK) hit_ck[i] = D.hits[i];
     }
     const int a = active_slot(D);
     if (a >= D.nactive) return;
@@ -548,6 +562,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, H
     // global atomics), which saves that substep's clear pass
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
     D.vin[cell] = z;
+}
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
+    grid_save_block(D, (int)gridDim.x, ck, hit_ck, nhit_ck, hit_cap);
 }
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<R>* ck, const Hit* hit_ck, const int* nhit_ck, int zero_all) {
@@ -584,13 +602,11 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     if (D.n < -1) D.pmask[0] = lds_pad[(threadIdx.x * 7) % (SMAC_P2G_LDS_PAD / 4)];
 #endif
     SMAC_PHASE(22, true);                // (entry, every wave)
-#if !SMAC_P2G_EARLY_ROWS
     if (D.any_contact) {                 // (uniform) primitive states of this frame, converted once per workgroup for the band test
         if (threadIdx.x < D.P * 13)
             ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];
         __syncthreads();
     }
-#endif
     SMAC_CHUNK_PROLOGUE
     SMAC_PHASE(23, ch.count >= 0);       // (descriptor in, every wave)
     W* const tile = (W*)tile_raw;
@@ -606,33 +622,14 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
 #pragma unroll
     for (int i = 0; i < 9; ++i) aff[i] = R(0);
     R bound = R(0);                       // no single scattered momentum component of this particle exceeds it
-#if SMAC_P2G_EARLY_ROWS
-    // the chunk descriptor first, then the particle rows AND the primitive states in one round trip, then the barrier that publishes the latter
-    // (entry -> primitive states -> barrier -> descriptor -> rows were three dependent round trips at the head of every workgroup)
-    R v[3] = {R(0), R(0), R(0)}, C[9], E[9];
-    if (valid) {
-        const R* Sf = frame(D.S, f, D.Npad);
-        load_pos(Sf, D.Npad, p, x);
-        load_vec(Sf, CV, 3, D.Npad, p, v);
-        load_vec(Sf, CC, 9, D.Npad, p, C);
-        load_vec(Sf, CF, 9, D.Npad, p, E);
-    }
-    if (D.any_contact) {
-        if (threadIdx.x < D.P * 13)
-            ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];
-        __syncthreads();
-    }
-#endif
     if (valid) {
         R Et[9], En[9], stress[9];
-#if !SMAC_P2G_EARLY_ROWS
         const R* Sf = frame(D.S, f, D.Npad);
         R v[3], C[9], E[9];
         load_pos(Sf, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
-#endif
         int cloth_face = -1;
         if (PCON && D.cloth.present) {                             // cloth primitive, penalty contact: the contact face was searched before the substep
             const size_t at = (size_t)f * D.cloth.n_ids + D.orig_id[p];
@@ -1134,14 +1131,31 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
     for (int c = 0; c < 9; ++c) Sn[rowoff(CC + c, p, D.Npad)] = four_inv_dx * nC[c];
 }
 
-template <class R>
+// SAVE: the grid checkpoint of the frame (k_grid_save's work: 20 s G_t bytes, a 9 us launch of its own that only waits for memory) is done by the
+// first D.save_blocks workgroups of THIS launch - it reads the same finished grid and touches nothing k_g2p reads ({m,p} is zeroed, v_out only
+// copied), so the two run side by side and a kernel boundary goes.  The hit counter cannot be emptied here while the save part still reads it:
+// the counters of even and odd frames alternate, and this launch empties the NEXT frame's.
+template <class R, bool SAVE>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_g2p(DevSim<R> D, int f) {
     __shared__ Vec4<R> gt[TILE_WORDS];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // last kernel of the substep: hand the contact lists back empty
+    int bid = (int)blockIdx.x;
+    if (SAVE) {
+        if (bid == 0 && threadIdx.x == 0) {
+            D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
+            *D.nhits_next = 0; *D.ncand = 0;
+        }
+        if (bid < D.save_blocks) {
+            grid_save_block(D, D.save_blocks, D.save_ck, D.save_hits, D.save_nhits, D.save_hit_cap);
+            return;
+        }
+        bid -= D.save_blocks;
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {      // last kernel of the substep: hand the contact lists back empty
         D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
-        *D.nhits = 0; *D.ncand = 0;
+        *D.nhits = 0; *D.nhits_next = 0; *D.ncand = 0;
     }
-    SMAC_CHUNK_PROLOGUE
+    const int cid = xcd_chunk_at(bid, D.nchunks);
+    if (cid >= D.nchunks) return;
+    SMAC_CHUNK_PROLOGUE_AT(cid)
     const R* Sf = frame(D.S, f, D.Npad);
     R* Sn = frame(D.S, f + 1, D.Npad);
     typename pos_of<R>::type x[3];
@@ -1164,7 +1178,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P_PIPE : 2)) vo
     __shared__ Vec4<R> gt[2][TILE_WORDS];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
-        *D.nhits = 0; *D.ncand = 0;
+        *D.nhits = 0; *D.nhits_next = 0; *D.ncand = 0;
     }
     const int t = threadIdx.x;
     const int per = (D.nchunks + 7) >> 3;                              // the XCD-aware split of xcd_chunk()
@@ -1850,22 +1864,9 @@ template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SM
 // p2g.grad + svd_grad + compute_F_tmp.grad of one particle (mpm_simulator.py:371-374): `gt` is the staged grid_v_in.grad / grid_m.grad tile, `stash` the
 // workgroup's LDS parking space.  Writes the adjoint of frame f to D.Af; KEEP: also hands x.grad, v.grad, C.grad of frame f back in registers
 // (k_p2g_g2p_grad feeds them to the G2P adjoint of the substep before) - only with ACC_VCF = false, i.e. when frame f carried no seed.
-// the rows p2g.grad reads first (frame f: x, v, C, E; adjoint frame f + 1: F.grad), fetched by the kernel BEFORE its tile barrier when SMAC_PGG_EARLY_ROWS
-template <class R> struct PggRows {
-    typename pos_of<R>::type x[3];
-    R v[3], C[9], E[9], gFn[9];
-    __device__ __forceinline__ void load(const DevSim<R>& D, int f, int p) {
-        const R* Sf = frame(D.S, f, D.Npad);
-        load_vec(Sf, CC, 9, D.Npad, p, C);
-        load_vec(Sf, CF, 9, D.Npad, p, E);
-        load_pos(Sf, D.Npad, p, x);
-        load_vec(Sf, CV, 3, D.Npad, p, v);
-        load_vec(D.An, CF, 9, D.Npad, p, gFn);
-    }
-};
 template <class R, bool ACC_VCF, bool PCON, bool KEEP>
 __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, const Chunk& ch, int p, int t, typename const_t<R>::type* stash, const Vec4<R>* gt,
-                                                  R* gx_o, R* gv_o, R* gC_o, const PggRows<R>* pre = nullptr) {
+                                                  R* gx_o, R* gv_o, R* gC_o) {
     constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
     typedef typename const_t<R>::type CT;
     const R* Sf = frame(D.S, f, D.Npad);
@@ -1881,12 +1882,6 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
     {
         R C[9], E[9];
         CT Et[9], En[9], stress[9];
-#if SMAC_PGG_EARLY_ROWS
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { C[i] = pre->C[i]; E[i] = pre->E[i]; gFn[i] = pre->gFn[i]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { x[i] = pre->x[i]; v[i] = pre->v[i]; }
-#else
         load_vec(Sf, CC, 9, D.Npad, p, C);
         load_vec(Sf, CF, 9, D.Npad, p, E);
         load_pos(Sf, D.Npad, p, x);
@@ -1895,7 +1890,6 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         R gFn[9];
 #endif
         load_vec(An, CF, 9, D.Npad, p, gFn);       // F.grad[f+1]: fetched with the rest (parked in LDS until the constitutive adjoint)
-#endif
         ConstState<CT> cs;
         {
             CT Cc[9], Ec[9];
@@ -2125,17 +2119,9 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     __shared__ Vec4<R> gt[TILE_WORDS];
     SMAC_CHUNK_PROLOGUE
     gather_tile_load(D, D.ain, ch.block, gt);
-#if SMAC_PGG_EARLY_ROWS
-    PggRows<R> rows;
-    if (valid) rows.load(D, f, p);
-    __syncthreads();
-    if (!valid) return;
-    p2g_grad_particle<R, ACC_VCF, PCON, false>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr, &rows);
-#else
     __syncthreads();
     if (!valid) return;
     p2g_grad_particle<R, ACC_VCF, PCON, false>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr);
-#endif
 }
 
 // k_p2g_grad of substep f and k_g2p_grad of substep f - 1 in one launch.  Between two re-sorts a particle keeps its chunk, and the adjoint of
@@ -2164,10 +2150,6 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? occ<R>::heavy : 1)) void k
     gather_tile_load_fwd(D, 2, ch.block, gtv);
     typename pos_of<R>::type xp[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
     if (valid) load_pos(frame(D.S, f - 1, D.Npad), D.Npad, p, xp);
-#if SMAC_PGG_EARLY_ROWS
-    PggRows<R> rows;
-    if (valid) rows.load(D, f, p);
-#endif
     __syncthreads();
     SMAC_PHASE(1, valid);                      // both gather tiles staged
     R gx[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
@@ -2175,11 +2157,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? occ<R>::heavy : 1)) void k
     for (int c = 0; c < 9; ++c) gC1[c] = R(0);
     if (valid) {
         R gv[3];
-#if SMAC_PGG_EARLY_ROWS
-        p2g_grad_particle<R, false, true, true>(D, f, ch, p, t, stash, gt, gx, gv, gC1, &rows);
-#else
         p2g_grad_particle<R, false, true, true>(D, f, ch, p, t, stash, gt, gx, gv, gC1);
-#endif
         const R four_inv_dx = R(4) * D.inv_dx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) gnv[c] = gv[c] + D.dt * gx[c];                           // x' = x + dt v'

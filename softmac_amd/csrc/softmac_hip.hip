@@ -332,11 +332,12 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(grid_block, 0, 6 * D.G * sizeof(Vec4<R>), stream));
         D.vin = grid_block; D.vmix = grid_block + D.G; D.vout = grid_block + 2 * D.G;
         D.ain = grid_block + 3 * D.G; D.amix = grid_block + 4 * D.G; D.aout = grid_block + 5 * D.G;
-        HIP_TRY(hipMalloc((void**)&d_nhits, 4 * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(d_nhits, 0, 4 * sizeof(int), stream));
+        HIP_TRY(hipMalloc((void**)&d_nhits, 8 * sizeof(int)));         // [0] hit counter (even frames, backward pass), [1] ncand, [2..3] last counts, [4] hit counter of odd frames
+        HIP_TRY(hipMemsetAsync(d_nhits, 0, 8 * sizeof(int), stream));
         HIP_TRY(hipMalloc((void**)&d_hits, (size_t)D.Npad * sizeof(Hit)));
         HIP_TRY(hipMalloc((void**)&d_pmask, (size_t)D.Npad * sizeof(int)));
         D.nhits = d_nhits;
+        D.nhits_next = d_nhits + 4;
         D.last_counts = d_nhits + 2;
         D.ncand = d_nhits + 1;
         D.hits = d_hits;
@@ -1554,6 +1555,14 @@ template <class R> struct Sim final : ISim {
         ++launch_counter;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
+        // the hit counters of even and odd frames alternate (k_g2p<R, true> empties the next frame's while its save part still reads this one's)
+        D.nhits = d_nhits + ((f & 1) ? 4 : 0);
+        D.nhits_next = d_nhits + ((f & 1) ? 0 : 4);
+        if (phase <= 0 && nhits_zero_frame != f) {
+            HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
+            HIP_TRY(hipMemsetAsync(d_nhits + 4, 0, sizeof(int), stream));
+        }
+        if (phase <= 0) nhits_zero_frame = -1;
         if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
@@ -1587,13 +1596,17 @@ template <class R> struct Sim final : ISim {
         if (phase == 1 && (rc = forward_grid(f, true, false, 2))) return rc;
         if (phase < 0 || phase == 2) {
             const int e = frame_epoch[f];
-            if (ck_epoch[f] != e && D.nchunks > 0 && D.n_control == 0 && ck_prepare()) {   // (slab phases) keep the forward grid for substep_grad
-                prof_begin(K_CKPT);
-                const bool keep_hits = ck_hits && any_contact();
+            const bool save = ck_epoch[f] != e && D.nchunks > 0 && D.n_control == 0 && ck_prepare();   // keep the forward grid for substep_grad
+            const bool keep_hits = save && ck_hits && any_contact();
+            const bool save_in_g2p = save && save_in_g2p_env && !g2p_pipe;                  // the save rides in k_g2p's launch (SMAC_SAVE_IN_G2P=0: own kernel)
+            if (save) {
                 ck_has_hits[f] = keep_hits ? 1 : 0;
-                hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f),
-                                   keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr, ck_hit_cap);
-                prof_end();
+                if (!save_in_g2p) {
+                    prof_begin(K_CKPT);
+                    hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f),
+                                       keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr, ck_hit_cap);
+                    prof_end();
+                }
                 ck_epoch[f] = e;
                 ck_gen[f] = config_gen;
                 vin_clean = true;
@@ -1604,8 +1617,17 @@ template <class R> struct Sim final : ISim {
                 if (g2p_pipe) {
                     const int per = (D.nchunks + 7) / 8, J = per < g2p_pipe ? per : g2p_pipe;
                     hipLaunchKernelGGL(k_g2p_pipe<R>, dim3(8 * J), dim3(BLOCK), 0, stream, D, f);
+                } else if (save_in_g2p) {
+                    DevSim<R> Dg = D;
+                    Dg.save_ck = ck_slot(f);
+                    Dg.save_hits = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
+                    Dg.save_nhits = keep_hits ? ck_nhits + f : (int*)nullptr;
+                    Dg.save_hit_cap = ck_hit_cap;
+                    Dg.save_blocks = (ngrid_blocks() + 7) & ~7;                              // (a multiple of 8: the chunk -> XCD dealing of the g2p part stays aligned)
+                    hipLaunchKernelGGL((k_g2p<R, true>), dim3(Dg.save_blocks + nchunk_blocks()), dim3(BLOCK), 0, stream, Dg, f);
                 } else
-                    hipLaunchKernelGGL(k_g2p<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                    hipLaunchKernelGGL((k_g2p<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                nhits_zero_frame = f + 1;                                                    // every form of k_g2p leaves the next frame's hit counter empty
                 prof_end();
             }
             frame_epoch[f + 1] = e;
@@ -1627,6 +1649,8 @@ template <class R> struct Sim final : ISim {
     // p2g.grad launch of substep f also does the G2P adjoint of substep f - 1 - its forward grid is restored first - and the call for f - 1
     // resumes at the slab reduction.  SMAC_FUSED_PG=0 keeps the two kernels apart.
     int fused_pg_env = getenv("SMAC_FUSED_PG") ? atoi(getenv("SMAC_FUSED_PG")) : 1;
+    int save_in_g2p_env = getenv("SMAC_SAVE_IN_G2P") ? atoi(getenv("SMAC_SAVE_IN_G2P")) : 1;
+    int nhits_zero_frame = -1;           // forward frame whose hit counter is known to be empty (k_g2p<R, true> of the frame before emptied it)
     int bwd_hint = -1;                   // frame the caller will reverse next (-1: unknown)
     int g2p_done_frame = -1;             // substep whose restore + g2p.grad already ran inside the previous call
     bool g2p_done_paz = false;           // ... and whether its adjoint frame started from zero
@@ -1650,6 +1674,8 @@ template <class R> struct Sim final : ISim {
         int rc;
         ++launch_counter;
         if ((rc = need_grad())) return rc;
+        if (!direct_bwd) D.nhits = d_nhits;  // (the backward pass uses one counter; the forward pass re-binds and re-empties its pair)
+        nhits_zero_frame = -1;
         if (phase <= 0 && !bwd_since_fwd) {                 // first backward substep after a forward pass: a drifted epoch is repaired (or reported) now
             if ((rc = check_drift())) return rc;
             bwd_since_fwd = true;

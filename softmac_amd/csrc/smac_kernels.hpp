@@ -1438,6 +1438,36 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad(DevSim<R> D) {
     D.ain[cell] = grid_op_node_adjoint(D, in, i, j, k, g);
 }
 
+// The same, with the forward grid of the NEXT substep of the sweep (the one before this in time) restored from its checkpoint by the second half of the
+// launch (k_grid_restore's work).  That grid goes to the OTHER of two buffer sets - this substep's reduction and contact adjoint still read the
+// current one - and the fused backward step that follows gathers grid_v_out from there; then the sets change roles.  The hit list is not copied:
+// the contact adjoint of that substep walks the filed list in place.  One launch and 9 us of waiting for memory less per backward substep.
+template <class R> struct GridSet { Vec4<R> *vin, *vmix, *vout, *aout; };
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, GridSet<R> nx, const Vec4<R>* ck) {
+    const int half = (int)(gridDim.x >> 1);
+    if ((int)blockIdx.x < half) {
+        int b, l, i, j, k;
+        size_t cell;
+        if (!active_cell(D, b, l, cell, i, j, k)) return;
+        Vec4<R> acc = D.aout[cell];
+        const Vec4<R> in = D.vin[cell];
+        slab_reduce(D, b, l, acc);
+        if (D.any_contact) D.aout[cell] = acc;
+        R g[3] = {acc.x, acc.y, acc.z};
+        D.ain[cell] = grid_op_node_adjoint(D, in, i, j, k, g);
+    } else {
+        const int a = ((int)blockIdx.x - half) * 4 + (int)(threadIdx.x >> 6);
+        if (a >= D.nactive) return;
+        const int l = threadIdx.x & 63;
+        const size_t cell = (size_t)D.active[a] * 64 + l;
+        const Vec4<R>* src = ck + (size_t)a * 192 + l;
+        const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+        nx.vin[cell] = src[0]; nx.vmix[cell] = src[64]; nx.vout[cell] = src[128];
+        nx.aout[cell] = z;                               // g2p.grad's drifted lanes add to it
+    }
+}
+
 // Adjoint of grid_op_mixed4 / mixed3 / mixed2 for the listed particles.  One hit = one group of 32 lanes:
 // every lane of the group recomputes the (cheap) shared forward quantities, and the 19 forward-mode
 // directions of collide_mixed's adjoint (p_pos3, p_v3, state13) run in 19 different lanes instead of 19

@@ -3,6 +3,9 @@
 //
 //   grid   : cells grouped in 4x4x4 blocks, block-major:  cell = block*64 + (lx*16 + ly*4 + lz)
 //            -> one block = 64 consecutive scalars = one 256-B wave access per field
+//   ranks  : a particle that is still in the cell of the previous binning KEEPS its rank there (a bit of the cell's 15-bit occupancy word,
+//            claimed with one atomicOr); newcomers take the lowest free ranks, then the overflow ranks.  A re-sort therefore moves most
+//            particles by a few slots only (bins shift, ranks do not), and the row moves of the frame stay nearly coalesced.
 //   sort   : counting sort with key = block*KMAX + min(rank_in_cell, KMAX-1).  All particles of one
 //            bin live in DIFFERENT cells, so the 64 lanes of a wave scatter to (mostly) distinct
 //            nodes: LDS / global float atomics do not serialise on one address.  Inside a bin the
@@ -30,12 +33,17 @@ __host__ __device__ __forceinline__ size_t cell_of(int nb, int i, int j, int k) 
     return (size_t)block_of(nb, i, j, k) * 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
 }
 
-// pass 1: rank of each particle inside its cell; key; (rank, local cell) packed for pass 2
+// per cell, one packed word: bits 0..14 = ranks claimed by particles that stayed in the cell, bits 16.. = number of newcomers
+constexpr unsigned RANK_BITS = (1u << (KMAX - 1)) - 1u;
+// per particle slot of an epoch: (cell << 5) | min(rank, 31) at the time of its binning
+__host__ __device__ __forceinline__ int cellrank_pack(int cell, int r) { return (int)(((unsigned)cell << 5) | (unsigned)(r < 31 ? r : 31)); }
+
+// pass 1: claim a rank in the particle's cell (see "ranks" above); the cell and the claim go to pass 2.
 // Also records the largest velocity component (float bits of a non-negative value order like unsigned ints): the
 // host turns it into the number of substeps the binning stays valid for.
 template <class R>
 __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, const R* v1, const R* v2, int N, int n, int nb,
-                            R inv_dx, int* cell_count, int* key_out, int* slot_out, float* vmax_part) {
+                            R inv_dx, int* cell_count, int* cell_out, int* tag_out, float* vmax_part, const int* cellrank_old) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     float vm = 0.f;
     if (p < N) {
@@ -62,14 +70,34 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, 
         int v = pos_base(x[d], n);                       // the base of make_stencil_pos
         b[d] = v < 0 ? 0 : (v > n - 3 ? n - 3 : v);
     }
-    const size_t cell = cell_of(nb, b[0], b[1], b[2]);
-    const int r = atomicAdd(cell_count + cell, 1);
-    key_out[p] = (int)(cell >> 6) * KMAX + (r < KMAX - 1 ? r : KMAX - 1);
-    slot_out[p] = (r << 6) | (int)(cell & 63);
+    const int cell = (int)cell_of(nb, b[0], b[1], b[2]);
+    int tag;
+    const int cr = cellrank_old ? cellrank_old[p] : -1;
+    if (cr >= 0 && (int)((unsigned)cr >> 5) == cell && (cr & 31) < KMAX - 1) {
+        tag = cr & 31;                                   // stayed: keeps its rank (two stayers of a cell never held the same one)
+        atomicOr((unsigned*)cell_count + cell, 1u << tag);
+    } else {
+        tag = 16 + (int)(atomicAdd((unsigned*)cell_count + cell, 1u << 16) >> 16);   // newcomer number w (also: ranks beyond the bins, first binning)
+    }
+    cell_out[p] = cell;
+    tag_out[p] = tag;
+}
+
+// ranks of a cell from its packed word: the newcomers take the lowest free ranks below KMAX-1, the rest overflow
+__device__ __forceinline__ void cell_ranks(unsigned cc, unsigned& occ, int& over) {
+    const unsigned stay = cc & RANK_BITS;
+    const int narr = (int)(cc >> 16);
+    unsigned fb = ~stay & RANK_BITS;
+    const int nfree = __popc(fb);
+    const int fill = narr < nfree ? narr : nfree;
+    unsigned taken = 0;
+    for (int i = 0; i < fill; ++i) { const unsigned low = fb & (0u - fb); taken |= low; fb ^= low; }
+    occ = stay | taken;
+    over = narr - fill;
 }
 
 // pass 1b, one wave per block: bin sizes and, per bin, the set of cells that own a particle of that rank
-// (bit c of mask[block*KMAX + r] <=> cell c holds more than r particles).  A particle's slot inside its bin is
+// (bit c of mask[block*KMAX + r] <=> cell c holds a particle of rank r).  A particle's slot inside its bin is
 // the number of lower cells in the mask; the overflow bin (rank >= KMAX-1) uses a prefix sum of the excess counts.
 __global__ void k_bin_masks(int nblocks, const int* cell_count, int* bin_count, unsigned long long* mask, int* over_prefix,
                             const float* vmax_part, int nparts, float* vmax_out) {
@@ -88,16 +116,18 @@ __global__ void k_bin_masks(int nblocks, const int* cell_count, int* bin_count, 
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= nblocks) return;
     const int lane = threadIdx.x & 63;
-    const int c = cell_count[(size_t)b * 64 + lane];
-    if (__ballot(c > 0) == 0ull) {
+    const unsigned cc = (unsigned)cell_count[(size_t)b * 64 + lane];
+    if (__ballot(cc != 0u) == 0ull) {
         if (lane < KMAX) bin_count[b * KMAX + lane] = 0;
         return;
     }
+    unsigned occ;
+    int over;
+    cell_ranks(cc, occ, over);
     for (int r = 0; r < KMAX - 1; ++r) {
-        const unsigned long long m = __ballot(c > r);
+        const unsigned long long m = __ballot((occ >> r) & 1u);
         if (lane == 0) { mask[b * KMAX + r] = m; bin_count[b * KMAX + r] = __popcll(m); }
     }
-    const int over = c > KMAX - 1 ? c - (KMAX - 1) : 0;
     int incl = over;
     for (int d = 1; d < 64; d <<= 1) {
         const int o = __shfl_up(incl, d, 64);
@@ -107,18 +137,31 @@ __global__ void k_bin_masks(int nblocks, const int* cell_count, int* bin_count, 
     if (lane == 63) bin_count[b * KMAX + KMAX - 1] = incl;
 }
 
-// pass 2 (after an exclusive scan of bin_count): destination index + composed original id
-__global__ void k_sort_dest(int N, const int* key, const int* slot, const int* bin_start, const unsigned long long* mask,
-                            const int* over_prefix, const int* orig_old, int* dest, int* orig_new) {
+// pass 2 (after an exclusive scan of bin_count): final rank, destination index, composed original id, (cell, rank) of the new slot
+__global__ void k_sort_dest(int N, const int* cell_in, const int* tag_in, const int* cell_count, const int* bin_start, const unsigned long long* mask,
+                            const int* over_prefix, const int* orig_old, int* dest, int* orig_new, int* cellrank_new) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
-    const int k = key[p], r = slot[p] >> 6, cl = slot[p] & 63;
+    const int cell = cell_in[p], tag = tag_in[p], cl = cell & 63, blk = cell >> 6;
+    int r;
+    if (tag < KMAX - 1) r = tag;
+    else {
+        const int w = tag - 16;
+        unsigned fb = ~((unsigned)cell_count[cell]) & RANK_BITS;
+        const int nfree = __popc(fb);
+        if (w < nfree) {
+            for (int i = 0; i < w; ++i) fb &= fb - 1u;
+            r = __ffs((int)fb) - 1;
+        } else r = (KMAX - 1) + (w - nfree);
+    }
+    const int k = blk * KMAX + (r < KMAX - 1 ? r : KMAX - 1);
     int pos;
     if (r < KMAX - 1) pos = __popcll(mask[k] & ((1ull << cl) - 1ull));
-    else pos = over_prefix[(size_t)(k / KMAX) * 64 + cl] + (r - (KMAX - 1));
+    else pos = over_prefix[(size_t)blk * 64 + cl] + (r - (KMAX - 1));
     const int q = bin_start[k] + pos;
     dest[p] = q;
     orig_new[q] = orig_old ? orig_old[p] : p;
+    if (cellrank_new) cellrank_new[q] = cellrank_pack(cell, r);
 }
 
 // Host IO: f64 AOS arrays in the caller's particle order <-> component rows of a frame in the order of an epoch

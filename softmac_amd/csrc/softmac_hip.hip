@@ -161,6 +161,7 @@ template <class R> struct Sim final : ISim {
     // ---- epochs: one per re-sort.  Epoch 0 is the identity order of user-provided frames.
     struct Epoch {
         int* orig = nullptr;        // sorted slot -> original id (device)
+        int* cellrank = nullptr;    // sorted slot -> (cell << 5 | rank in the cell) at this binning: the next re-sort keeps the ranks of particles that stayed (smac_sort.hpp)
         int* inv = nullptr;         // original id -> sorted slot (device, lazy)
         bool inv_valid = false;
         Chunk* chunks = nullptr;
@@ -243,7 +244,7 @@ template <class R> struct Sim final : ISim {
         }
 #endif
         comm_destroy();
-        hipFree(D.S); hipFree(D.A); hipFree(grid_block); hipFree(D.prim_state); hipFree(D.prim_grad);
+        hipFree(D.S); hipFree(D.A); hipFree(grid_block); hipFree(grid_alt); hipFree(D.prim_state); hipFree(D.prim_grad);
         hipFree(D.ext_f); hipFree(D.action); hipFree(D.action_grad); hipFree(d_control_idx); hipFree(d_counter);
         hipFree(action_buf); hipFree(action_buf_grad); hipFree(scratch);
         for (auto& e : epochs) free_epoch(e);
@@ -860,20 +861,20 @@ template <class R> struct Sim final : ISim {
 
     // ---- epochs / sorting ------------------------------------------------------------------
     static void free_epoch(Epoch& e) {
-        hipFree(e.orig); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
+        hipFree(e.orig); hipFree(e.cellrank); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
         hipFree(e.block_slot);
-        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
+        e.orig = e.cellrank = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
         e.chunks = nullptr;
         e.live = false;
     }
     // a dropped epoch hands its device buffers to the pool (kernels still using them are ahead of any new writer on the stream)
     void retire_epoch(Epoch& e) {
         Epoch b;
-        b.orig = e.orig; b.inv = e.inv; b.chunks = e.chunks; b.active = e.active;
+        b.orig = e.orig; b.cellrank = e.cellrank; b.inv = e.inv; b.chunks = e.chunks; b.active = e.active;
         b.block_chunk_start = e.block_chunk_start; b.block_chunks = e.block_chunks; b.block_active = e.block_active;
         b.block_slot = e.block_slot;
         epoch_pool.push_back(std::move(b));
-        e.orig = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
+        e.orig = e.cellrank = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
         e.chunks = nullptr;
         e.inv_valid = false;
         e.live = false;
@@ -883,13 +884,14 @@ template <class R> struct Sim final : ISim {
         if (!epoch_pool.empty()) {
             Epoch b = std::move(epoch_pool.back());
             epoch_pool.pop_back();
-            ep.orig = b.orig; ep.inv = b.inv; ep.chunks = b.chunks; ep.active = b.active;
+            ep.orig = b.orig; ep.cellrank = b.cellrank; ep.inv = b.inv; ep.chunks = b.chunks; ep.active = b.active;
             ep.block_chunk_start = b.block_chunk_start; ep.block_chunks = b.block_chunks; ep.block_active = b.block_active;
             ep.block_slot = b.block_slot;
             ep.inv_valid = false;
             return SMAC_OK;
         }
         HIP_TRY(hipMalloc((void**)&ep.orig, D.Npad * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.cellrank, D.Npad * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.chunks, chunk_capacity() * sizeof(Chunk)));
         HIP_TRY(hipMalloc((void**)&ep.active, ((size_t)nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.block_chunk_start, (nblocks + 1) * sizeof(int)));
@@ -975,6 +977,7 @@ template <class R> struct Sim final : ISim {
     // `aos` (reset): the frame's x and v rows are already there in the caller's order; after the binning ALL rows are written straight from the
     // caller's (N, cols) array in the new order (192 contiguous bytes per particle) instead of being moved row by row - an episode's first
     // binning then costs no scattered frame move (411 us at 1M particles from a random order) and no copy-back.
+    int stable_ranks = getenv("SMAC_STABLE_RANKS") ? atoi(getenv("SMAC_STABLE_RANKS")) : 1;   // 0: every re-sort hands the ranks out afresh (round 2)
     int sort_frame(int f, bool read_drift = false, bool allow_repair = true, const double* aos = nullptr, int cols = 0) {
         const int e_old = frame_epoch[f];
         gc_epochs();
@@ -986,16 +989,17 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(d_bin + nbins, 0, sizeof(int), stream));
         hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + rowbase(1, D.Npad)),
                            (const R*)(Sf + rowbase(2, D.Npad)), (const R*)(Sf + rowbase(3, D.Npad)), (const R*)(Sf + rowbase(4, D.Npad)),
-                           (const R*)(Sf + rowbase(5, D.Npad)), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax_part);
+                           (const R*)(Sf + rowbase(5, D.Npad)), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax_part,
+                           (const int*)((e_old > 0 && stable_ranks && D.G <= ((size_t)1 << 26)) ? epochs[e_old].cellrank : nullptr));
         hipLaunchKernelGGL(k_bin_masks, dim3((nblocks + 3) / 4), dim3(BLOCK), 0, stream, nblocks, (const int*)d_cell_count, d_bin,
                            d_bin_mask, d_over_prefix, (const float*)d_vmax_part, nblk(D.N), (float*)d_vmax);
         int rc = scan(d_bin, d_bin_start, nbins + 1);
         if (rc) return rc;
         Epoch ep;
         if ((rc = epoch_buffers(ep))) return rc;
-        hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot,
+        hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot, (const int*)d_cell_count,
                            (const int*)d_bin_start, (const unsigned long long*)d_bin_mask, (const int*)d_over_prefix,
-                           (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig);
+                           (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig, D.G <= ((size_t)1 << 26) ? ep.cellrank : (int*)nullptr);
         if (aos) {
             auto rows = [&](int c0, int cnt, int offset, int ident) {
                 hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, aos, cols, offset, cnt, (const int*)ep.orig,
@@ -1555,6 +1559,7 @@ template <class R> struct Sim final : ISim {
         ++launch_counter;
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
+        normalize_grid_set();
         // the hit counters of even and odd frames alternate (k_g2p<R, true> empties the next frame's while its save part still reads this one's)
         D.nhits = d_nhits + ((f & 1) ? 4 : 0);
         D.nhits_next = d_nhits + ((f & 1) ? 0 : 4);
@@ -1650,6 +1655,49 @@ template <class R> struct Sim final : ISim {
     // resumes at the slab reduction.  SMAC_FUSED_PG=0 keeps the two kernels apart.
     int fused_pg_env = getenv("SMAC_FUSED_PG") ? atoi(getenv("SMAC_FUSED_PG")) : 1;
     int save_in_g2p_env = getenv("SMAC_SAVE_IN_G2P") ? atoi(getenv("SMAC_SAVE_IN_G2P")) : 1;
+    // Restore-ahead (k_reduce_grid_grad_ahead): inside the fused batched sweep the forward grid of substep f - 1 is restored by the launch that
+    // reduces substep f's grid adjoint, into the second of two buffer sets {grid_in, grid_mixed, grid_out, grid_out.grad}; the sets change roles after
+    // the fused particle kernel.  Outside the sweep everything lives in set 0 (normalize_grid_set).  SMAC_RESTORE_AHEAD=0: k_grid_restore as before.
+    int restore_ahead_env = getenv("SMAC_RESTORE_AHEAD") ? atoi(getenv("SMAC_RESTORE_AHEAD")) : 1;
+    Vec4<R>* grid_alt = nullptr;         // set 1: 4 fields
+    bool grid_alt_tried = false;
+    int grid_set = 0;                    // the set D.vin / vmix / vout / aout point to
+    int ahead_frame = -1;                // frame whose forward grid the last reduction launch restored into the OTHER set
+    int hits_in_place_frame = -1;        // frame whose contact adjoint walks the filed hit list in place (its restore did not copy it)
+    GridSet<R> grid_set_ptrs(int which) const {
+        if (which == 0) return GridSet<R>{grid_block, grid_block + D.G, grid_block + 2 * D.G, grid_block + 5 * D.G};
+        return GridSet<R>{grid_alt, grid_alt + D.G, grid_alt + 2 * D.G, grid_alt + 3 * D.G};
+    }
+    void use_grid_set(int which) {
+        const GridSet<R> g = grid_set_ptrs(which);
+        D.vin = g.vin; D.vmix = g.vmix; D.vout = g.vout; D.aout = g.aout;
+        grid_set = which;
+    }
+    bool grid_alt_ready() {
+        if (!grid_alt && !grid_alt_tried) {
+            grid_alt_tried = true;
+            size_t free_b = 0, total_b = 0;
+            const size_t bytes = 4 * D.G * sizeof(Vec4<R>);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4 || hipMalloc((void**)&grid_alt, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                grid_alt = nullptr;
+            } else if (hipMemsetAsync(grid_alt, 0, bytes, stream) != hipSuccess) {
+                hipFree(grid_alt);
+                grid_alt = nullptr;
+            }
+        }
+        return grid_alt != nullptr;
+    }
+    // back to set 0 (whose contents are then stale: the flags say so).  Called wherever the fused sweep is not being continued.
+    void normalize_grid_set() {
+        ahead_frame = -1;
+        hits_in_place_frame = -1;
+        if (grid_set != 0) {
+            use_grid_set(0);
+            vin_clean = false;
+            adj_grid_clean = false;
+        }
+    }
     int nhits_zero_frame = -1;           // forward frame whose hit counter is known to be empty (k_g2p<R, true> of the frame before emptied it)
     int bwd_hint = -1;                   // frame the caller will reverse next (-1: unknown)
     int g2p_done_frame = -1;             // substep whose restore + g2p.grad already ran inside the previous call
@@ -1685,8 +1733,10 @@ template <class R> struct Sim final : ISim {
         const int e = frame_epoch[f];
         if (g2p_done_frame >= 0 && (g2p_done_frame != f || phase >= 0)) {
             g2p_done_frame = -1;
+            normalize_grid_set();
             REQUIRE(false, "substep_grad: the batched backward sweep was interrupted (its next substep had been started)");
         }
+        if (!(phase < 0 && g2p_done_frame == f)) normalize_grid_set();
         if (phase < 0 && g2p_done_frame == f) {           // restore + g2p.grad of this substep ran inside the previous call (k_p2g_g2p_grad)
             g2p_done_frame = -1;
             if ((rc = stage_ext_f_grad(ext_f_grad))) return rc;
@@ -1695,7 +1745,13 @@ template <class R> struct Sim final : ISim {
             pending_adj_zero = g2p_done_paz;
             D.cur_frame = f;
             prof_begin(K_REDUCE);
-            hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+            if (restore_ahead_env && can_fuse_prev(f, e, phase, action_grad_out) && grid_alt_ready()) {
+                // this substep will hand over to substep f - 1 inside k_p2g_g2p_grad: its forward grid is restored by THIS launch, into the other set
+                hipLaunchKernelGGL(k_reduce_grid_grad_ahead<R>, dim3(2 * ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_set_ptrs(1 - grid_set),
+                                   (const Vec4<R>*)ck_slot(f - 1));
+                ahead_frame = f - 1;
+            } else
+                hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
             prof_end();
         } else if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
@@ -1779,11 +1835,16 @@ template <class R> struct Sim final : ISim {
         }
         if ((phase < 0 || phase == 1) && D.nchunks > 0 && D.collision_type == CONTACT_MIXED && any_contact()) {   // :362-363, 389-393
             prof_begin(K_CONTACT_GRAD);
+            DevSim<R> Dc = D;
+            if (hits_in_place_frame == f) {                // (restored ahead: the hit list was not copied out of the checkpoint)
+                Dc.hits = ck_hits + (size_t)f * ck_hit_cap;
+                Dc.nhits = ck_nhits + f;
+            }
             if (D.cloth.present) {
-                if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
-                else hipLaunchKernelGGL((k_contact_grad<R, false, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
-            } else if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
-            else hipLaunchKernelGGL((k_contact_grad<R, false, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, D, f);
+                if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+                else hipLaunchKernelGGL((k_contact_grad<R, false, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+            } else if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+            else hipLaunchKernelGGL((k_contact_grad<R, false, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
             prof_end();
         }
         if (phase < 0 || phase == 2) {
@@ -1806,11 +1867,19 @@ template <class R> struct Sim final : ISim {
                 REQUIRE(Af_prev, kPoolMessage);
                 const bool paz_prev = adj_epoch[f - 1] < 0;
                 const bool have_hits = ck_has_hits[f - 1] && D.any_contact && D.collision_type == CONTACT_MIXED;
-                prof_begin(K_CKPT);
-                hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f - 1),
-                                   have_hits ? (const Hit*)(ck_hits + (size_t)(f - 1) * ck_hit_cap) : (const Hit*)nullptr,
-                                   have_hits ? (const int*)(ck_nhits + (f - 1)) : (const int*)nullptr, 0);
-                prof_end();
+                const bool ahead = ahead_frame == f - 1;
+                if (ahead) {
+                    use_grid_set(1 - grid_set);            // the reduction launch of this call restored frame f - 1 there; nothing below reads frame f's grid
+                    hits_in_place_frame = have_hits ? f - 1 : -1;
+                    ahead_frame = -1;
+                } else {
+                    prof_begin(K_CKPT);
+                    hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f - 1),
+                                       have_hits ? (const Hit*)(ck_hits + (size_t)(f - 1) * ck_hit_cap) : (const Hit*)nullptr,
+                                       have_hits ? (const int*)(ck_nhits + (f - 1)) : (const int*)nullptr, 0);
+                    prof_end();
+                    hits_in_place_frame = -1;
+                }
                 DevSim<R> D2 = D;
                 D2.Af_prev = Af_prev;
                 prof_begin(K_P2G_G2P_GRAD);
@@ -1843,6 +1912,7 @@ template <class R> struct Sim final : ISim {
                 for (int i = 0; i < 3 * D.n_control; ++i) action_grad_out[i] = (double)tmp[i];
             }
             adj_release(f + 2);                    // rolling storage: the sweep has passed frame f+2 two substeps ago
+            if (g2p_done_frame < 0) normalize_grid_set();   // the sweep does not continue inside this epoch: back to buffer set 0
             if (direct_bwd) {
                 D.ck = nullptr; D.hits = d_hits; D.nhits = d_nhits;
                 direct_bwd = false;

@@ -18,19 +18,22 @@ from softmac_amd import scenes
 pytestmark = pytest.mark.gpu
 
 
-def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=64, want_zone=False):
-    old = os.environ.get("SMAC_FUSED_PG")
-    os.environ["SMAC_FUSED_PG"] = "1" if fused else "0"
+def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=64, want_zone=False, env=None):
+    """`env`: further switches the library reads when the handle is created (SMAC_RESTORE_AHEAD, SMAC_SAVE_IN_G2P ...)"""
+    env = dict(env or {}, SMAC_FUSED_PG="1" if fused else "0")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         cfg, env_dt, state, specs, s13 = scenes.s_grip(n, grid, max_steps=n_sub + 4, precision="float32")
         cfg.sort_interval = sort_interval
         pst = [[np.concatenate([s[:3] + s[7:10] * cfg.dt * f, s[3:]]) for s in s13] for f in range(n_sub + 4)]
         sim, prm = H.build_engine(cfg, env_dt, specs, pst)
     finally:
-        if old is None:
-            os.environ.pop("SMAC_FUSED_PG", None)
-        else:
-            os.environ["SMAC_FUSED_PG"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     N = cfg.n_particles
     sim.reset(state)
     sim.run_substeps(0, n_sub)
@@ -97,3 +100,41 @@ def test_fused_backward_step_is_actually_taken():
     b, pb, cb = _rollout(False, 12, (12,), 1000)
     assert ca.get("p2g_g2p_grad", (0, 0))[1] == 11 and cb.get("p2g_g2p_grad", (0, 0))[1] == 0
     assert ca.get("p2g_grad", (0, 0))[1] == 1 and cb.get("p2g_grad", (0, 0))[1] == 12
+
+
+@pytest.mark.parametrize("switch", ["SMAC_RESTORE_AHEAD", "SMAC_SAVE_IN_G2P"])
+def test_ride_along_launches_change_nothing(switch):
+    """Round 3 moved two small grid kernels into their neighbours' launches: the checkpoint save into k_g2p (SMAC_SAVE_IN_G2P) and, inside the fused
+    sweep, the next substep's checkpoint restore into the grid-adjoint reduction, on a second set of grid buffers whose roles alternate
+    (SMAC_RESTORE_AHEAD; the contact adjoint then walks the filed hit list in place).  Same arithmetic either way: the sweeps with the switch off
+    and on must agree like two handles of one path do (the bound of test_fused_backward_step_equals_the_two_kernels), across two re-sorts, with
+    seeds in the middle of the window, contact in every substep."""
+    n_sub, seeds, sort_interval = 24, (24, 13, 12), 9
+    a, pa, ca = _rollout(True, n_sub, seeds, sort_interval, env={switch: "1"})
+    b, pb, cb, ill = _rollout(True, n_sub, seeds, sort_interval, want_zone=True, env={switch: "0"})
+    c, pc, cc = _rollout(True, n_sub, seeds, sort_interval, env={switch: "0"})              # a second handle of the SAME configuration: the path's own noise
+    assert ca.get("p2g_g2p_grad", (0, 0))[1] > 10 and cb.get("p2g_g2p_grad", (0, 0))[1] == ca["p2g_g2p_grad"][1]
+    if switch == "SMAC_RESTORE_AHEAD":                      # (profile key "grid_checkpoint" = save and restore launches)
+        assert ca.get("grid_checkpoint", (0, 0))[1] < cb.get("grid_checkpoint", (0, 0))[1]
+    N = len(ill)
+    da, dc = np.zeros(N), np.zeros(N)
+    for f in sorted(b):
+        scale = np.abs(b[f]).max()
+        assert scale > 0
+        da = np.maximum(da, np.abs(a[f] - b[f]).max(axis=1) / scale)
+        dc = np.maximum(dc, np.abs(c[f] - b[f]).max(axis=1) / scale)
+    # Three handles = three particle orders = three f32 forward passes a rounding apart, and over 24 substeps a particle that lands on the other side
+    # of a branch of the reference's function (yield clip, contact band) changes its own adjoint by O(1e-4) and those of its stencil neighbours by
+    # less: the same 5.7e-5 on the same neighbourhood has shown up in either pairing, with the switch and without (profiles/scripts/r03_u.sh,
+    # r03_v.sh: "on vs off" 5.8e-6 and 5.7e-5 in two sessions, "off vs off" 1.4e-6).  What a ride-along launch could break is the grid of a whole
+    # frame, i.e. every particle: the comparison is therefore on the 99th percentile, with the kink neighbourhood (the 1 % above it) held to 2e-4.
+    q99 = lambda d: float(np.quantile(d[~ill], 0.99))
+    worst, noise = q99(da), q99(dc)
+    print(f"\n[{switch}] adjoint-frame difference on vs off: 99th percentile {worst:.1e}, max {da[~ill].max():.1e}; off vs off (two handles): {noise:.1e}, "
+          f"max {dc[~ill].max():.1e}; clamp zone {da[ill].max() if ill.any() else 0:.1e} / {dc[ill].max() if ill.any() else 0:.1e}")
+    assert noise < 2e-5 and worst < max(10 * noise, 5e-6)
+    k = max(1, int(1.2e-4 * N))
+    assert float(np.sort(da[~ill])[-(k + 1)]) < 2e-4 and float(np.sort(dc[~ill])[-(k + 1)]) < 2e-4
+    assert max(da.max(), dc.max()) < 1e-1
+    assert (not ill.any()) or max(da[ill].max(), dc[ill].max()) < H.F32_TOL["clamp"]
+    assert np.abs(pb).max() > 0 and H.rel_err(pa, pb) < max(10 * H.rel_err(pc, pb), 2e-6)

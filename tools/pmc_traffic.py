@@ -15,7 +15,9 @@ NAMES = {"k_p2g<float, true, false>": "p2g", "k_p2g_grad<float, false, true>": "
          "k_grid_op<float, false>": "grid_op", "k_grid_op_grad<float, false>": "grid_op_grad", "k_clear_active<float>": "clear_grid",
          "k_contact_hits<float>": "contact", "k_contact_grad<float>": "contact_grad", "k_reduce_aout<float>": "reduce_agvout",
          "k_grid_save<float>": "grid_checkpoint", "k_p2g_g2p_grad<float, false>": "p2g_g2p_grad", "k_reduce_grid_grad<float>": "reduce_agvout",
-         "k_contact_hits<float, false>": "contact", "k_contact_grad<float, true, false>": "contact_grad", "k_grid_restore<float>": "grid_restore"}
+         "k_contact_hits<float, false>": "contact", "k_contact_grad<float, true, false>": "contact_grad", "k_grid_restore<float>": "grid_restore",
+         # round 3: the checkpoint save rides in k_g2p's launch, the next restore in the grid-adjoint reduction's
+         "k_g2p<float, false>": "g2p", "k_g2p<float, true>": "g2p", "k_reduce_grid_grad_ahead<float>": "reduce_agvout"}
 
 
 def mean_by_kernel(path, counter):

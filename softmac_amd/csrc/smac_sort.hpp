@@ -164,6 +164,15 @@ __global__ void k_sort_dest(int N, const int* cell_in, const int* tag_in, const 
     if (cellrank_new) cellrank_new[q] = cellrank_pack(cell, r);
 }
 
+// particles the last binning moved by more than `farther_than` slots (smac_get_param "resort_moved" / "resort_far": on request only, one atomic per workgroup)
+__global__ void k_count_moved(int N, const int* dest, unsigned long long* out, int farther_than) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dd = p < N ? dest[p] - p : 0;
+    const int moved = (dd > farther_than || dd < -farther_than) ? 1 : 0;
+    const int n = __syncthreads_count(moved);
+    if (threadIdx.x == 0 && n) atomicAdd(out, (unsigned long long)n);
+}
+
 // Host IO: f64 AOS arrays in the caller's particle order <-> component rows of a frame in the order of an epoch
 // (orig[q] = caller's id of the particle in slot q; nullptr = identity).  `ident` 1: the rows hold F - I, the host sees F;
 // `ident` 2: position rows (pos_of<R>: fixed point in f32 mode), padding slots sit at the middle of the box.

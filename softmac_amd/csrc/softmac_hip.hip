@@ -977,6 +977,7 @@ template <class R> struct Sim final : ISim {
     // `aos` (reset): the frame's x and v rows are already there in the caller's order; after the binning ALL rows are written straight from the
     // caller's (N, cols) array in the new order (192 contiguous bytes per particle) instead of being moved row by row - an episode's first
     // binning then costs no scattered frame move (411 us at 1M particles from a random order) and no copy-back.
+    int resorts_done = 0;
     int stable_ranks = getenv("SMAC_STABLE_RANKS") ? atoi(getenv("SMAC_STABLE_RANKS")) : 1;   // 0: every re-sort hands the ranks out afresh (round 2)
     int sort_frame(int f, bool read_drift = false, bool allow_repair = true, const double* aos = nullptr, int cols = 0) {
         const int e_old = frame_epoch[f];
@@ -1013,6 +1014,7 @@ template <class R> struct Sim final : ISim {
                                D.Npad, (int)NCOMP);
             HIP_TRY(hipMemcpyAsync(Sf, tmp_frame, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
         }
+        ++resorts_done;
         // block info, chunk list, active list
         HIP_TRY(hipMemsetAsync(d_active_flag, 0, (nblocks + 1) * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_block_chunks, 0, (nblocks + 1) * sizeof(int), stream));
@@ -1216,7 +1218,18 @@ template <class R> struct Sim final : ISim {
         else if (!strcmp(name, "plasticity")) *value = (double)D.mat.plast;
         else if (!strcmp(name, "yield_ratio")) *value = (double)D.mat.yield_c;
         else if (!strcmp(name, "mass_eps")) *value = (double)D.m_eps;
-        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | plasticity | yield_ratio | mass_eps)");
+        else if (!strcmp(name, "resorts")) *value = (double)resorts_done;                // re-binnings so far (the first one, at reset, included)
+        else if (!strcmp(name, "resort_moved") || !strcmp(name, "resort_far")) {         // particles the LAST re-binning moved to another slot / by more than a chunk (256 slots); counted on request
+            unsigned long long h = 0;
+            if (resorts_done > 0 && D.N > 0) {
+                HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), stream));
+                hipLaunchKernelGGL(k_count_moved, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_dest, d_counter, !strcmp(name, "resort_far") ? 256 : 0);
+                HIP_TRY(hipMemcpyAsync(&h, d_counter, sizeof(h), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
+            *value = (double)h;
+        }
+        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | exchanges | resorts | resort_moved | resort_far | cloth_hash_entries | plasticity | yield_ratio | mass_eps)");
         return SMAC_OK;
     }
     int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,

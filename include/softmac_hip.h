@@ -104,6 +104,10 @@ int smac_copy_frame(smac_handle h, int src, int dst);                         /*
 int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC);   /* get_grad :570-574 (+F,C) */
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC); /* loss kernels' `x.grad[f,i] +=` */
 int smac_clear_grads(smac_handle h);                                          /* ti.ad.clear_all_gradients() */
+/* Windowed episodes (checkpoint-every-K state frames with recompute; no reference counterpart: the reference keeps every frame resident).
+ * smac_clear_grads, except that the particle adjoint of frame `src` survives as the adjoint of frame `dst` (with its particle order): the adjoint a
+ * window's backward sweep leaves on its first frame is the seed of the window before it (softmac_amd/engine/windowed.py).  Not with rolling adjoint storage. */
+int smac_carry_grad(smac_handle h, int src, int dst);
 int smac_set_control_idx(smac_handle h, const int32_t* idx);                  /* set_control_idx :599-602 */
 /* Slab decomposition with particle MIGRATION (no reference counterpart): a handle is created with the CAPACITY
  * n_particles; a rank's live particle count changes when particles are handed to a neighbouring slab.  Frames written or

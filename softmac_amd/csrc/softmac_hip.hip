@@ -76,6 +76,7 @@ struct ISim {
     virtual int get_grad(int f, double* gx, double* gv, double* gF, double* gC) = 0;
     virtual int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) = 0;
     virtual int clear_grads() = 0;
+    virtual int carry_grad(int src, int dst) = 0;
     virtual int set_control_idx(const int32_t* idx) = 0;
     virtual int set_action_v(const double* action) = 0;
     virtual int get_action_grad(double* out) = 0;
@@ -692,6 +693,22 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMemsetAsync(D.cloth.vel_grad, 0, vs, stream));
             HIP_TRY(hipMemsetAsync(D.cloth.ext_f_grad, 0, (size_t)D.cloth.V * 3 * sizeof(double), stream));
         }
+        return SMAC_OK;
+    }
+    // clear_grads, except that the particle adjoint of frame `src` survives as the adjoint of frame `dst`, order tag included (windowed episodes)
+    int carry_grad(int src, int dst) override {
+        int rc;
+        if ((rc = need_grad()) || (rc = check_frame(src)) || (rc = check_frame(dst))) return rc;
+        REQUIRE(!rolling(), "carry_grad: not with rolling adjoint storage (smac_config.adjoint_frames)");
+        REQUIRE(g2p_done_frame < 0, "carry_grad: a batched backward sweep is in flight");
+        const int e = adj_epoch[src];
+        if (e < 0) return clear_grads();                                      // frame `src` carries no adjoint: all zero
+        if (!tmp_frame2) HIP_TRY(hipMalloc((void**)&tmp_frame2, frame_scalars() * sizeof(R)));
+        HIP_TRY(hipMemcpyAsync(tmp_frame2, adj_ptr(src), frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        if ((rc = clear_grads())) return rc;
+        HIP_TRY(hipMemcpyAsync(adj_ptr(dst), tmp_frame2, frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        adj_epoch[dst] = e;                                                   // (keeps that epoch alive: gc_epochs looks at the adjoint frames too)
+        adj_stale[dst] = 0;
         return SMAC_OK;
     }
     int set_control_idx(const int32_t* idx) override {
@@ -2645,6 +2662,7 @@ int smac_copy_frame(smac_handle h, int src, int dst) { return FWD(copy_frame(src
 int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC) { return FWD(get_grad(f, gx, gv, gF, gC)); }
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC) { return FWD(add_grad(f, gx, gv, gF, gC)); }
 int smac_clear_grads(smac_handle h) { return FWD(clear_grads()); }
+int smac_carry_grad(smac_handle h, int src, int dst) { return FWD(carry_grad(src, dst)); }
 int smac_set_control_idx(smac_handle h, const int32_t* idx) { return FWD(set_control_idx(idx)); }
 int smac_set_action(smac_handle h, const double* action) { return FWD(set_action_v(action)); }
 int smac_set_segment(smac_handle h, int n_live, int frame_shift) { return FWD(set_segment(n_live, frame_shift)); }

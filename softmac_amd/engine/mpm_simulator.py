@@ -266,6 +266,10 @@ class MPMSimulator:
     def clear_grads(self):
         self._h.call("smac_clear_grads")
 
+    def carry_grad(self, src, dst):
+        """clear_grads(), except that the particle adjoint of frame `src` survives as the adjoint of frame `dst` (engine/windowed.py)"""
+        self._h.call("smac_carry_grad", int(src), int(dst))
+
     # ------------------------------------------------------------------ control (:579-602)
     def set_action(self, action):                           # :589-592 (the device copy persists until the next set_action)
         a = _ffi.as_f64(np.asarray(action, dtype=np.float64).reshape(self.n_control, self.dim))

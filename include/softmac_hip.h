@@ -142,6 +142,10 @@ int smac_prim_set_params(smac_handle h, int prim, double friction, double softne
 int smac_prim_set_state(smac_handle h, int prim, int f_begin, int f_end, const double s13[13]);  /* set_all_states :258-260, frames [f_begin,f_end) */
 int smac_prim_get_state(smac_handle h, int prim, int f, double s13[13]);                         /* get_state :248-251 (+v,w) */
 int smac_prim_get_state_grad(smac_handle h, int prim, int f_begin, int f_end, double g13[13]);   /* sum of get_all_states_grad :262-265 over frames */
+/* A whole trajectory in one call (prescribed primitive states of an episode / a window; their adjoints frame by frame): the per-frame forms above cost
+ * a host sync each.  s13 / g13: (f_end - f_begin) x 13, frame-major. */
+int smac_prim_set_states(smac_handle h, int prim, int f_begin, int f_end, const double* s13);
+int smac_prim_get_state_grads(smac_handle h, int prim, int f_begin, int f_end, double* g13);
 int smac_prim_add_state_grad(smac_handle h, int prim, int f, const double g13[13]);              /* loss kernels' position/v/w .grad[f] += */
 int smac_prim_forward_kinematics(smac_handle h, int prim, int f);                                /* forward_kinematics :280-283 */
 int smac_prim_forward_kinematics_grad(smac_handle h, int prim, int f);                           /* forward_kinematics.grad */

@@ -90,6 +90,8 @@ struct ISim {
     virtual int prim_set_state(int prim, int f0, int f1, const double* s13) = 0;
     virtual int prim_get_state(int prim, int f, double* s13) = 0;
     virtual int prim_get_state_grad(int prim, int f0, int f1, double* g13) = 0;
+    virtual int prim_set_states(int prim, int f0, int f1, const double* s13) = 0;
+    virtual int prim_get_state_grads(int prim, int f0, int f1, double* g13) = 0;
     virtual int prim_add_state_grad(int prim, int f, const double* g13) = 0;
     virtual int prim_fk(int prim, int f) = 0;
     virtual int prim_fk_grad(int prim, int f) = 0;
@@ -2447,6 +2449,23 @@ template <class R> struct Sim final : ISim {
             for (int c = 0; c < 13; ++c) g13[c] += tmp[(size_t)f * 13 + c];
         return SMAC_OK;
     }
+    int prim_set_states(int prim, int f0, int f1, const double* s13) override {       // one state per frame of [f0, f1)
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(s13 && f0 >= 0 && f1 <= cfg.max_frames && f0 < f1, "prim_set_states: bad frame range");
+        for (int f = f0; f < f1; ++f) ck_epoch[f] = -1;
+        HIP_TRY(hipMemcpyAsync(pstate(prim) + (size_t)f0 * 13, s13, (size_t)(f1 - f0) * 13 * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));                                          // (the caller's array may go away)
+        return SMAC_OK;
+    }
+    int prim_get_state_grads(int prim, int f0, int f1, double* g13) override {
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(g13 && f0 >= 0 && f1 <= cfg.max_frames && f0 < f1, "prim_get_state_grads: bad frame range");
+        HIP_TRY(hipMemcpyAsync(g13, pgrad(prim) + (size_t)f0 * 13, (size_t)(f1 - f0) * 13 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
     int prim_add_state_grad(int prim, int f, const double* g13) override {
         int rc;
         if ((rc = check_prim(prim)) || (rc = check_frame(f))) return rc;
@@ -2712,6 +2731,8 @@ int smac_prim_set_params(smac_handle h, int prim, double friction, double softne
 int smac_prim_set_state(smac_handle h, int prim, int f0, int f1, const double s13[13]) { return FWD(prim_set_state(prim, f0, f1, s13)); }
 int smac_prim_get_state(smac_handle h, int prim, int f, double s13[13]) { return FWD(prim_get_state(prim, f, s13)); }
 int smac_prim_get_state_grad(smac_handle h, int prim, int f0, int f1, double g13[13]) { return FWD(prim_get_state_grad(prim, f0, f1, g13)); }
+int smac_prim_set_states(smac_handle h, int prim, int f0, int f1, const double* s13) { return FWD(prim_set_states(prim, f0, f1, s13)); }
+int smac_prim_get_state_grads(smac_handle h, int prim, int f0, int f1, double* g13) { return FWD(prim_get_state_grads(prim, f0, f1, g13)); }
 int smac_prim_add_state_grad(smac_handle h, int prim, int f, const double g13[13]) { return FWD(prim_add_state_grad(prim, f, g13)); }
 int smac_prim_forward_kinematics(smac_handle h, int prim, int f) { return FWD(prim_fk(prim, f)); }
 int smac_prim_forward_kinematics_grad(smac_handle h, int prim, int f) { return FWD(prim_fk_grad(prim, f)); }

@@ -151,6 +151,22 @@ class Primitive:
         else:
             self._h.call("smac_prim_set_state", self._slot, f0, f1, _ffi.dptr(st13))
 
+    def set_states_trajectory(self, f0, states):
+        """one 13-vector per frame of [f0, f0 + len(states)) in ONE transfer (an episode's or a window's prescribed trajectory)"""
+        st = _ffi.as_f64(np.asarray(states, dtype=np.float64).reshape(-1, 13))
+        if self._h is None:
+            for j in range(len(st)):
+                self._pending.append((f0 + j, f0 + j + 1, st[j].copy()))
+        else:
+            self._h.call("smac_prim_set_states", self._slot, int(f0), int(f0) + len(st), _ffi.dptr(st))
+
+    def get_states_grad_trajectory(self, f0, f1):
+        """(f1 - f0, 13): get_all_states_grad of every frame of [f0, f1) in ONE transfer"""
+        out = np.zeros((int(f1) - int(f0), 13))
+        if self._h is not None:
+            self._h.call("smac_prim_get_state_grads", self._slot, int(f0), int(f1), _ffi.dptr(out))
+        return out
+
     def get_all_states_grad(self, f):                        # :262-265
         return self._get_state_grad(int(f), int(f) + 1)
 

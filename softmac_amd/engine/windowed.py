@@ -37,10 +37,9 @@ class WindowedEpisode:
     def _upload_primitives(self, t0, n):
         if self.prim_state is None:
             return
-        for j in range(n + 1):
-            states = self.prim_state(t0 + j)
-            for m, s in zip(self.sim.primitives, states):
-                m.set_all_states(j, s)
+        traj = np.array([self.prim_state(t0 + j) for j in range(n + 1)], dtype=np.float64)     # (n + 1, primitives, 13)
+        for i, m in enumerate(self.sim.primitives):
+            m.set_states_trajectory(0, traj[:, i])
 
     @property
     def T(self):
@@ -94,6 +93,7 @@ class WindowedEpisode:
                     sim.add_grad(t - t0, **g)
             sim.run_substeps_grad(0, n)
             carried = True
+            pg = [m.get_states_grad_trajectory(0, n) for m in sim.primitives]
             for j in range(n):
-                prim_grads[t0 + j] = [m.get_all_states_grad(j) for m in sim.primitives]
+                prim_grads[t0 + j] = [g[j] for g in pg]
         return sim.get_grad_full(0), prim_grads

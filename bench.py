@@ -247,9 +247,12 @@ def env_loop_record(args, seed_gx):
         return g, (t1 - t0) + (time.perf_counter() - t2)
 
     episode(w_env)
-    g, wall = episode(n_env)
+    runs = [episode(n_env) for _ in range(max(args.repeats, 1))]     # the same statistic as `value`: the median of `repeats` identical episodes
+    walls = sorted(w for _, w in runs)
+    g, wall = runs[0][0], walls[len(walls) // 2]
     sim._h.close()
     return {"value": n_env * 10 / wall, "unit": "substeps/s", "ms_per_step": 1e3 * wall / (n_env * 10), "env_steps": n_env, "substeps_per_env_step": 10,
+            "repeats": len(runs), "ms_per_step_all": [round(1e3 * w / (n_env * 10), 5) for _, w in runs],
             "action_grad_norm": float(np.linalg.norm(g.numpy())),
             "note": "TaichiEnv.step x env_steps, then TaichiEnv.backward(), with velocity-controlled primitives (the reference's loop shape, "
                     "taichi_env.py:93-151): host orchestration per env step included, reset and the loss seed's upload not; same particles / grid / "

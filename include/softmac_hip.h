@@ -144,6 +144,7 @@ int smac_prim_get_state(smac_handle h, int prim, int f, double s13[13]);        
 int smac_prim_get_state_grad(smac_handle h, int prim, int f_begin, int f_end, double g13[13]);   /* sum of get_all_states_grad :262-265 over frames */
 /* A whole trajectory in one call (prescribed primitive states of an episode / a window; their adjoints frame by frame): the per-frame forms above cost
  * a host sync each.  s13 / g13: (f_end - f_begin) x 13, frame-major. */
+int smac_prim_get_action_grads(smac_handle h, int prim, int s_begin, int s_end, int n, double* g6);   /* get_action_grad of the env steps [s_begin, s_end) in one launch and one transfer: (s_end - s_begin) x 6 */
 int smac_prim_set_states(smac_handle h, int prim, int f_begin, int f_end, const double* s13);
 int smac_prim_get_state_grads(smac_handle h, int prim, int f_begin, int f_end, double* g13);
 int smac_prim_add_state_grad(smac_handle h, int prim, int f, const double g13[13]);              /* loss kernels' position/v/w .grad[f] += */

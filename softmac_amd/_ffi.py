@@ -70,6 +70,7 @@ SIGNATURES = {
     "smac_prim_set_state": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_double_p]),
     "smac_prim_get_state": (C.c_int, [H, C.c_int, C.c_int, c_double_p]),
     "smac_prim_get_state_grad": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_double_p]),
+    "smac_prim_get_action_grads": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p]),
     "smac_prim_set_states": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_double_p]),
     "smac_prim_get_state_grads": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_double_p]),
     "smac_prim_add_state_grad": (C.c_int, [H, C.c_int, C.c_int, c_double_p]),

@@ -142,6 +142,8 @@ template <class R> struct DevSim {
     int* save_nhits;
     int save_hit_cap;
     int save_blocks;
+    int fk_ride;                 // > 0: this launch also carries forward_kinematics (k_g2p: its last workgroup) / its adjoint (the grid-adjoint reduction: its last
+    size_t fk_stride;            // fk_ride workgroups) of that many velocity-controlled primitives (primitive_base.py:280-283, mpm_simulator.py:329-331, 367-369)
     int* nhits_next;             // the hit counter of the NEXT substep (two counters alternate by frame parity): emptied here while this frame's is still read
     ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
 };
@@ -1131,6 +1133,23 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
     for (int c = 0; c < 9; ++c) Sn[rowoff(CC + c, p, D.Npad)] = four_inv_dx * nC[c];
 }
 
+// forward_kinematics :280-283 of primitive `i` from frame f to f + 1, and its adjoint (13 inputs -> 7 outputs, forward-mode duals: thread `dir` owns input `dir`)
+__device__ __forceinline__ void prim_fk_step(double* state, int f, double dt) {
+    double* s = state + (size_t)f * 13;
+    double o[7];
+    forward_kinematics(s, dt, o);
+    for (int i = 0; i < 7; ++i) s[13 + i] = o[i];
+}
+__device__ __forceinline__ void prim_fk_step_grad(const double* state, double* grad, int f, double dt, int dir) {
+    const double* s = state + (size_t)f * 13;
+    Dual<double> sd[13], o[7];
+    for (int i = 0; i < 13; ++i) sd[i] = Dual<double>(s[i], i == dir ? 1.0 : 0.0);
+    forward_kinematics(sd, dt, o);
+    double acc = 0.0;
+    for (int i = 0; i < 7; ++i) acc += grad[(size_t)(f + 1) * 13 + i] * o[i].d;
+    grad[(size_t)f * 13 + dir] += acc;
+}
+
 // SAVE: the grid checkpoint of the frame (k_grid_save's work: 20 s G_t bytes, a 9 us launch of its own that only waits for memory) is done by the
 // first D.save_blocks workgroups of THIS launch - it reads the same finished grid and touches nothing k_g2p reads ({m,p} is zeroed, v_out only
 // copied), so the two run side by side and a kernel boundary goes.  The hit counter cannot be emptied here while the save part still reads it:
@@ -1139,6 +1158,10 @@ template <class R, bool SAVE>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_g2p(DevSim<R> D, int f) {
     __shared__ Vec4<R> gt[TILE_WORDS];
     int bid = (int)blockIdx.x;
+    if (D.fk_ride > 0 && blockIdx.x == gridDim.x - 1) {       // the velocity-controlled primitives step to frame f + 1 here (nothing in substep f reads that frame)
+        if ((int)threadIdx.x < D.fk_ride) prim_fk_step(D.prim_state + threadIdx.x * D.fk_stride, f, D.dt64);
+        return;
+    }
     if (SAVE) {
         if (bid == 0 && threadIdx.x == 0) {
             D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
@@ -1427,6 +1450,11 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_aout(DevSim<R> D) {
 // through the same node map and adds them to grid_v_in.grad / grid_m.grad (one kernel and the dense grid_v_mixed.grad field less).
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad(DevSim<R> D) {
+    if (D.fk_ride > 0 && blockIdx.x >= gridDim.x - D.fk_ride) {                   // forward_kinematics.grad of this substep, one workgroup per primitive (:367-369)
+        const int prim = (int)(blockIdx.x - (gridDim.x - D.fk_ride));
+        if (threadIdx.x < 13) prim_fk_step_grad(D.prim_state + prim * D.fk_stride, D.prim_grad + prim * D.fk_stride, D.cur_frame, D.dt64, (int)threadIdx.x);
+        return;
+    }
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
@@ -1445,7 +1473,12 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad(DevSim<R> D) {
 template <class R> struct GridSet { Vec4<R> *vin, *vmix, *vout, *aout; };
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, GridSet<R> nx, const Vec4<R>* ck) {
-    const int half = (int)(gridDim.x >> 1);
+    if (D.fk_ride > 0 && blockIdx.x >= gridDim.x - D.fk_ride) {
+        const int prim = (int)(blockIdx.x - (gridDim.x - D.fk_ride));
+        if (threadIdx.x < 13) prim_fk_step_grad(D.prim_state + prim * D.fk_stride, D.prim_grad + prim * D.fk_stride, D.cur_frame, D.dt64, (int)threadIdx.x);
+        return;
+    }
+    const int half = (int)((gridDim.x - (D.fk_ride > 0 ? D.fk_ride : 0)) >> 1);
     if ((int)blockIdx.x < half) {
         int b, l, i, j, k;
         size_t cell;
@@ -2296,24 +2329,13 @@ __global__ void k_count_active(const R* gm, size_t G, unsigned long long* out) {
 template <class R>
 __global__ void k_prim_fk(R* state, int f, R dt, int nprims = 1, size_t stride = 0) {      // instantiated with R = double: primitive state is f64 in both modes
     if ((int)threadIdx.x >= nprims || blockIdx.x != 0) return;
-    R* s = state + threadIdx.x * stride + (size_t)f * 13;
-    R o[7];
-    forward_kinematics(s, dt, o);
-    for (int i = 0; i < 7; ++i) s[13 + i] = o[i];
+    prim_fk_step(state + threadIdx.x * stride, f, dt);
 }
 template <class R>
 __global__ void k_prim_fk_grad(const R* state, R* grad, int f, R dt, size_t stride = 0) {   // one workgroup per primitive (they do not interact: :367-369 in any order)
     const int dir = threadIdx.x;
     if (dir >= 13) return;
-    state += blockIdx.x * stride;
-    grad += blockIdx.x * stride;
-    const R* s = state + (size_t)f * 13;
-    Dual<R> sd[13], o[7];
-    for (int i = 0; i < 13; ++i) sd[i] = Dual<R>(s[i], i == dir ? R(1) : R(0));
-    forward_kinematics(sd, dt, o);
-    R acc = R(0);
-    for (int i = 0; i < 7; ++i) acc += grad[(size_t)(f + 1) * 13 + i] * o[i].d;
-    grad[(size_t)f * 13 + dir] += acc;
+    prim_fk_step_grad(state + blockIdx.x * stride, grad + blockIdx.x * stride, f, dt, dir);
 }
 
 
@@ -2328,9 +2350,10 @@ __global__ void k_prim_set_action(double* state, double* action_buf, int s, int 
         for (int k = 0; k < 3; ++k) { st[7 + k] = a.a[3 + k]; st[10 + k] = a.a[k]; }
     }
 }
-__global__ void k_prim_action_grad(const double* grad, double* action_buf_grad, int s, int n) {
+__global__ void k_prim_action_grad(const double* grad, double* action_buf_grad, int s, int n) {      // one workgroup per env step: s + blockIdx.x
     const int c = threadIdx.x;
     if (c >= 6) return;
+    s += (int)blockIdx.x;
     double acc = action_buf_grad[(size_t)s * 6 + c];
     for (int j = 0; j < n; ++j) acc += grad[(size_t)(s * n + j) * 13 + (c < 3 ? 10 + c : 7 + (c - 3))];     // set_velocity_from_action_kernel.grad :315-319
     action_buf_grad[(size_t)s * 6 + c] = acc;

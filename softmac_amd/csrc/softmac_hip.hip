@@ -99,6 +99,7 @@ struct ISim {
     virtual int prim_clear_ext_f(int prim) = 0;
     virtual int prim_set_action(int prim, int s, int n, const double* a6) = 0;
     virtual int prim_get_action_grad(int prim, int s, int n, double* g6) = 0;
+    virtual int prim_get_action_grads(int prim, int s0, int s1, int n, double* g6) = 0;
     virtual int prim_reset(int prim) = 0;
     virtual int timer_start() = 0;
     virtual int timer_stop(double* ms) = 0;
@@ -1529,7 +1530,9 @@ template <class R> struct Sim final : ISim {
                 else hipLaunchKernelGGL((k_p2g<R, false, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
             }
             prof_end();
-            if (!is_recompute && cfg.rigid_velocity_control && D.P > 0) {         // :329-331, every primitive in one launch
+            if (!is_recompute && cfg.rigid_velocity_control && D.P > 0 && fk_rides_g2p) {
+                REQUIRE(f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");   // (done by the last workgroup of this substep's k_g2p launch)
+            } else if (!is_recompute && cfg.rigid_velocity_control && D.P > 0) {  // :329-331, every primitive in one launch
                 REQUIRE(f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");
                 prof_begin(K_FK);
                 hipLaunchKernelGGL(k_prim_fk<double>, dim3(1), dim3(64), 0, stream, D.prim_state, f, D.dt64, D.P, (size_t)cfg.max_frames * 13);
@@ -1620,6 +1623,8 @@ template <class R> struct Sim final : ISim {
                 D.nhit_ck = keep_hits ? ck_nhits + f : (int*)nullptr;
                 D.hit_cap = ck_hit_cap;
             }
+            // whole substep with particles: forward_kinematics rides in k_g2p's launch instead of a launch of its own (SMAC_FK_RIDE=0: own kernel)
+            fk_rides_g2p = fk_ride_env && phase < 0 && !g2p_pipe && cfg.rigid_velocity_control && D.P > 0 && D.nchunks > 0 && D.nactive > 0;
             rc = forward_grid(f, true, false, phase < 0 ? 0 : 1);
             D.ck = nullptr; D.hit_ck = nullptr; D.nhit_ck = nullptr;
             if (rc) return rc;
@@ -1656,14 +1661,19 @@ template <class R> struct Sim final : ISim {
                     hipLaunchKernelGGL(k_g2p_pipe<R>, dim3(8 * J), dim3(BLOCK), 0, stream, D, f);
                 } else if (save_in_g2p) {
                     DevSim<R> Dg = D;
+                    if (fk_rides_g2p) { Dg.fk_ride = D.P; Dg.fk_stride = (size_t)cfg.max_frames * 13; }
                     Dg.save_ck = ck_slot(f);
                     Dg.save_hits = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
                     Dg.save_nhits = keep_hits ? ck_nhits + f : (int*)nullptr;
                     Dg.save_hit_cap = ck_hit_cap;
                     Dg.save_blocks = (ngrid_blocks() + 7) & ~7;                              // (a multiple of 8: the chunk -> XCD dealing of the g2p part stays aligned)
-                    hipLaunchKernelGGL((k_g2p<R, true>), dim3(Dg.save_blocks + nchunk_blocks()), dim3(BLOCK), 0, stream, Dg, f);
-                } else
-                    hipLaunchKernelGGL((k_g2p<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                    hipLaunchKernelGGL((k_g2p<R, true>), dim3(Dg.save_blocks + nchunk_blocks() + (fk_rides_g2p ? 1 : 0)), dim3(BLOCK), 0, stream, Dg, f);
+                } else {
+                    DevSim<R> Dg = D;
+                    if (fk_rides_g2p) { Dg.fk_ride = D.P; Dg.fk_stride = (size_t)cfg.max_frames * 13; }
+                    hipLaunchKernelGGL((k_g2p<R, false>), dim3(nchunk_blocks() + (fk_rides_g2p ? 1 : 0)), dim3(BLOCK), 0, stream, Dg, f);
+                }
+                fk_rides_g2p = false;
                 nhits_zero_frame = f + 1;                                                    // every form of k_g2p leaves the next frame's hit counter empty
                 prof_end();
             }
@@ -1687,6 +1697,9 @@ template <class R> struct Sim final : ISim {
     // resumes at the slab reduction.  SMAC_FUSED_PG=0 keeps the two kernels apart.
     int fused_pg_env = getenv("SMAC_FUSED_PG") ? atoi(getenv("SMAC_FUSED_PG")) : 1;
     int save_in_g2p_env = getenv("SMAC_SAVE_IN_G2P") ? atoi(getenv("SMAC_SAVE_IN_G2P")) : 1;
+    int fk_ride_env = getenv("SMAC_FK_RIDE") ? atoi(getenv("SMAC_FK_RIDE")) : 1;   // forward_kinematics inside k_g2p's launch, its adjoint inside the grid-adjoint reduction's
+    bool fk_rides_g2p = false;
+    bool fk_grad_rode = false;           // this substep_grad call's forward_kinematics.grad already ran inside its reduction launch
     // Restore-ahead (k_reduce_grid_grad_ahead): inside the fused batched sweep the forward grid of substep f - 1 is restored by the launch that
     // reduces substep f's grid adjoint, into the second of two buffer sets {grid_in, grid_mixed, grid_out, grid_out.grad}; the sets change roles after
     // the fused particle kernel.  Outside the sweep everything lives in set 0 (normalize_grid_set).  SMAC_RESTORE_AHEAD=0: k_grid_restore as before.
@@ -1756,6 +1769,7 @@ template <class R> struct Sim final : ISim {
         if ((rc = need_grad())) return rc;
         if (!direct_bwd) D.nhits = d_nhits;  // (the backward pass uses one counter; the forward pass re-binds and re-empties its pair)
         nhits_zero_frame = -1;
+        if (phase <= 0) fk_grad_rode = false;
         if (phase <= 0 && !bwd_since_fwd) {                 // first backward substep after a forward pass: a drifted epoch is repaired (or reported) now
             if ((rc = check_drift())) return rc;
             bwd_since_fwd = true;
@@ -1777,13 +1791,16 @@ template <class R> struct Sim final : ISim {
             pending_adj_zero = g2p_done_paz;
             D.cur_frame = f;
             prof_begin(K_REDUCE);
+            DevSim<R> Dr = D;
+            fk_grad_rode = fk_ride_env && cfg.rigid_velocity_control && D.P > 0;     // forward_kinematics.grad of this substep: the last D.P workgroups of the launch
+            if (fk_grad_rode) { Dr.fk_ride = D.P; Dr.fk_stride = (size_t)cfg.max_frames * 13; }
             if (restore_ahead_env && can_fuse_prev(f, e, phase, action_grad_out) && grid_alt_ready()) {
                 // this substep will hand over to substep f - 1 inside k_p2g_g2p_grad: its forward grid is restored by THIS launch, into the other set
-                hipLaunchKernelGGL(k_reduce_grid_grad_ahead<R>, dim3(2 * ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_set_ptrs(1 - grid_set),
+                hipLaunchKernelGGL(k_reduce_grid_grad_ahead<R>, dim3(2 * ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr, grid_set_ptrs(1 - grid_set),
                                    (const Vec4<R>*)ck_slot(f - 1));
                 ahead_frame = f - 1;
             } else
-                hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+                hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr);
             prof_end();
         } else if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
@@ -1860,8 +1877,12 @@ template <class R> struct Sim final : ISim {
                 else hipLaunchKernelGGL((k_g2p_grad<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
                 prof_begin(K_REDUCE);
-                if (fused_grid_bwd(phase)) hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
-                else hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+                if (fused_grid_bwd(phase)) {
+                    DevSim<R> Dr = D;
+                    fk_grad_rode = fk_ride_env && cfg.rigid_velocity_control && D.P > 0;
+                    if (fk_grad_rode) { Dr.fk_ride = D.P; Dr.fk_stride = (size_t)cfg.max_frames * 13; }
+                    hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr);
+                } else hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
             }
         }
@@ -1888,7 +1909,7 @@ template <class R> struct Sim final : ISim {
                     hipLaunchKernelGGL((k_grid_op_grad<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
             }
-            if (cfg.rigid_velocity_control && D.P > 0) {                          // :367-369 (the primitives do not interact: one launch)
+            if (cfg.rigid_velocity_control && D.P > 0 && !fk_grad_rode) {         // :367-369 (the primitives do not interact: one launch)
                 prof_begin(K_FK);
                 hipLaunchKernelGGL(k_prim_fk_grad<double>, dim3(D.P), dim3(64), 0, stream, (const double*)D.prim_state, D.prim_grad, f, D.dt64,
                                    (size_t)cfg.max_frames * 13);
@@ -2535,6 +2556,16 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipStreamSynchronize(stream));
         return check_launch();
     }
+    int prim_get_action_grads(int prim, int s0, int s1, int n, double* g6) override {   // the env steps [s0, s1) of an episode at once
+        int rc = check_prim(prim);
+        if (rc) return rc;
+        REQUIRE(g6 && s0 >= 0 && s0 < s1 && n >= 1 && (size_t)s1 * n <= (size_t)cfg.max_frames, "prim_get_action_grads: frames out of range");
+        double* abg = action_buf_grad + (size_t)prim * cfg.max_frames * 6;
+        hipLaunchKernelGGL(k_prim_action_grad, dim3(s1 - s0), dim3(64), 0, stream, (const double*)pgrad(prim), abg, s0, n);
+        HIP_TRY(hipMemcpyAsync(g6, abg + (size_t)s0 * 6, (size_t)(s1 - s0) * 6 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return check_launch();
+    }
     int prim_reset(int prim) override {                                       // :271-275
         int rc = check_prim(prim);
         if (rc) return rc;
@@ -2740,6 +2771,7 @@ int smac_prim_get_ext_f(smac_handle h, int prim, double ext_f[6]) { return FWD(p
 int smac_prim_clear_ext_f(smac_handle h, int prim) { return FWD(prim_clear_ext_f(prim)); }
 int smac_prim_set_action(smac_handle h, int prim, int s, int n, const double a6[6]) { return FWD(prim_set_action(prim, s, n, a6)); }
 int smac_prim_get_action_grad(smac_handle h, int prim, int s, int n, double g6[6]) { return FWD(prim_get_action_grad(prim, s, n, g6)); }
+int smac_prim_get_action_grads(smac_handle h, int prim, int s0, int s1, int n, double* g6) { return FWD(prim_get_action_grads(prim, s0, s1, n, g6)); }
 int smac_prim_reset(smac_handle h, int prim) { return FWD(prim_reset(prim)); }
 int smac_timer_start(smac_handle h) { return FWD(timer_start()); }
 int smac_timer_stop(smac_handle h, double* ms) { return FWD(timer_stop(ms)); }

@@ -201,6 +201,12 @@ class Primitive:
         self._h.call("smac_prim_get_action_grad", self._slot, int(s), int(n), _ffi.dptr(g))
         return g
 
+    def get_action_grads(self, s0, s1, n):
+        """(s1 - s0, 6): get_action_grad of the env steps [s0, s1) in one launch and one transfer (an episode's backward())"""
+        g = np.zeros((int(s1) - int(s0), 6))
+        self._h.call("smac_prim_get_action_grads", self._slot, int(s0), int(s1), int(n), _ffi.dptr(g))
+        return g
+
     @classmethod
     def default_config(cls):                                 # :328-335
         from ...config import CfgNode as CN

@@ -35,6 +35,13 @@ class RigidSimulatorVelocityControl:
             g[i * 6: i * 6 + 6] = self.primitives[i].get_action_grad(s + 1, self.substeps)
         return torch.tensor(g), None
 
+    def step_grad_all(self, total_steps):
+        """step_grad of the env steps 0 .. total_steps - 1 at once: (total_steps, 6 n_primitive); one device round trip per primitive, not per env step"""
+        g = np.zeros((total_steps, self.n_primitive * 6))
+        for i in range(self.n_primitive):
+            g[:, i * 6: i * 6 + 6] = self.primitives[i].get_action_grads(1, total_steps + 1, self.substeps)
+        return torch.tensor(g)
+
     def exp2quat(self, e):                                       # :46-55
         mag = np.linalg.norm(e)
         if mag > 1e-10:

@@ -112,12 +112,8 @@ class TaichiEnv:
             # not interrupted at every env-step boundary.  (step_grad remains for callers that walk the env steps themselves.)
             cur = self.simulator.cur
             self.simulator.run_substeps_grad(0, cur)
-            grads = []
-            for s in range(total_steps):
-                g, _ = self.rigid_simulator.step_grad(s, self.action_list[s])
-                grads.append(g)
             self.simulator.cur = 0
-            return torch.vstack(grads)
+            return self.rigid_simulator.step_grad_all(total_steps)
         action_grad = []
         for s in range(total_steps - 1, -1, -1):
             action_grad = [self.step_grad(self.action_list[s])] + action_grad

@@ -142,6 +142,11 @@ template <class R> struct DevSim {
     int* save_nhits;
     int save_hit_cap;
     int save_blocks;
+    // One byte per active slot of the frame whose checkpoint this launch files or restores (nullptr: off): 1 = the block held no mass - {m,p} all zero,
+    // hence v_mixed = v_out = 0 - and nothing was filed for it.  The drift margin around the cloud is a third of the active blocks (round 3: the grid
+    // passes run at the bandwidth of their 16-byte accesses, so bytes not moved are time).  ck_flags_next: the frame k_reduce_grid_grad_ahead restores.
+    unsigned char* ck_flags;
+    const unsigned char* ck_flags_next;
     int fk_ride;                 // > 0: this launch also carries forward_kinematics (k_g2p: its last workgroup) / its adjoint (the grid-adjoint reduction: its last
     size_t fk_stride;            // fk_ride workgroups) of that many velocity-controlled primitives (primitive_base.py:280-283, mpm_simulator.py:329-331, 367-369)
     int* nhits_next;             // the hit counter of the NEXT substep (two counters alternate by frame parity): emptied here while this frame's is still read
@@ -559,7 +564,13 @@ __device__ __forceinline__ void grid_save_block(const DevSim<R>& D, int nblocks,
     const int l = threadIdx.x & 63;
     const size_t cell = (size_t)D.active[a] * 64 + l;
     Vec4<R>* dst = ck + (size_t)a * 192 + l;
-    dst[0] = D.vin[cell]; dst[64] = D.vmix[cell]; dst[128] = D.vout[cell];
+    const Vec4<R> in = D.vin[cell];
+    if (D.ck_flags) {                                                    // (a wave = a block)
+        const bool empty = __ballot(in.x != R(0) || in.y != R(0) || in.z != R(0) || in.w != R(0)) == 0ull;
+        if (l == 0) D.ck_flags[a] = empty ? 1 : 0;
+        if (empty) return;                                               // no mass: grid_op left v_mixed = v_out = 0 there, {m,p} is zero already
+    }
+    dst[0] = in; dst[64] = D.vmix[cell]; dst[128] = D.vout[cell];
     // {m, p} is not read again this substep: leave it zeroed for the next P2G (drifted particles add to it with
     // global atomics), which saves that substep's clear pass
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
@@ -582,7 +593,8 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
     const size_t cell = (size_t)D.active[a] * 64 + l;
     const Vec4<R>* src = ck + (size_t)a * 192 + l;
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-    D.vin[cell] = src[0]; D.vmix[cell] = src[64]; D.vout[cell] = src[128];
+    if (D.ck_flags && D.ck_flags[a]) { D.vin[cell] = z; D.vmix[cell] = z; D.vout[cell] = z; }        // a block that held no mass: nothing was filed
+    else { D.vin[cell] = src[0]; D.vmix[cell] = src[64]; D.vout[cell] = src[128]; }
     D.aout[cell] = z;                                // g2p.grad's drifted lanes add to it
     if (zero_all) { D.ain[cell] = z; D.amix[cell] = z; }   // (the fused backward grid pass writes every grid_v_in.grad and never reads grid_v_mixed.grad)
 }
@@ -1496,7 +1508,8 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, G
         const size_t cell = (size_t)D.active[a] * 64 + l;
         const Vec4<R>* src = ck + (size_t)a * 192 + l;
         const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-        nx.vin[cell] = src[0]; nx.vmix[cell] = src[64]; nx.vout[cell] = src[128];
+        if (D.ck_flags_next && D.ck_flags_next[a]) { nx.vin[cell] = z; nx.vmix[cell] = z; nx.vout[cell] = z; }
+        else { nx.vin[cell] = src[0]; nx.vmix[cell] = src[64]; nx.vout[cell] = src[128]; }
         nx.aout[cell] = z;                               // g2p.grad's drifted lanes add to it
     }
 }

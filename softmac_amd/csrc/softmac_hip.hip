@@ -214,6 +214,9 @@ template <class R> struct Sim final : ISim {
     Hit* ck_hits = nullptr;          // per frame: the contact hit list of that substep (capacity ck_hit_cap), with its length
     int ck_hit_cap = 0;
     int* ck_nhits = nullptr;
+    unsigned char* ck_empty = nullptr;   // [frame][active slot]: the block held no mass and nothing was filed for it (DevSim::ck_flags)
+    int ck_skip_empty = getenv("SMAC_CK_SKIP_EMPTY") ? atoi(getenv("SMAC_CK_SKIP_EMPTY")) : 1;
+    unsigned char* ck_flags_of(int f) { return (ck_empty && ck_skip_empty && ck_mode == 0) ? ck_empty + (size_t)f * ck_slot_blocks : (unsigned char*)nullptr; }
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
     bool vin_clean = false;          // {m,p} of every active block is zero (saves the clear pass before P2G)
@@ -268,7 +271,7 @@ template <class R> struct Sim final : ISim {
         hipFree(D.cloth.pos); hipFree(D.cloth.vel); hipFree(D.cloth.pos_grad); hipFree(D.cloth.vel_grad); hipFree(D.cloth.ext_f);
         hipFree(D.cloth.ext_f_grad); hipFree(D.cloth.contact_id); hipFree(D.cloth.penetration); hipFree(D.cloth.contact_before);
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
-        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits);
+        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
             if ((void*)prim_tables64[i][0] != (void*)prim_tables[i][0]) { hipFree(prim_tables64[i][0]); hipFree(prim_tables64[i][1]); }
             hipFree(prim_tables[i][0]); hipFree(prim_tables[i][1]);
@@ -1570,6 +1573,12 @@ template <class R> struct Sim final : ISim {
                 ck_arena = nullptr;
                 ck_enabled = false;                        // not enough memory: substep_grad recomputes the forward grid
             }
+            if (ck_arena && (hipMalloc((void**)&ck_empty, (size_t)cfg.max_frames * ck_slot_blocks) != hipSuccess ||
+                             hipMemsetAsync(ck_empty, 0, (size_t)cfg.max_frames * ck_slot_blocks, stream) != hipSuccess)) {
+                (void)hipGetLastError();
+                hipFree(ck_empty);
+                ck_empty = nullptr;                        // (no flags: every active block is filed)
+            }
             // the hit lists ride along when they fit too (otherwise substep_grad repeats the band test).  A slot holds the
             // hits of 1/8 of the particles (the bench has 0.15 % of them inside a contact band); more is reported as an error
             ck_hit_cap = D.Npad / 8 > 8192 ? D.Npad / 8 : 8192;
@@ -1645,7 +1654,9 @@ template <class R> struct Sim final : ISim {
                 ck_has_hits[f] = keep_hits ? 1 : 0;
                 if (!save_in_g2p) {
                     prof_begin(K_CKPT);
-                    hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, ck_slot(f),
+                    DevSim<R> Ds = D;
+                    Ds.ck_flags = ck_flags_of(f);
+                    hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Ds, ck_slot(f),
                                        keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr, ck_hit_cap);
                     prof_end();
                 }
@@ -1666,6 +1677,7 @@ template <class R> struct Sim final : ISim {
                     Dg.save_hits = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
                     Dg.save_nhits = keep_hits ? ck_nhits + f : (int*)nullptr;
                     Dg.save_hit_cap = ck_hit_cap;
+                    Dg.ck_flags = ck_flags_of(f);
                     Dg.save_blocks = (ngrid_blocks() + 7) & ~7;                              // (a multiple of 8: the chunk -> XCD dealing of the g2p part stays aligned)
                     hipLaunchKernelGGL((k_g2p<R, true>), dim3(Dg.save_blocks + nchunk_blocks() + (fk_rides_g2p ? 1 : 0)), dim3(BLOCK), 0, stream, Dg, f);
                 } else {
@@ -1794,6 +1806,7 @@ template <class R> struct Sim final : ISim {
             DevSim<R> Dr = D;
             fk_grad_rode = fk_ride_env && cfg.rigid_velocity_control && D.P > 0;     // forward_kinematics.grad of this substep: the last D.P workgroups of the launch
             if (fk_grad_rode) { Dr.fk_ride = D.P; Dr.fk_stride = (size_t)cfg.max_frames * 13; }
+            Dr.ck_flags_next = f > 0 ? ck_flags_of(f - 1) : nullptr;
             if (restore_ahead_env && can_fuse_prev(f, e, phase, action_grad_out) && grid_alt_ready()) {
                 // this substep will hand over to substep f - 1 inside k_p2g_g2p_grad: its forward grid is restored by THIS launch, into the other set
                 hipLaunchKernelGGL(k_reduce_grid_grad_ahead<R>, dim3(2 * ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr, grid_set_ptrs(1 - grid_set),
@@ -1857,7 +1870,9 @@ template <class R> struct Sim final : ISim {
                 prof_begin(K_CKPT);
                 const bool have_hits = ck_has_hits[f] && D.any_contact && D.collision_type == CONTACT_MIXED;
                 vin_clean = false;
-                hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f),
+                DevSim<R> Dk = D;
+                Dk.ck_flags = ck_flags_of(f);
+                hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dk, (const Vec4<R>*)ck_slot(f),
                                    have_hits ? (const Hit*)(ck_hits + (size_t)f * ck_hit_cap) : (const Hit*)nullptr,
                                    have_hits ? (const int*)(ck_nhits + f) : (const int*)nullptr, fused_grid_bwd(phase) ? 0 : 1);
                 if (D.any_contact && D.collision_type != CONTACT_GRID && !have_hits) {
@@ -1927,7 +1942,9 @@ template <class R> struct Sim final : ISim {
                     ahead_frame = -1;
                 } else {
                     prof_begin(K_CKPT);
-                    hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)ck_slot(f - 1),
+                    DevSim<R> Dk = D;
+                    Dk.ck_flags = ck_flags_of(f - 1);
+                    hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dk, (const Vec4<R>*)ck_slot(f - 1),
                                        have_hits ? (const Hit*)(ck_hits + (size_t)(f - 1) * ck_hit_cap) : (const Hit*)nullptr,
                                        have_hits ? (const int*)(ck_nhits + (f - 1)) : (const int*)nullptr, 0);
                     prof_end();

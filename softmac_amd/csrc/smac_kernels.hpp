@@ -1470,6 +1470,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
+    // a block that held no mass in this frame (flag written with its checkpoint): no particle's stencil reached it, so nothing was scattered to it and
+    // nothing will gather its grid_v_in.grad - no reads, no writes (what the array holds there is never looked at: gathers read touched nodes only)
+    if (D.ck_flags && D.ck_flags[active_slot(D)]) return;
     Vec4<R> acc = D.aout[cell];
     const Vec4<R> in = D.vin[cell];
     slab_reduce(D, b, l, acc);
@@ -1495,6 +1498,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, G
         int b, l, i, j, k;
         size_t cell;
         if (!active_cell(D, b, l, cell, i, j, k)) return;
+        if (D.ck_flags && D.ck_flags[active_slot(D)]) return;            // (no mass in this frame: see k_reduce_grid_grad)
         Vec4<R> acc = D.aout[cell];
         const Vec4<R> in = D.vin[cell];
         slab_reduce(D, b, l, acc);

@@ -216,6 +216,8 @@ template <class R> struct Sim final : ISim {
     int* ck_nhits = nullptr;
     unsigned char* ck_empty = nullptr;   // [frame][active slot]: the block held no mass and nothing was filed for it (DevSim::ck_flags)
     int ck_skip_empty = getenv("SMAC_CK_SKIP_EMPTY") ? atoi(getenv("SMAC_CK_SKIP_EMPTY")) : 1;
+    // the flags of frame f for the backward grid pass: only while the frame's checkpoint (and with it the flags) is the one this epoch filed
+    unsigned char* reduce_flags(int f, int e) { return (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen) ? ck_flags_of(f) : (unsigned char*)nullptr; }
     unsigned char* ck_flags_of(int f) { return (ck_empty && ck_skip_empty && ck_mode == 0) ? ck_empty + (size_t)f * ck_slot_blocks : (unsigned char*)nullptr; }
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
@@ -1807,6 +1809,7 @@ template <class R> struct Sim final : ISim {
             fk_grad_rode = fk_ride_env && cfg.rigid_velocity_control && D.P > 0;     // forward_kinematics.grad of this substep: the last D.P workgroups of the launch
             if (fk_grad_rode) { Dr.fk_ride = D.P; Dr.fk_stride = (size_t)cfg.max_frames * 13; }
             Dr.ck_flags_next = f > 0 ? ck_flags_of(f - 1) : nullptr;
+            Dr.ck_flags = reduce_flags(f, e);
             if (restore_ahead_env && can_fuse_prev(f, e, phase, action_grad_out) && grid_alt_ready()) {
                 // this substep will hand over to substep f - 1 inside k_p2g_g2p_grad: its forward grid is restored by THIS launch, into the other set
                 hipLaunchKernelGGL(k_reduce_grid_grad_ahead<R>, dim3(2 * ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr, grid_set_ptrs(1 - grid_set),
@@ -1896,6 +1899,7 @@ template <class R> struct Sim final : ISim {
                     DevSim<R> Dr = D;
                     fk_grad_rode = fk_ride_env && cfg.rigid_velocity_control && D.P > 0;
                     if (fk_grad_rode) { Dr.fk_ride = D.P; Dr.fk_stride = (size_t)cfg.max_frames * 13; }
+                    Dr.ck_flags = ck_ok ? reduce_flags(f, e) : nullptr;      // (a recomputed forward grid has no flags)
                     hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr);
                 } else hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();

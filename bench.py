@@ -85,15 +85,35 @@ def build_sim(args, rank, world, precision=None, frames=None):
         traj = [np.stack([s13[i] + np.concatenate([f * cfg.dt * s13[i][7:10], np.zeros(10)]) for f in range(frames)]) for i in range(len(specs))]
         sides = contact_sides(specs, traj, args.grid, slab[0], slab[1], slab[2], rank, world)
         sides = agree_contact_sides(sides, rank, world)    # a boundary's two ranks must post the same exchanges
+        fallback = None
         if args.slab_runner == "lib":
             # the loop inside the library: ncclSend / ncclRecv on its own stream, no Python between the phases; the process group (gloo, CPU)
             # only carries the RCCL id, the barriers and the max-over-ranks of the wall clock
+            from softmac_amd.parallel import all_ranks_ok
             tol = (slab[2] - 2) // 2                        # range of stencil bases this rank owns, from its shared planes (scenes.s_grip_strong)
             own = (slab[0] + tol if rank > 0 else 0, slab[1] + tol if rank < world - 1 else args.grid)
-            runner = LibSlabRunner(sim, rank, world, slab[0], slab[1], slab[2], has_contact=sides, own=own, unique_id=rendezvous_unique_id(rank))
+            err = None
+            try:
+                runner = LibSlabRunner(sim, rank, world, slab[0], slab[1], slab[2], has_contact=sides, own=own, unique_id=rendezvous_unique_id(rank))
+            except Exception as e:                          # noqa: BLE001
+                err, runner = f"{type(e).__name__}: {e}", None
+            failed = all_ranks_ok(err)                      # every rank takes the same decision
+            if failed:
+                # the RCCL communicator did not come up on every rank: the run is not lost - the Python loop over the control group (gloo: halo planes
+                # staged through the host) carries the same exchange, slowly; the line says so
+                if runner is not None:
+                    try:
+                        runner.close()
+                    except Exception:                       # noqa: BLE001
+                        pass
+                fallback = "in-library RCCL loop unavailable (" + "; ".join(failed)[:400] + "): Python SlabRunner over gloo, halo planes staged through the host"
+                if rank == 0:
+                    print("bench.py: " + fallback, file=sys.stderr, flush=True)
+                runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=sides)
         else:
             runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=sides)
         runner.contact_sides_note = sides
+        runner.fallback_note = fallback
     return sim, runner, cfg
 
 
@@ -495,6 +515,7 @@ def main():
                        else "forward grid restored from the per-frame checkpoint saved by substep",
                        "resort_interval": args.sort_interval, "resorts_in_window": int(kern.get("sort", (0, 0))[1]),
                        "parallelism": par},
+            "slab_runner": None if world == 1 else (getattr(run, "fallback_note", None) or ("in-library RCCL loop" if args.slab_runner == "lib" else "Python SlabRunner")),
             "multi_gpu_note": None if world == 1 else ("the in-library RCCL slab loop has run on ONE GPU only (world-1 self exchange, tests/test_gpu_slab_lib.py) "
                                                          "and the Python SlabRunner under gloo; no N > 1 result existed when this code was committed"),
             "repeats": len(walls), "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],

@@ -258,10 +258,27 @@ def comm_unique_id():
 
 
 def rendezvous_unique_id(rank, group=None):
-    """rank 0 makes the id, every rank of the (CPU, gloo) process group receives it"""
-    box = [comm_unique_id() if rank == 0 else None]
+    """rank 0 makes the id, every rank of the (CPU, gloo) process group receives it.  A failure on rank 0 (RCCL not loadable) travels instead of the
+    id and is raised on EVERY rank - a rank 0 that raised before the broadcast would leave the others waiting in it."""
+    box = [None]
+    if rank == 0:
+        try:
+            box = [comm_unique_id()]
+        except Exception as e:                               # noqa: BLE001 - whatever it is, the other ranks must hear of it
+            box = [RuntimeError(f"rank 0 could not create the RCCL id: {type(e).__name__}: {e}")]
     dist.broadcast_object_list(box, src=0, group=group)
+    if isinstance(box[0], Exception):
+        raise box[0]
     return box[0]
+
+
+def all_ranks_ok(error, group=None):
+    """error: None or this rank's failure (str).  Returns the list of failures of all ranks (empty = every rank is fine): the ranks decide TOGETHER
+    whether a collective resource came up, so that none of them walks on into an exchange its neighbour never posts."""
+    world = dist.get_world_size(group)
+    allf = [None] * world
+    dist.all_gather_object(allf, error, group=group)
+    return [f"rank {r}: {e}" for r, e in enumerate(allf) if e]
 
 
 def agree_contact_sides(sides, rank, world, group=None):

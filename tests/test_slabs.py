@@ -224,3 +224,23 @@ def test_contact_sides_predicate(monkeypatch):
     assert contact_sides([spec], [np.concatenate([[0.345], still[1:]])], 128, 62, 62, 4, 1, 3) == (False, False)
     monkeypatch.setenv("SMAC_SLAB_ALL_EXCHANGES", "1")
     assert contact_sides([spec], [still], 128, 62, 62, 4, 1, 3) == (True, True)
+
+
+@pytest.mark.parametrize("mode", ["fine", "rank0_fails", "rank1_fails_later"])
+def test_rendezvous_failure_reaches_every_rank(tmp_path, mode):
+    """bench.py --gpus N brings the in-library RCCL loop up on every rank or on none: a rank 0 that cannot create the RCCL id sends the failure through
+    the broadcast the others are waiting in (instead of raising in front of it and leaving them there), and a failure on any one rank afterwards is
+    known to all before any of them posts an exchange (parallel.all_ranks_ok) - bench.py then falls back to the Python loop on every rank."""
+    import json
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, str(HERE / "rendezvous_worker.py"), str(r), "2", port, str(tmp_path), mode]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert res[0]["failed"] == res[1]["failed"]
+    if mode == "fine":
+        assert all(r["uid_ok"] and r["err"] is None for r in res) and res[0]["failed"] == []
+    elif mode == "rank0_fails":
+        assert all(r["err"] and "librccl" in r["err"] for r in res) and len(res[0]["failed"]) == 2
+    else:
+        assert res[0]["err"] is None and res[0]["failed"] == ["rank 1: SmacError: smac_comm_init failed"]

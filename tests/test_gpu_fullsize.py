@@ -263,3 +263,22 @@ def test_c4_slice_4m_particles_256_grid_vs_cpu_port(precision):
     tg = 1e-8 if precision == "float64" else H.F32_TOL["grad"]
     for name, got, rf in (("gx", gx, ref[0]), ("gv", gv, ref[1]), ("gC", gC, ref[2]), ("gF", gF, ref[3])):
         assert H.rel_err(got, rf) < tg, (name, H.rel_err(got, rf))               # (a liquid with mu = 0 takes no SVD: no clamp zone)
+    # the batched sweep at this size (float32: fused backward step, restore-ahead on the second grid buffer set - 1 GB at 256^3 -, checkpoint
+    # save inside k_g2p, empty-block flags) against the substep-by-substep sweep of the same handle
+    sim.run_substeps(0, 3)
+    seed = rng.standard_normal((N, 3))
+    sim.clear_grads()
+    sim.add_grad(3, gx=seed)
+    for f in (2, 1, 0):
+        sim.substep_grad(f)
+    one_by_one = sim.get_grad_full(0)
+    sim.clear_grads()
+    sim.add_grad(3, gx=seed)
+    sim.profile(True)
+    sim.run_substeps_grad(0, 3)
+    counts = sim.profile_report()
+    sim.profile(False)
+    if precision == "float32":
+        assert counts.get("p2g_g2p_grad", (0, 0))[1] == 2
+    for name, got, rf in zip(("gx", "gv", "gF", "gC"), sim.get_grad_full(0), one_by_one):
+        assert H.rel_err(got, rf) < (1e-10 if precision == "float64" else 1e-5), (name, H.rel_err(got, rf))

@@ -97,3 +97,96 @@ class WindowedEpisode:
             for j in range(n):
                 prim_grads[t0 + j] = [g[j] for g in pg]
         return sim.get_grad_full(0), prim_grads
+
+
+class WindowedEnvEpisode:
+    """The same for the reference's env loop with velocity-controlled primitives (TaichiEnv.step / backward, taichi_env.py:93-151): an episode of any
+    number of env steps in a handle that holds `window` of them.
+
+    Working frames 0 .. (window + 1) n - 1 (n = substeps per env step; an action sets the velocities of the NEXT env step's n frames, primitive_base.py:
+    298-304, so the last env step of a window writes one env step past its end); the w-th window's first frame is filed at slot (window + 1) n + w n
+    (smac_copy_frame moves the particles and the primitives' n frames from there on, as the reference's copyframe does).
+
+    step(action):  TaichiEnv.step; when the window is full its last frame - particles, poses, the velocities the last action set - becomes frame 0 first.
+    backward(seeds): per window, last first: filed frame back to slot 0, the window's actions stepped again, the later window's particle adjoint
+        (smac_carry_grad) and POSE adjoint of its first frame handed to this window's last frame, the window's loss seeds, one backward sweep.  The
+        velocity adjoints of a window's first n frames belong to the action given in the LAST env step of the window before it."""
+
+    def __init__(self, env, window):
+        sim = env.simulator
+        assert env.control_mode == "rigid" and env.rigid_velocity_control, "velocity-controlled primitives only (the reference's RigidSimulatorVelocityControl)"
+        self.env, self.sim, self.W, self.n = env, sim, int(window), int(env.substeps)
+        assert self.W >= 1
+        self.first_file = (self.W + 1) * self.n
+        assert sim.max_steps >= self.first_file + 2 * self.n, "the handle needs (window + 1) env steps of working frames and room for filed frames"
+        self.actions, self.windows = [], []
+
+    def _file_slot(self, w):
+        slot = self.first_file + w * self.n
+        assert slot + self.n <= self.sim.max_steps, f"max_steps = {self.sim.max_steps} holds {(self.sim.max_steps - self.first_file) // self.n} windows"
+        return slot
+
+    def reset(self):
+        self.env.reset()
+        self.actions, self.windows = [], []
+
+    def step(self, action):
+        sim = self.sim
+        if not self.windows or self.windows[-1] == self.W:
+            if self.windows:
+                sim.copyframe(self.W * self.n, 0)          # the full window's last frame opens the next one
+            sim.copyframe(0, self._file_slot(len(self.windows)))
+            self.windows.append(0)
+            sim.cur = 0
+            self.env.action_list = []
+        self.env.step(action)
+        self.actions.append(action)
+        self.windows[-1] += 1
+
+    @property
+    def frame(self):
+        """slot of the episode's current last frame"""
+        return self.sim.cur
+
+    def backward(self, seeds):
+        """seeds: {logical frame t (in substeps): dict(gx=, gv=, gF=, gC=)}.  Returns the action gradients, (env steps, 6 x primitives)."""
+        import torch
+        env, sim, n = self.env, self.sim, self.n
+        prims = list(sim.primitives)
+        out = np.zeros((len(self.actions), 6 * len(prims)))
+        carried, pose_carry = False, None
+        k_end = len(self.actions)
+        for w in range(len(self.windows) - 1, -1, -1):
+            nw = self.windows[w]
+            k0 = k_end - nw
+            sim.copyframe(self._file_slot(w), 0)
+            sim.cur = 0
+            env.action_list = []
+            for k in range(nw):                            # recompute: states, checkpoints, the primitives' trajectories of this window
+                env.step(self.actions[k0 + k])
+            n_sub = nw * n
+            if carried:
+                sim.carry_grad(0, n_sub)
+            else:
+                sim.clear_grads()
+            if pose_carry is not None:
+                for m, g in zip(prims, pose_carry):
+                    m.add_state_grad(n_sub, g)
+            for t, g in seeds.items():
+                if k0 * n < t <= k0 * n + n_sub or (t == 0 and w == 0):
+                    sim.add_grad(t - k0 * n, **g)
+            sim.run_substeps_grad(0, n_sub)
+            sim.cur = 0
+            for i, m in enumerate(prims):                  # env step s of this window carries the action given one env step earlier
+                g = m.get_action_grads(0, nw, n)
+                for s in range(nw):
+                    if k0 + s - 1 >= 0:
+                        out[k0 + s - 1, 6 * i: 6 * i + 6] += g[s]
+            pose_carry = []
+            for m in prims:
+                g13 = m.get_states_grad_trajectory(0, 1)[0].copy()
+                g13[7:] = 0.0                              # (the velocity adjoints of this frame are in the action gradient above)
+                pose_carry.append(g13)
+            carried = True
+            k_end = k0
+        return torch.tensor(out)

@@ -69,3 +69,52 @@ def test_windowed_episode_needs_few_frames():
         ep2 = WindowedEpisode(sim, 15)
         ep2.reset(state)
         ep2.forward(90)                                # six windows: one filed frame too many for this handle
+
+
+@pytest.mark.parametrize("precision,tol", [("float64", 1e-8), ("float32", 2e-4)])
+def test_windowed_env_episode_equals_the_resident_env(precision, tol):
+    """The reference's env loop (velocity-controlled palm pressing on a block, tests/test_gpu_env.py's scene): 6 env steps of 2 substeps in windows of 2
+    env steps against the resident episode - action gradients, final particle positions, final pose."""
+    import torch
+    from softmac_amd.config import CfgNode
+    from softmac_amd.engine.primitive import Mesh, Primitives
+    from softmac_amd.engine.taichi_env import TaichiEnv
+    from softmac_amd.engine.windowed import WindowedEnvEpisode
+    from test_gpu_env import _scene
+    K, W = 6, 2
+    rng = np.random.default_rng(21)
+    actions = np.array([0.1, 0.05, -0.2, 0.02, -0.3, 0.01]) + 0.05 * rng.standard_normal((K, 6))     # (w, v): the palm keeps pressing down, as its initial velocity does
+
+    def make():
+        cfg, state, pose, vel = _scene(precision)
+        cfg.SIMULATOR.max_steps = 24
+        palm = H.load_palm()
+        pc = CfgNode(); pc.friction = 0.4; pc.enable_external_force = True; pc.urdf_path = ""
+        mesh = Mesh(sdf=palm, cfg=pc, max_timesteps=cfg.SIMULATOR.max_steps, rigid_velocity_control=True)
+        env = TaichiEnv(cfg, primitives=Primitives(primitives=[mesh]))
+        mesh.friction[None] = 0.4
+        return env, mesh, len(state)
+
+    env, mesh, N = make()
+    n = env.substeps
+    T = K * n
+    seeds = {T: dict(gx=rng.standard_normal((N, 3))), 2 * n: dict(gx=rng.standard_normal((N, 3))), 2 * n + 1: dict(gv=rng.standard_normal((N, 3)))}
+    for k in range(K):
+        env.step(torch.tensor(actions[k]))
+    env.simulator.clear_grads()
+    for t, g in seeds.items():
+        env.simulator.add_grad(t, **g)
+    want_x, want_pose = env.simulator.get_x(T), mesh.get_state(T)
+    want = env.backward().numpy()
+    assert np.abs(want[:-1]).max() > 0
+
+    env2, mesh2, _ = make()
+    ep = WindowedEnvEpisode(env2, W)
+    ep.reset()
+    for k in range(K):
+        ep.step(torch.tensor(actions[k]))
+    assert ep.windows == [2, 2, 2]
+    assert H.rel_err(env2.simulator.get_x(ep.frame), want_x) < (1e-9 if precision == "float64" else 1e-5)
+    assert np.abs(mesh2.get_state(ep.frame) - want_pose).max() < 1e-8
+    got = ep.backward(seeds).numpy()
+    assert H.rel_err(got, want) < tol, (got, want)

@@ -73,9 +73,11 @@ class WindowedEpisode:
     def get_state(self):
         return self.sim.get_state(self.end_slot)
 
-    def backward(self, seeds):
-        """seeds: {logical frame t: dict(gx=, gv=, gF=, gC=)} (any subset).  Returns (adjoint of frame 0 as (gx, gv, gF, gC),
-        {t: [13-vector per primitive]} adjoints of the prescribed primitive states of every frame)."""
+    def backward(self, seeds, seed_fn=None):
+        """seeds: {logical frame t: dict(gx=, gv=, gF=, gC=)} (any subset).  seed_fn(t0, n) (optional) is called once per window, after its frames
+        [t0, t0 + n] have been recomputed into slots 0 .. n and before they are reversed: a loss evaluated on the device adds its gradients there
+        (e.g. `smac_loss_chamfer(slot, add_grad=1)` through engine/losses: logical frame t lives in slot t - t0).  Returns (adjoint of frame 0 as
+        (gx, gv, gF, gC), {t: [13-vector per primitive]} adjoints of the prescribed primitive states of every frame)."""
         sim, K = self.sim, self.K
         carried = False
         prim_grads = {}
@@ -91,6 +93,8 @@ class WindowedEpisode:
             for t, g in seeds.items():
                 if t0 < t <= t0 + n or (t == 0 and w == 0):
                     sim.add_grad(t - t0, **g)
+            if seed_fn is not None:
+                seed_fn(t0, n)
             sim.run_substeps_grad(0, n)
             carried = True
             pg = [m.get_states_grad_trajectory(0, n) for m in sim.primitives]
@@ -148,8 +152,9 @@ class WindowedEnvEpisode:
         """slot of the episode's current last frame"""
         return self.sim.cur
 
-    def backward(self, seeds):
-        """seeds: {logical frame t (in substeps): dict(gx=, gv=, gF=, gC=)}.  Returns the action gradients, (env steps, 6 x primitives)."""
+    def backward(self, seeds, seed_fn=None):
+        """seeds: {logical frame t (in substeps): dict(gx=, gv=, gF=, gC=)}; seed_fn(t0, n): as in WindowedEpisode.backward (the place for a loss
+        that seeds on the device).  Returns the action gradients, (env steps, 6 x primitives)."""
         import torch
         env, sim, n = self.env, self.sim, self.n
         prims = list(sim.primitives)
@@ -175,6 +180,8 @@ class WindowedEnvEpisode:
             for t, g in seeds.items():
                 if k0 * n < t <= k0 * n + n_sub or (t == 0 and w == 0):
                     sim.add_grad(t - k0 * n, **g)
+            if seed_fn is not None:
+                seed_fn(k0 * n, n_sub)
             sim.run_substeps_grad(0, n_sub)
             sim.cur = 0
             for i, m in enumerate(prims):                  # env step s of this window carries the action given one env step earlier

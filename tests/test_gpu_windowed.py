@@ -65,6 +65,10 @@ def test_windowed_episode_needs_few_frames():
     ep.forward(60)
     g, _ = ep.backward({60: dict(gx=np.ones((N, 3)))})
     assert np.isfinite(g[0]).all() and np.abs(g[0]).max() > 0
+    calls = []
+    g2, _ = ep.backward({}, seed_fn=lambda t0, n: (calls.append((t0, n)), sim.add_grad(n, gx=np.ones((N, 3))) if t0 + n == 60 else None))
+    assert calls == [(45, 15), (30, 15), (15, 15), (0, 15)]                     # the same seed, placed by the callback on the last window's last slot
+    assert H.rel_err(g2[0], g[0]) < 1e-5
     with pytest.raises(AssertionError):
         ep2 = WindowedEpisode(sim, 15)
         ep2.reset(state)

@@ -143,7 +143,7 @@ def _rebinning_outputs(precision, si, nsub=20, branches=True):
     #   bits 8-11 collide_mixed's branches per finger (primitive_base.py:152 inside the 5e-3 band, :168 forecast position inside the body)
     side = np.zeros((nsub, N), dtype=np.uint16) if branches else None
     base0 = None
-    for f in range(nsub if branches else 0):
+    for f in (range(0, nsub, 4) if branches else ()):         # (every fourth frame: these statistics are printed, not asserted, and were 50 s of the suite)
         s = sim.get_state(f)
         if base0 is None:
             base0 = np.floor(s[:, 0:3] * cfg.n_grid - 0.5).astype(np.int64)

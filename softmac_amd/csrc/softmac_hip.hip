@@ -165,6 +165,9 @@ template <class R> struct Sim final : ISim {
     // ---- epochs: one per re-sort.  Epoch 0 is the identity order of user-provided frames.
     struct Epoch {
         int* orig = nullptr;        // sorted slot -> original id (device)
+        int* from_prev = nullptr;   // slot in the epoch this one was sorted FROM -> slot here (the re-sort's destination map): an adjoint frame of this
+        int prev = -1;              // epoch goes back to that order by one gather through it, without the two inverse / compose passes
+        long long serial = 0, prev_serial = -1;   // (epoch slots are recycled: `prev` names the same epoch only while the serials match)
         int* cellrank = nullptr;    // sorted slot -> (cell << 5 | rank in the cell) at this binning: the next re-sort keeps the ranks of particles that stayed (smac_sort.hpp)
         int* inv = nullptr;         // original id -> sorted slot (device, lazy)
         bool inv_valid = false;
@@ -886,20 +889,20 @@ template <class R> struct Sim final : ISim {
 
     // ---- epochs / sorting ------------------------------------------------------------------
     static void free_epoch(Epoch& e) {
-        hipFree(e.orig); hipFree(e.cellrank); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
+        hipFree(e.orig); hipFree(e.cellrank); hipFree(e.from_prev); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
         hipFree(e.block_slot);
-        e.orig = e.cellrank = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
+        e.orig = e.cellrank = e.from_prev = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
         e.chunks = nullptr;
         e.live = false;
     }
     // a dropped epoch hands its device buffers to the pool (kernels still using them are ahead of any new writer on the stream)
     void retire_epoch(Epoch& e) {
         Epoch b;
-        b.orig = e.orig; b.cellrank = e.cellrank; b.inv = e.inv; b.chunks = e.chunks; b.active = e.active;
+        b.orig = e.orig; b.cellrank = e.cellrank; b.from_prev = e.from_prev; b.inv = e.inv; b.chunks = e.chunks; b.active = e.active;
         b.block_chunk_start = e.block_chunk_start; b.block_chunks = e.block_chunks; b.block_active = e.block_active;
         b.block_slot = e.block_slot;
         epoch_pool.push_back(std::move(b));
-        e.orig = e.cellrank = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
+        e.orig = e.cellrank = e.from_prev = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
         e.chunks = nullptr;
         e.inv_valid = false;
         e.live = false;
@@ -909,7 +912,7 @@ template <class R> struct Sim final : ISim {
         if (!epoch_pool.empty()) {
             Epoch b = std::move(epoch_pool.back());
             epoch_pool.pop_back();
-            ep.orig = b.orig; ep.cellrank = b.cellrank; ep.inv = b.inv; ep.chunks = b.chunks; ep.active = b.active;
+            ep.orig = b.orig; ep.cellrank = b.cellrank; ep.from_prev = b.from_prev; ep.inv = b.inv; ep.chunks = b.chunks; ep.active = b.active;
             ep.block_chunk_start = b.block_chunk_start; ep.block_chunks = b.block_chunks; ep.block_active = b.block_active;
             ep.block_slot = b.block_slot;
             ep.inv_valid = false;
@@ -917,6 +920,7 @@ template <class R> struct Sim final : ISim {
         }
         HIP_TRY(hipMalloc((void**)&ep.orig, D.Npad * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.cellrank, D.Npad * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.from_prev, D.Npad * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.chunks, chunk_capacity() * sizeof(Chunk)));
         HIP_TRY(hipMalloc((void**)&ep.active, ((size_t)nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.block_chunk_start, (nblocks + 1) * sizeof(int)));
@@ -1003,6 +1007,7 @@ template <class R> struct Sim final : ISim {
     // caller's (N, cols) array in the new order (192 contiguous bytes per particle) instead of being moved row by row - an episode's first
     // binning then costs no scattered frame move (411 us at 1M particles from a random order) and no copy-back.
     int resorts_done = 0;
+    long long epoch_serial = 0;
     int stable_ranks = getenv("SMAC_STABLE_RANKS") ? atoi(getenv("SMAC_STABLE_RANKS")) : 1;   // 0: every re-sort hands the ranks out afresh (round 2)
     int sort_frame(int f, bool read_drift = false, bool allow_repair = true, const double* aos = nullptr, int cols = 0) {
         const int e_old = frame_epoch[f];
@@ -1026,6 +1031,10 @@ template <class R> struct Sim final : ISim {
         hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot, (const int*)d_cell_count,
                            (const int*)d_bin_start, (const unsigned long long*)d_bin_mask, (const int*)d_over_prefix,
                            (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig, D.G <= ((size_t)1 << 26) ? ep.cellrank : (int*)nullptr);
+        HIP_TRY(hipMemcpyAsync(ep.from_prev, d_dest, (size_t)D.N * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        ep.prev = e_old;
+        ep.prev_serial = e_old > 0 ? epochs[e_old].serial : -1;
+        ep.serial = ++epoch_serial;
         if (aos) {
             auto rows = [&](int c0, int cnt, int offset, int ident) {
                 hipLaunchKernelGGL(k_rows_from_aos<R>, dim3(nblk(D.Npad)), dim3(BLOCK), 0, stream, D.N, D.Npad, aos, cols, offset, cnt, (const int*)ep.orig,
@@ -1143,7 +1152,9 @@ template <class R> struct Sim final : ISim {
         if (from < 0 || from == to) { *out = Af; return SMAC_OK; }   // all-zero frames have no order
         int rc;
         const int* map;
-        if (from == 0) map = epochs[to].orig;                          // identity -> sorted: src index = original id
+        if (from > 0 && to > 0 && epochs[from].prev == to && epochs[from].prev_serial == epochs[to].serial && epochs[from].from_prev)
+            map = epochs[from].from_prev;                              // the sweep crosses the re-sort that made `from` out of `to`: its destination map is the gather
+        else if (from == 0) map = epochs[to].orig;                     // identity -> sorted: src index = original id
         else {
             if ((rc = ensure_inverse(from))) return rc;
             if (to == 0) map = epochs[from].inv;

@@ -120,7 +120,9 @@ def build_sim(args, rank, world, precision=None, frames=None):
 def kernel_sources_sha1():
     import hashlib
     h = hashlib.sha1()
-    for name in ("smac_kernels.hpp", "smac_math.hpp", "smac_sort.hpp"):
+    # everything that can change the bytes a launch moves: the kernels, the launch structure (save-in-g2p, restore-ahead, skip-empty flags, ride-along
+    # parts live in softmac_hip.hip), the cloth contact kernels, and for N > 1 the migration / communication code
+    for name in ("smac_kernels.hpp", "smac_math.hpp", "smac_sort.hpp", "softmac_hip.hip", "smac_cloth.hpp", "smac_cloth_kernels.hpp", "smac_migrate.hpp", "smac_comm.hpp"):
         h.update(open(os.path.join(ROOT, "softmac_amd", "csrc", name), "rb").read())
     return h.hexdigest()
 
@@ -298,8 +300,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
     ap.add_argument("--sort-interval", type=int, default=0, help="0: min(32, steps), so that every timed window holds a re-sort")
-    ap.add_argument("--slab-runner", default=os.environ.get("SMAC_SLAB_RUNNER", "lib"), choices=["lib", "python"],
-                    help="N > 1: lib = smac_substeps_slab (RCCL inside the library); python = parallel.SlabRunner on torch.distributed")
+    ap.add_argument("--slab-runner", default=os.environ.get("SMAC_SLAB_RUNNER", "python"), choices=["lib", "python"],
+                    help="N > 1: python (default) = parallel.SlabRunner on torch.distributed (RCCL through torch); lib = smac_substeps_slab (RCCL inside "
+                         "the library) - selectable, not the default, until it has run between two different ranks (it has only run as a world-1 self exchange)")
     ap.add_argument("--launch-check", action="store_true",
                     help="spawn the ranks, rendezvous (gloo), report - no simulator, no GPU call (CPU test of the launcher)")
     return ap.parse_args(argv)
@@ -424,7 +427,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    walls, devs, forward, backward = timed_windows(args, sim, run, reducer, seed_gx, barrier, dist)
+    try:
+        walls, devs, forward, backward = timed_windows(args, sim, run, reducer, seed_gx, barrier, dist)
+    except Exception as e:                                  # noqa: BLE001
+        if world == 1:
+            raise
+        # One rank failed inside the collective loop (drift, the slab-range guard, a HIP / RCCL error): its neighbours sit in an exchange nobody will
+        # answer.  The library has aborted this rank's communicator (smac_substeps_slab: slab_guard); nothing is retried in-process - this rank ends
+        # NOW with a non-zero status and the launcher (torch.distributed.run) stops the others.  os._exit: no destructor may wait on the dead exchange.
+        print(f"bench.py: rank {rank} failed inside the collective run: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        try:
+            if hasattr(run, "abort"):
+                run.abort()
+        except Exception:                                   # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os._exit(1)
     order = sorted(range(len(walls)), key=lambda i: walls[i])
     mid = order[len(order) // 2]
     wall, dev_ms = walls[mid], devs[mid]

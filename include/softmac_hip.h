@@ -252,6 +252,12 @@ int smac_substeps_slab_grad(smac_handle h, int f0, int count, const double* ext_
 int smac_comm_allreduce_ext_f(smac_handle h, double* total_out, int clear);
 int smac_comm_allreduce_prim_grad(smac_handle h, int f_begin, int f_end);
 int smac_comm_destroy(smac_handle h);
+/* Failure inside the collective loop.  A rank whose smac_substeps_slab[_grad] / smac_migrate[_grad] fails while it holds a communicator of world > 1
+ * aborts that communicator itself (ncclCommAbort) before it returns the error: its neighbours have the matching receive enqueued and nothing will
+ * ever answer it, so the caller must END THE PROCESS with a non-zero status (the launcher then stops the peers) or, with a control plane of its own,
+ * tell the other ranks, which call smac_comm_abort - ncclCommAbort without the stream sync of smac_comm_destroy, which would wait for a receive
+ * that cannot complete.  Nothing is retried in-process.  (No reference counterpart: the reference is single-device.) */
+int smac_comm_abort(smac_handle h);
 /* Particle migration between slabs on the device (SURVEY 8e "Particle migration"; round 2 went through the host with get_state / set_state).
  * smac_migrate: the particles of frame f whose stencil base (x) left [base_lo, base_hi) go to the neighbour on that side (rows and global ids over
  * RCCL, neighbour-only); frame f + 1 starts the next segment = kept particles, arrivals from the left, arrivals from the right (the caller goes on

@@ -123,6 +123,7 @@ SIGNATURES = {
     "smac_comm_allreduce_ext_f": (C.c_int, [H, c_double_p, C.c_int]),
     "smac_comm_allreduce_prim_grad": (C.c_int, [H, C.c_int, C.c_int]),
     "smac_comm_destroy": (C.c_int, [H]),
+    "smac_comm_abort": (C.c_int, [H]),
     "smac_migrate": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_int32_p]),
     "smac_migrate_grad": (C.c_int, [H]),
     "smac_set_ids": (C.c_int, [H, C.POINTER(C.c_int64)]),

@@ -18,6 +18,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -32,25 +33,31 @@ struct Rccl {
         // or not torch.distributed ever uses it) gets THAT instance: RTLD_NOLOAD by the names it is known under.  Otherwise the ROCm install's
         // library is loaded with RTLD_DEEPBIND, so that its internal calls bind to itself whatever other copy a later import brings into the
         // process (without it, round 3's first run printed torch's library path from inside /opt/rocm's RCCL: symbols of two copies had mixed).
-        // SMAC_RCCL_LIB: explicit path, taken as given.
+        // SMAC_RCCL_LIB: explicit path, taken as given - if it does not load, nothing else is tried (tests/test_abi.py provokes the failure path with it).
         const char* forced = getenv("SMAC_RCCL_LIB");
-        if (forced && *forced) lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
-        if (!lib)
+        const bool only_forced = forced && *forced;
+        if (only_forced) lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        if (!lib && !only_forced)
             for (const char* n : {"librccl.so", "librccl.so.1"}) {
                 lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
                 if (lib) break;
             }
-        if (!lib)
+        if (!lib && !only_forced)
             for (const char* n : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
                 lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
                 if (lib) break;
             }
-        if (!lib) { err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return false; }
+        if (!lib) {
+            const char* why = dlerror();          // (one call: dlerror() clears the message it returns)
+            err = std::string("RCCL not found (dlopen librccl.so.1): ") + (why ? why : "no loader message");
+            return false;
+        }
         bool ok = true;
         auto sym = [&](const char* name) { void* p = dlsym(lib, name); if (!p) { ok = false; err = std::string("RCCL symbol missing: ") + name; } return p; };
         GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         Send = (decltype(Send))sym("ncclSend");

@@ -124,6 +124,7 @@ struct ISim {
     virtual int comm_allreduce_ext_f(double* total_out, int clear) = 0;
     virtual int comm_allreduce_prim_grad(int f0, int f1) = 0;
     virtual int comm_destroy() = 0;
+    virtual int comm_abort() = 0;
     virtual int migrate(int f, int base_lo, int base_hi, int32_t* out3) = 0;
     virtual int migrate_grad() = 0;
     virtual int set_ids(const int64_t* ids) = 0;
@@ -1618,21 +1619,29 @@ template <class R> struct Sim final : ISim {
         REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
         normalize_grid_set();
         // the hit counters of even and odd frames alternate (k_g2p<R, true> empties the next frame's while its save part still reads this one's)
-        D.nhits = d_nhits + ((f & 1) ? 4 : 0);
-        D.nhits_next = d_nhits + ((f & 1) ? 0 : 4);
-        if (phase <= 0 && nhits_zero_frame != f) {
-            HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
-            HIP_TRY(hipMemsetAsync(d_nhits + 4, 0, sizeof(int), stream));
-        }
-        if (phase <= 0) nhits_zero_frame = -1;
+        auto bind_hit_counters = [&]() {
+            D.nhits = d_nhits + ((f & 1) ? 4 : 0);
+            D.nhits_next = d_nhits + ((f & 1) ? 0 : 4);
+        };
+        bind_hit_counters();
         if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
             int e = frame_epoch[f];
+            const int repairs_before = drift_repairs;
             if (e == 0 || f - epochs[e].frame >= epochs[e].interval || f < epochs[e].frame) {
                 if ((rc = sort_frame(f, e > 0))) return rc;                     // also reports a drift error of the epoch that ends here
                 e = frame_epoch[f];
             }
+            // A drift repair inside sort_frame replays substeps fs .. f-1 through this function: they re-bound the counter pair to THEIR parity and
+            // left counts behind.  Bind for f again and start from two empty counters (the stale binding appended behind nh(f-1) hits and
+            // the contact correction of those particles was applied twice).
+            bind_hit_counters();
+            if (nhits_zero_frame != f || drift_repairs != repairs_before) {
+                HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
+                HIP_TRY(hipMemsetAsync(d_nhits + 4, 0, sizeof(int), stream));
+            }
+            nhits_zero_frame = -1;
             if ((rc = bind_epoch(e))) return rc;
             ck_epoch[f] = -1;
             // whole substep on one GPU: k_grid_op / k_contact_hits file the forward grid in the frame's checkpoint slot themselves
@@ -2150,16 +2159,40 @@ template <class R> struct Sim final : ISim {
         ++exchanges_done;
         return check_launch();
     }
+    // A failure on ONE rank inside a collective loop (drift, the slab-range guard, a HIP error ...) returns on that rank only, while its neighbours
+    // have the matching ncclRecv enqueued and would wait for ever.  With a live multi-rank communicator the failing rank therefore
+    // ABORTS it (ncclCommAbort: its own pending operations are torn down, nothing is retried in-process) and says so in the message; the caller is
+    // expected to end the process with a non-zero status so that the launcher tears the peers down (bench.py; parallel.agreed_failure for hosts that
+    // have a control plane of their own).  World 1 (the self-loop test mode) has no peer to release and keeps its communicator.
+    int slab_guard(int rc) {
+        if (rc != SMAC_OK && comm && c_world > 1) {
+            Rccl& L = Rccl::get();
+            if (L.CommAbort) L.CommAbort(comm);
+            comm = nullptr;
+            sc.on = false;
+            err += " [rank " + std::to_string(c_rank) + ": the RCCL communicator was aborted; end this process so that the launcher stops the other ranks]";
+        }
+        return rc;
+    }
+    int comm_abort() override {                               // the host's reaction to ANOTHER rank's failure: no stream sync (a receive may never complete)
+        if (comm) {
+            Rccl& L = Rccl::get();
+            if (L.CommAbort) L.CommAbort(comm);
+            comm = nullptr;
+        }
+        sc.on = false;
+        return SMAC_OK;
+    }
     int substeps_slab(int f0, int count) override {
         REQUIRE(sc.on, "substeps_slab: no slab geometry (smac_comm_slab)");
         const bool contact = sc.contact_l || sc.contact_r;
         int rc;
         for (int f = f0; f < f0 + count; ++f) {
-            if ((rc = substep_phase(f, nullptr, 0))) return rc;
-            if ((rc = exchange(D.vin, nullptr, false))) return rc;                       // {m, p} partials after P2G
-            if ((rc = substep_phase(f, nullptr, 1))) return rc;
-            if (contact && any_contact() && (rc = exchange(D.vout, D.vmix, true))) return rc;   // contact corrections v_out - v_mixed
-            if ((rc = substep_phase(f, nullptr, 2))) return rc;
+            if ((rc = substep_phase(f, nullptr, 0))) return slab_guard(rc);
+            if ((rc = exchange(D.vin, nullptr, false))) return slab_guard(rc);                       // {m, p} partials after P2G
+            if ((rc = substep_phase(f, nullptr, 1))) return slab_guard(rc);
+            if (contact && any_contact() && (rc = exchange(D.vout, D.vmix, true))) return slab_guard(rc);   // contact corrections v_out - v_mixed
+            if ((rc = substep_phase(f, nullptr, 2))) return slab_guard(rc);
         }
         return SMAC_OK;
     }
@@ -2168,11 +2201,11 @@ template <class R> struct Sim final : ISim {
         const bool contact = sc.contact_l || sc.contact_r;
         int rc;
         for (int f = f0 + count - 1; f >= f0; --f) {
-            if ((rc = substep_grad_phase(f, nullptr, f == f0 + count - 1 ? ext_f_grad : nullptr, nullptr, 0))) return rc;
-            if ((rc = exchange(D.aout, nullptr, false))) return rc;                      // grid_v_out.grad partials after g2p.grad
-            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 1))) return rc;
-            if (contact && any_contact() && (rc = exchange(D.amix, nullptr, true))) return rc;   // grid_v_mixed.grad partials after the contact adjoint
-            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 2))) return rc;
+            if ((rc = substep_grad_phase(f, nullptr, f == f0 + count - 1 ? ext_f_grad : nullptr, nullptr, 0))) return slab_guard(rc);
+            if ((rc = exchange(D.aout, nullptr, false))) return slab_guard(rc);                      // grid_v_out.grad partials after g2p.grad
+            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 1))) return slab_guard(rc);
+            if (contact && any_contact() && (rc = exchange(D.amix, nullptr, true))) return slab_guard(rc);   // grid_v_mixed.grad partials after the contact adjoint
+            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 2))) return slab_guard(rc);
         }
         return SMAC_OK;
     }
@@ -2289,6 +2322,13 @@ template <class R> struct Sim final : ISim {
     // Hand the particles of frame f whose stencil base left [base_lo, base_hi) to the neighbour on that side; frame f + 1 starts the next segment
     // (kept particles, then the arrivals from the left, then from the right).  out3: {live particles now, sent away, received}.
     int migrate(int f, int base_lo, int base_hi, int32_t* out3) override {
+        MigRec rec = {};
+        bool filed = false;
+        const int rc = migrate_impl(f, base_lo, base_hi, out3, rec, filed);
+        if (rc && !filed) { hipFree(rec.src_slot); hipFree(rec.ids_old); }       // (the record's buffers leaked on the error paths behind their allocation)
+        return slab_guard(rc);
+    }
+    int migrate_impl(int f, int base_lo, int base_hi, int32_t* out3, MigRec& rec, bool& filed) {
         int rc;
         REQUIRE(sc.on, "migrate: no slab geometry (smac_comm_slab)");
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames && frame_epoch[f] >= 0, "migrate: frame f holds no state or f + 1 exceeds max_frames");
@@ -2330,7 +2370,7 @@ template <class R> struct Sim final : ISim {
         REQUIRE(n_new >= 1, "migrate: this slab lost all its particles");
         REQUIRE(n_new <= cfg.n_particles, "migrate: more particles arrive than the handle's capacity (n_particles) holds");
         if ((rc = mig_reserve(0, nl)) || (rc = mig_reserve(1, nr)) || (rc = mig_reserve(2, in_counts[0])) || (rc = mig_reserve(3, in_counts[1]))) return rc;
-        MigRec rec = {f, e, N, nk, nl, nr, in_counts[0], in_counts[1], nullptr, nullptr};
+        rec = MigRec{f, e, N, nk, nl, nr, in_counts[0], in_counts[1], nullptr, nullptr};
         HIP_TRY(hipMalloc((void**)&rec.src_slot, (size_t)(N > 0 ? N : 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&rec.ids_old, (size_t)Npad * sizeof(long long)));
         HIP_TRY(hipMemcpyAsync(rec.ids_old, d_ids, (size_t)Npad * sizeof(long long), hipMemcpyDeviceToDevice, stream));
@@ -2350,6 +2390,7 @@ template <class R> struct Sim final : ISim {
         hipLaunchKernelGGL(k_mig_pad<R>, dim3(nblk(Npad - n_new + 1)), dim3(BLOCK), 0, stream, n_new, Npad, Sn);
         HIP_TRY(hipMemcpyAsync(d_ids, ids_new, (size_t)n_new * sizeof(long long), hipMemcpyDeviceToDevice, stream));
         migs.push_back(rec);
+        filed = true;
         D.N = n_new;
         D.frame_shift += 1;
         frame_epoch[f + 1] = 0;                                            // the new segment's caller order; binned at its first substep
@@ -2361,6 +2402,14 @@ template <class R> struct Sim final : ISim {
     // Backward of the most recent migrate: the adjoint of the later segment's first frame goes back to the frame it was copied from - across the
     // slab boundary for the particles that crossed it - and is ADDED there (frame f may carry seeds of its own).
     int migrate_grad() override {
+        // the segment bookkeeping (live particle count, frame shift) is restored when the way back fails: the record is still on the tape then,
+        // and the handle must keep describing the LATER segment it belongs to
+        const int n_keep = D.N, shift_keep = D.frame_shift;
+        const int rc = migrate_grad_impl();
+        if (rc) { D.N = n_keep; D.frame_shift = shift_keep; }
+        return slab_guard(rc);
+    }
+    int migrate_grad_impl() {
         int rc;
         REQUIRE(!migs.empty(), "migrate_grad: no migration on record");
         if ((rc = need_grad())) return rc;
@@ -2865,6 +2914,7 @@ int smac_substeps_slab_grad(smac_handle h, int f0, int count, const double* ext_
 int smac_comm_allreduce_ext_f(smac_handle h, double* total_out, int clear) { return FWD(comm_allreduce_ext_f(total_out, clear)); }
 int smac_comm_allreduce_prim_grad(smac_handle h, int f_begin, int f_end) { return FWD(comm_allreduce_prim_grad(f_begin, f_end)); }
 int smac_comm_destroy(smac_handle h) { return FWD(comm_destroy()); }
+int smac_comm_abort(smac_handle h) { return FWD(comm_abort()); }
 int smac_migrate(smac_handle h, int f, int base_lo, int base_hi, int32_t out3[3]) { return FWD(migrate(f, base_lo, base_hi, out3)); }
 int smac_migrate_grad(smac_handle h) { return FWD(migrate_grad()); }
 int smac_set_ids(smac_handle h, const int64_t* ids) { return FWD(set_ids(ids)); }

@@ -281,6 +281,22 @@ def all_ranks_ok(error, group=None):
     return [f"rank {r}: {e}" for r, e in enumerate(allf) if e]
 
 
+def agreed_failure(error, runner=None, group=None):
+    """End of a window of collective work (bench.py calls it once per timed window, outside the substep loop): every rank reports None or its
+    failure; if ANY rank failed, every rank aborts its communicator (`runner.abort()`: ncclCommAbort - the failing rank's library already did,
+    smac_comm_abort elsewhere releases receives that would never be answered) and raises the same RuntimeError naming the ranks that failed.
+    The caller lets it propagate: a non-zero exit is what makes the launcher stop everybody (an error on one rank must not leave its
+    neighbours waiting in an exchange)."""
+    failed = all_ranks_ok(error, group=group)
+    if failed:
+        if runner is not None and hasattr(runner, "abort"):
+            try:
+                runner.abort()
+            except Exception:                                # noqa: BLE001 - the failure being reported is the one that matters
+                pass
+        raise RuntimeError("collective run failed: " + "; ".join(failed))
+
+
 def agree_contact_sides(sides, rank, world, group=None):
     """`contact_sides` is evaluated per rank; a boundary's two ranks must take the same decision or one of them posts an exchange the other
     does not: every rank learns every rank's flags and a boundary uses the OR of its two sides."""
@@ -364,6 +380,10 @@ class LibSlabRunner:
 
     def close(self):
         self.sim._h.call("smac_comm_destroy")
+
+    def abort(self):
+        """another rank failed inside the collective loop: drop the communicator without waiting for its pending receives (smac_comm_abort)"""
+        self.sim._h.call("smac_comm_abort")
 
 
 def contact_sides(specs, states, n_grid, left_plane0, right_plane0, nplanes, rank, world, band=5e-3, drift_cells=2.0):

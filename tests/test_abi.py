@@ -43,3 +43,27 @@ def test_product_does_not_reference_the_oracle():
         if p.suffix in (".py", ".hpp", ".hip", ".h", ".cpp"):
             text = p.read_text()
             assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, p
+
+
+def test_rccl_not_found_is_an_error_message_not_a_crash(hip_lib):
+    """the 'RCCL not found' path built its message from two dlerror() calls (the second returns NULL).  A forced library path
+    that does not exist must come back as SMAC_ERR_INVALID with a message; run in a child so that this process keeps its own loader state."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {str(H.ROOT)!r})\n"
+        "from softmac_amd import _ffi\n"
+        "lib = _ffi.load_library()\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "rc = lib.smac_comm_unique_id(buf)\n"
+        "msg = lib.smac_last_error(None)\n"
+        "msg = msg.decode() if isinstance(msg, bytes) else str(msg)\n"
+        "print(rc, '|', msg)\n"
+    )
+    env = dict(os.environ, SMAC_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, msg = out.stdout.strip().split("|", 1)
+    assert int(rc) != 0 and "RCCL not found" in msg and "librccl-not-here" in msg, out.stdout

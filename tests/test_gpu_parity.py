@@ -312,6 +312,52 @@ def test_drift_repair_inside_a_multi_env_step_epoch_does_not_double_count_ext_f(
     assert H.rel_err(sim.get_x(n), x) < 1e-9
 
 
+def test_drift_repair_found_at_a_resort_leaves_the_hit_counters_of_the_next_substep_clean():
+    """the re-sort at frame 32 finds the drift flag INSIDE a batched run; the replay of substeps 0 .. 31 re-binds the alternating hit
+    counters to frame 31's parity and leaves that frame's count behind.  Substep 32 must start from its own, empty counter: before the fix the
+    particles of frame 31's list were appended again, their contact correction and wrench applied twice and the duplicated list filed with the
+    checkpoint.  Checked on the substeps after the repair: wrench per env step, state, the number of particles the contact kernels walked, and the
+    adjoint through them."""
+    n_grid, N, n = 32, 1500, 36
+    state = H.make_cloud(N, n_grid, seed=21, lo=(0.3, 0.6, 0.3), hi=(0.6, 0.8, 0.6), v_std=0.0)
+    state[:, 3:6] = 0.0
+    palm = H.load_palm()
+    spec = dict(palm, friction=0.4, softness=666.0, contact=True)
+    s13 = np.concatenate([[0.45, 0.45, 0.33], [1.0, 0.0, 0.0, 0.0], np.zeros(6)])
+    pstates = [[s13.copy()] for _ in range(n + 1)]
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, gravity=(0., -9000., 0.), ground_friction=0.0, precision="float64", sort_interval=32, max_steps=40)
+    P = H.oracle_params(cfg, 2.4e-3)
+    assert P.substeps == 12
+    orc = H.OracleRollout(P, state, [spec], pstates).forward(n)
+    ext = np.array(orc.ext)[:, 0]
+    sim, prims = H.build_engine(cfg, 2.4e-3, [spec], pstates)
+    sim.reset(state)
+    got = []
+    for k in range(3):
+        sim.run_substeps(12 * k, 12)                      # the third call crosses frame 32: re-sort, drift flag, replay, then substeps 32 .. 35
+        if k == 2:
+            assert sim.get_param("drift_repairs") >= 1    # (repaired inside the call, before any host read)
+            walked = sim.contact_counts()[0]
+        got.append(prims[0].ext_f.to_numpy().copy())
+        prims[0].clear_ext_f()
+    for k in range(3):
+        ref = ext[12 * k:12 * k + 12].sum(axis=0)
+        assert np.abs(got[k] - ref).max() < 1e-8 * np.abs(ref).max(), (k, got[k], ref)
+    x = orc.frames[n][0].numpy()
+    assert H.rel_err(sim.get_x(n), x) < 1e-9
+    prim = orc.prims_at(n - 1)[0]
+    band = int((O.prim_sdf(prim, orc.frames[n - 1][0]) <= 5e-3).sum())
+    assert band > 0 and abs(walked - band) <= 1, (walked, band)    # every particle of the band once (one on the band's edge may differ) - a stale counter doubles it
+    rng = np.random.default_rng(5)
+    sn = (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), None, None)
+    adj, _, _ = orc.backward({n: sn})
+    sim.clear_grads()
+    sim.add_grad(n, gx=sn[0], gv=sn[1])
+    sim.run_substeps_grad(0, n)
+    gx, gv = sim.get_grad(0)
+    assert H.rel_err(gx, adj[0][0].numpy()) < 1e-8 and H.rel_err(gv, adj[0][1].numpy()) < 1e-8
+
+
 @pytest.mark.parametrize("precision", ["float64", "float32"])
 def test_contact_hit_list_overflow_degrades_to_the_band_test(precision):
     """more particles inside a contact band than a checkpoint's hit-list slot holds (max(8192, N/8)): round 2 failed with an error at

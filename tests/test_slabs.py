@@ -244,3 +244,22 @@ def test_rendezvous_failure_reaches_every_rank(tmp_path, mode):
         assert all(r["err"] and "librccl" in r["err"] for r in res) and len(res[0]["failed"]) == 2
     else:
         assert res[0]["err"] is None and res[0]["failed"] == ["rank 1: SmacError: smac_comm_init failed"]
+
+
+@pytest.mark.parametrize("mode", ["fine", "rank1_fails"])
+def test_run_time_failure_on_one_rank_surfaces_on_all(tmp_path, mode):
+    """an error inside the collective loop returns on ONE rank (drift, the slab-range guard, a HIP error) while its neighbour waits in the
+    matching receive.  The failing rank's library aborts its communicator (softmac_hip.hip slab_guard); a host with a control plane then calls
+    parallel.agreed_failure at the end of the window: every rank learns of the failure, drops its own communicator (smac_comm_abort) and raises the
+    same error.  (bench.py, which runs under a launcher, ends the failing rank with a non-zero status instead and lets the launcher stop the peers.)"""
+    import json
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, str(HERE / "agreed_failure_worker.py"), str(r), "2", port, str(tmp_path), mode]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    if mode == "fine":
+        assert all(r["raised"] is None and not r["aborted"] for r in res)
+    else:
+        assert res[0]["raised"] == res[1]["raised"] and "rank 1:" in res[0]["raised"] and "left the halo" in res[0]["raised"]
+        assert all(r["aborted"] for r in res)

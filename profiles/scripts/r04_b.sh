@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 4, session B: deferred-particle build - parity, then A/B against the build of the commit before it (libsoftmac_hip_base.so), then the full suite
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04b; mkdir -p $O
+make -C oracle -s
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_backward.py tests/test_gpu_resort.py -x -q -m gpu > $O/pytest_quick.log 2>&1
+echo "pytest quick rc $?"; tail -5 $O/pytest_quick.log
+for round in 1 2; do
+  for v in base new; do
+    lib=libsoftmac_hip.so; [ $v = base ] && lib=libsoftmac_hip_base.so
+    SMAC_LIB=$PWD/softmac_amd/lib/$lib timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f64 --no-cloth --no-env-loop --repeats 3 > $O/bench_${v}_$round.json 2> $O/bench_${v}_$round.err
+    python3 -c "
+import json;d=json.loads([l for l in open('$O/bench_${v}_$round.json') if l.startswith('{')][-1]); print('$v round $round', round(d['value'],1), d['ms_per_step_all'], {k: round(x*1e3,1) for k,x in d['kernels_ms_per_step'].items()})"
+  done
+done
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > $O/pytest_full.log 2>&1
+echo "pytest full rc $?"; tail -5 $O/pytest_full.log

@@ -326,11 +326,11 @@ def test_drift_repair_found_at_a_resort_leaves_the_hit_counters_of_the_next_subs
     s13 = np.concatenate([[0.45, 0.45, 0.33], [1.0, 0.0, 0.0, 0.0], np.zeros(6)])
     pstates = [[s13.copy()] for _ in range(n + 1)]
     cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, gravity=(0., -9000., 0.), ground_friction=0.0, precision="float64", sort_interval=32, max_steps=40)
-    P = H.oracle_params(cfg, 2.4e-3)
+    P = H.oracle_params(cfg, 2.41e-3)
     assert P.substeps == 12
     orc = H.OracleRollout(P, state, [spec], pstates).forward(n)
     ext = np.array(orc.ext)[:, 0]
-    sim, prims = H.build_engine(cfg, 2.4e-3, [spec], pstates)
+    sim, prims = H.build_engine(cfg, 2.41e-3, [spec], pstates)
     sim.reset(state)
     got = []
     for k in range(3):

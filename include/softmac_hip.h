@@ -109,6 +109,12 @@ int smac_clear_grads(smac_handle h);                                          /*
  * window's backward sweep leaves on its first frame is the seed of the window before it (softmac_amd/engine/windowed.py).  Not with rolling adjoint storage. */
 int smac_carry_grad(smac_handle h, int src, int dst);
 int smac_set_control_idx(smac_handle h, const int32_t* idx);                  /* set_control_idx :599-602 */
+/* Two-entry material table (round 4, BASELINE config C5 "two material blocks").  The reference's mu / lam / yield_stress are per-particle fields
+ * (mpm_simulator.py:47-49; soft_cloth/engine/mpm_simulator.py:47-50), filled uniformly (:86-90): a scene with two kinds of particles keeps two entries
+ * and one selector per particle.  ids: n_particles entries, 0 = the material of smac_config (mu, lam, smac_set_param "yield_ratio"), 1 = entry 1
+ * (smac_set_param "mu2" / "lam2" / "yield_ratio2"); indexed by the caller's particle id; NULL: one material again.  ptype / model / plasticity stay
+ * per handle as in the reference.  Not with penalty contact (collision_type 1). */
+int smac_set_material_ids(smac_handle h, const int32_t* ids);
 /* Slab decomposition with particle MIGRATION (no reference counterpart): a handle is created with the CAPACITY
  * n_particles; a rank's live particle count changes when particles are handed to a neighbouring slab.  Frames written or
  * processed after this call hold `n_live` particles (the caller keeps frames of different segments apart: the migration point

@@ -56,6 +56,7 @@ SIGNATURES = {
     "smac_clear_grads": (C.c_int, [H]),
     "smac_carry_grad": (C.c_int, [H, C.c_int, C.c_int]),
     "smac_set_control_idx": (C.c_int, [H, c_int32_p]),
+    "smac_set_material_ids": (C.c_int, [H, c_int32_p]),
     "smac_set_action": (C.c_int, [H, c_double_p]),
     "smac_set_segment": (C.c_int, [H, C.c_int, C.c_int]),
     "smac_compute_grid_m": (C.c_int, [H, C.c_int, c_double_p]),

@@ -233,18 +233,26 @@ __global__ __launch_bounds__(BLOCK) void k_cloth_hit_list(DevSim<R> D, int f) {
     if (!valid) return;
     const ClothDev& Cl = D.cloth;
     const size_t at = (size_t)f * Cl.n_ids + D.orig_id[p];
-    const int face = Cl.contact_id[at];
+    int face = Cl.contact_id[at];
     const int pen = (face >= 0 && Cl.penetration[at] == 1) ? 1 : 0;
     if (D.collision_type == CONTACT_PARTICLE) D.pmask[p] = face >= 0 ? (1 | (pen << 1)) : 0;   // read back by p2g.grad (rebuilt here when the forward grid comes from a checkpoint)
-    if (face < 0) return;
-    if (!pen) {
+    // a scene that also holds SDF primitives (round 4, "mixed soft-rigid-cloth"): their band test runs here, so that a particle in reach of both is ONE entry -
+    // the contact chain is sequential (primitives in index order, then the sheet).  Hit::mask = sheet bits | primitive band bits << 8.
+    int pm = 0;
+    if (D.P > 0 && D.collision_type == CONTACT_MIXED) {
+        typename pos_of<R>::type xp[3];
+        load_pos(frame(D.S, f, D.Npad), D.Npad, p, xp);
+        pm = contact_mask(D, f, xp);
+    }
+    if (face >= 0 && !pen) {
         double px[3];
         cloth_particle_pos(D, frame(D.S, f, D.Npad), p, px);
         const double* vp = Cl.pos + (size_t)f * Cl.V * 3;
         const int* v = Cl.faces + 3 * face;
-        if (cl_distance(px, vp + 3 * v[0], vp + 3 * v[1], vp + 3 * v[2]) > (5e-3 + 1e-6) * Cl.par.scale) return;
+        if (cl_distance(px, vp + 3 * v[0], vp + 3 * v[1], vp + 3 * v[2]) > (5e-3 + 1e-6) * Cl.par.scale) face = -1;
     }
-    Hit h = {p, 1 | (pen << 1), ch.block, face};
+    if (face < 0 && pm == 0) return;
+    Hit h = {p, (face >= 0 ? (1 | (pen << 1)) : 0) | (pm << 8), ch.block, face >= 0 ? face : 0};
     D.hits[hit_slot(D.nhits)] = h;
 }
 

@@ -81,6 +81,11 @@ template <class R> struct DevSim {
     R m_eps;                     // a grid node carries a velocity when its mass exceeds this (1e-10, mpm_simulator.py:286; rescaled with mpm_scale^-2)
     R g[3];
     Material<R> mat;
+    // Two-entry material table (round 4, BASELINE config C5 "two material blocks"): the reference's mu / lam / yield_stress are PER-PARTICLE fields
+    // (mpm_simulator.py:47-49, filled uniformly at :86-90); a scene with two kinds of particles keeps two (mu, lam, yield) entries and one selector byte
+    // per particle (indexed by ORIGINAL particle id, like control_idx) instead of three rows.  mat_id == nullptr: one material (the MAT2 = false kernels).
+    R mu2, lam2, yield_c2;
+    const unsigned char* mat_id;
     R* S;
     R* A;
     R* Af;                       // adjoint frame of the substep being reversed (frames may live in rolling slots: set per launch)
@@ -325,6 +330,13 @@ template <class R> __device__ __forceinline__ void stencil_at(const DevSim<R>& D
         nd.oky |= ((unsigned)lj < (unsigned)TW) << o;
         nd.okz |= ((unsigned)lk < (unsigned)TW) << o;
     }
+}
+
+// the particle's material: entry 0 or - MAT2 instantiations, selector byte set - entry 1 of the two-entry table
+template <class CT, bool MAT2, class R> __device__ __forceinline__ Material<CT> particle_material(const DevSim<R>& D, int p) {
+    Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam, D.mat.plast, (CT)D.mat.yield_c};
+    if (MAT2 && D.mat_id && D.mat_id[D.orig_id[p]]) { mat.mu = (CT)D.mu2; mat.lam = (CT)D.lam2; mat.yield_c = (CT)D.yield_c2; }
+    return mat;
 }
 
 // F_tmp - I = E + dt (C + C E)     (compute_F_tmp, :125-128)
@@ -604,7 +616,8 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
 // ------------------------------------------------------------------------------------------
 // PCON: collision_type 1 (penalty contact inside p2g) - a separate instantiation, so that the benchmarked forecast-contact
 // kernel does not carry the f64 penalty chain in its register budget
-template <class R, bool STORE_F, bool PCON>
+// MAT2: the two-entry material table (a separate instantiation: the benchmarked one-material kernel keeps its registers)
+template <class R, bool STORE_F, bool PCON, bool MAT2 = false>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_p2g(DevSim<R> D, int f) {
     typedef typename ScatterTile<R>::word W;
     __shared__ double tile_raw[4 * TILE_WORDS];
@@ -666,7 +679,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
 #pragma unroll
             for (int i = 0; i < 9; ++i) { Cc[i] = (CT)C[i]; Ec[i] = (CT)E[i]; }
             f_tmp(Cc, Ec, (CT)D.dt, Etc);
-            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam, D.mat.plast, (CT)D.mat.yield_c};
+            const Material<CT> mat = particle_material<CT, MAT2>(D, p);
             ConstState<CT> cs;
             constitutive_fwd(mat, Etc, Enc, sc, cs);
 #pragma unroll
@@ -996,7 +1009,23 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         // mixed3 in double whatever R is: the push-out divides a signed distance by dt
         const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])};
         double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
-        if (CLOTH && mask) {                                                                // mixed3, soft_cloth :419-428
+        // CLOTH instantiation: Hit::mask = sheet bits (0: has a contact face, 1: penetrated) | SDF-primitive band bits << 8.  A scene with SDF primitives
+        // AND the sheet (round 4; BASELINE config C5 "mixed soft-rigid-cloth") walks the primitives in index order, then the sheet - the reference has no
+        // simulator with both (softmac :421-429 loops the primitives, soft_cloth :419-428 has the one sheet): the composition is this build's.
+        const int pmask = CLOTH ? (mask >> 8) & 15 : mask;
+#pragma unroll 1
+        for (int i = 0; i < D.P; ++i) {                                                     // mixed3: the SDF primitives in index order (:427)
+            if (!((pmask >> i) & 1)) continue;
+            const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+            double s13[13], ext[6] = {0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
+            collide_mixed(D.prim64[i], s13, x64, v_tgt, (double)D.p_mass, D.dt64, life, ext);
+            if (d < 6) {                                                                    // lane c adds component c
+                const double e = d == 0 ? ext[0] : (d == 1 ? ext[1] : (d == 2 ? ext[2] : (d == 3 ? ext[3] : (d == 4 ? ext[4] : ext[5]))));
+                if (e != 0.0) __hip_atomic_fetch_add(ext_acc + i * 6 + d, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (CLOTH && (mask & 1)) {                                                          // mixed3, soft_cloth :419-428: the sheet, on the velocity the primitives left
             const ClothDev& Cl = D.cloth;
             const double sc = Cl.par.scale;
             const int* vid = Cl.faces + 3 * h.pad;
@@ -1015,18 +1044,6 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
                     const double wv = vi == 0 ? wb[0] : (vi == 1 ? wb[1] : wb[2]), cc = c == 0 ? cf[0] : (c == 1 ? cf[1] : cf[2]);
                     atomic_add(Cl.ext_f + (size_t)(vi == 0 ? vid[0] : (vi == 1 ? vid[1] : vid[2])) * 3 + c, cc * wv);
                 }
-            }
-        }
-#pragma unroll 1
-        for (int i = 0; i < (CLOTH ? 0 : D.P); ++i) {                                       // mixed3
-            if (!((mask >> i) & 1)) continue;
-            const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-            double s13[13], ext[6] = {0, 0, 0, 0, 0, 0};
-            for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-            collide_mixed(D.prim64[i], s13, x64, v_tgt, (double)D.p_mass, D.dt64, life, ext);
-            if (d < 6) {                                                                    // lane c adds component c
-                const double e = d == 0 ? ext[0] : (d == 1 ? ext[1] : (d == 2 ? ext[2] : (d == 3 ? ext[3] : (d == 4 ? ext[4] : ext[5]))));
-                if (e != 0.0) __hip_atomic_fetch_add(ext_acc + i * 6 + d, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         if (mask && d < 27 && has) {                                                        // mixed4, alpha = 2 (:437)
@@ -1581,11 +1598,15 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         double dummy[6];
         // One primitive in range (the usual case): the value part of the dual pass below IS the forward result,
         // so the separate forward evaluation - a second chain of dependent SDF lookups - is skipped.
-        const bool single = CLOTH || (mask != 0 && (mask & (mask - 1)) == 0);
-        if (!single) {
+        // (CLOTH instantiation: sheet bits | primitive band bits << 8, see k_contact_hits; the forward chain is primitives in index order, then the sheet,
+        //  so the adjoint takes the sheet first and the primitives in reverse)
+        const int pm = CLOTH ? (mask >> 8) & 15 : mask;
+        const bool cloth_on = CLOTH && (mask & 1) != 0;
+        const bool single = !cloth_on && pm != 0 && (pm & (pm - 1)) == 0;
+        if (!single) {                        // velocity after the primitives (the sheet's input; the final velocity when there is no sheet)
 #pragma unroll 1
             for (int i = 0; i < D.P; ++i)
-                if ((mask >> i) & 1) {
+                if ((pm >> i) & 1) {
                     const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                     double s13[13];
                     for (int c = 0; c < 13; ++c) s13[c] = ps[c];
@@ -1597,15 +1618,15 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         if (CLOTH) {
             const ClothDev& Cl = D.cloth;
             const double sc = Cl.par.scale;
-            const bool act = mask != 0;
+            const bool act = cloth_on;
             const int* vid = Cl.faces + 3 * (act ? h.pad : 0);
             double out = 0.0, vfwd[3] = {0.0, 0.0, 0.0};
             if (act && d < 24) {
-                // particle position / velocity are unit-domain variables (x = sc * u), the vertices physical
+                // particle position / velocity are unit-domain variables (x = sc * u), the vertices physical; the velocity is the one the primitives left
                 Dual<double> pos[3], v[3], xv[3][3], vv[3][3], cf[3], wb[3];
                 for (int c = 0; c < 3; ++c) {
                     pos[c] = Dual<double>(sc * x64[c], d == c ? sc : 0.0);
-                    v[c] = Dual<double>(sc * (double)v_tmp[c], d == 3 + c ? sc : 0.0);
+                    v[c] = Dual<double>(sc * v_tgt[c], d == 3 + c ? sc : 0.0);
                 }
                 for (int i = 0; i < 3; ++i)
                     for (int c = 0; c < 3; ++c) {
@@ -1633,8 +1654,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             }
         }
 #pragma unroll 1
-        for (int i = (CLOTH ? 0 : D.P) - 1; i >= 0; --i) {
-            const bool act = (mask >> i) & 1;
+        for (int i = D.P - 1; i >= 0; --i) {
+            const bool act = (pm >> i) & 1;
             if (!__ballot(act)) continue;
             double out = 0.0;
             double vfwd[3] = {0.0, 0.0, 0.0};
@@ -1643,7 +1664,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                 // velocity entering primitive i: replay the chain up to i
                 double vin[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
                 for (int q = 0; q < i; ++q)
-                    if ((mask >> q) & 1) {
+                    if ((pm >> q) & 1) {
                         const double* pq = D.prim_state + ((size_t)q * D.max_frames + f) * 13;
                         double sq[13];
                         for (int c = 0; c < 13; ++c) sq[c] = pq[c];
@@ -1944,7 +1965,7 @@ template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SM
 // p2g.grad + svd_grad + compute_F_tmp.grad of one particle (mpm_simulator.py:371-374): `gt` is the staged grid_v_in.grad / grid_m.grad tile, `stash` the
 // workgroup's LDS parking space.  Writes the adjoint of frame f to D.Af; KEEP: also hands x.grad, v.grad, C.grad of frame f back in registers
 // (k_p2g_g2p_grad feeds them to the G2P adjoint of the substep before) - only with ACC_VCF = false, i.e. when frame f carried no seed.
-template <class R, bool ACC_VCF, bool PCON, bool KEEP>
+template <class R, bool ACC_VCF, bool PCON, bool KEEP, bool MAT2 = false>
 __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, const Chunk& ch, int p, int t, typename const_t<R>::type* stash, const Vec4<R>* gt,
                                                   R* gx_o, R* gv_o, R* gC_o) {
     constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
@@ -1976,7 +1997,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
 #pragma unroll
             for (int i = 0; i < 9; ++i) { Cc[i] = (CT)C[i]; Ec[i] = (CT)E[i]; }
             f_tmp(Cc, Ec, (CT)D.dt, Et);
-            const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam, D.mat.plast, (CT)D.mat.yield_c};
+            const Material<CT> mat = particle_material<CT, MAT2>(D, p);
             constitutive_fwd(mat, Et, En, stress, cs);
         }
 #pragma unroll
@@ -2156,7 +2177,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
 #else
         for (int i = 0; i < 9; ++i) { G[i] = (CT)(D.stress_scale * gaff[i]); gFc[i] = (CT)gFn[i]; }
 #endif
-        const Material<CT> mat = {D.mat.ptype, D.mat.model, (CT)D.mat.mu, (CT)D.mat.lam, D.mat.plast, (CT)D.mat.yield_c};
+        const Material<CT> mat = particle_material<CT, MAT2>(D, p);
         constitutive_bwd(mat, Et, cs, G, gFc, gEc);
 #pragma unroll
         for (int i = 0; i < 9; ++i) gEt[i] = (R)gEc[i];
@@ -2192,7 +2213,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
     SMAC_PHASE(5, KEEP);                       // F_tmp adjoint, 18 rows stored
 }
 
-template <class R, bool ACC_VCF, bool PCON>
+template <class R, bool ACC_VCF, bool PCON, bool MAT2 = false>
 __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, int f) {
     typedef typename const_t<R>::type CT;
     __shared__ CT stash[STASH * BLOCK];
@@ -2201,7 +2222,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     gather_tile_load(D, D.ain, ch.block, gt);
     __syncthreads();
     if (!valid) return;
-    p2g_grad_particle<R, ACC_VCF, PCON, false>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr);
+    p2g_grad_particle<R, ACC_VCF, PCON, false, MAT2>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr);
 }
 
 // k_p2g_grad of substep f and k_g2p_grad of substep f - 1 in one launch.  Between two re-sorts a particle keeps its chunk, and the adjoint of

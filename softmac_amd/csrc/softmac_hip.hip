@@ -78,6 +78,7 @@ struct ISim {
     virtual int clear_grads() = 0;
     virtual int carry_grad(int src, int dst) = 0;
     virtual int set_control_idx(const int32_t* idx) = 0;
+    virtual int set_material_ids(const int32_t* ids) = 0;
     virtual int set_action_v(const double* action) = 0;
     virtual int get_action_grad(double* out) = 0;
     virtual int set_segment(int n_live, int frame_shift) = 0;
@@ -277,6 +278,7 @@ template <class R> struct Sim final : ISim {
         hipFree(D.cloth.pos); hipFree(D.cloth.vel); hipFree(D.cloth.pos_grad); hipFree(D.cloth.vel_grad); hipFree(D.cloth.ext_f);
         hipFree(D.cloth.ext_f_grad); hipFree(D.cloth.contact_id); hipFree(D.cloth.penetration); hipFree(D.cloth.contact_before);
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
+        hipFree(d_mat_id);
         hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
             if ((void*)prim_tables64[i][0] != (void*)prim_tables[i][0]) { hipFree(prim_tables64[i][0]); hipFree(prim_tables64[i][1]); }
@@ -729,6 +731,22 @@ template <class R> struct Sim final : ISim {
         for (int p = 0; p < D.N; ++p) tmp[p] = D.n_control == 0 ? 0 : idx[p];          // :599-602
         HIP_TRY(hipMemcpyAsync(d_control_idx, tmp.data(), D.Npad * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        return SMAC_OK;
+    }
+    unsigned char* d_mat_id = nullptr;
+    int set_material_ids(const int32_t* ids) override {                       // per-particle selector of the two-entry material table (nullptr: one material again)
+        if (!ids) { D.mat_id = nullptr; ++config_gen; return SMAC_OK; }
+        REQUIRE(D.collision_type != CONTACT_PARTICLE || !any_contact(), "set_material_ids: not with penalty contact (collision_type 1)");
+        std::vector<unsigned char> tmp(D.Npad, 0);
+        for (int p = 0; p < cfg.n_particles; ++p) {
+            REQUIRE(ids[p] == 0 || ids[p] == 1, "set_material_ids: entries must be 0 or 1");
+            tmp[p] = (unsigned char)ids[p];
+        }
+        if (!d_mat_id) HIP_TRY(hipMalloc((void**)&d_mat_id, D.Npad));
+        HIP_TRY(hipMemcpyAsync(d_mat_id, tmp.data(), D.Npad, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        D.mat_id = d_mat_id;
+        ++config_gen;                                    // the forward grids on file were made with the old materials
         return SMAC_OK;
     }
     int dense_grid_m(int f) {                                                 // dense row-major grid_m of frame f in dense_tmp
@@ -1233,6 +1251,9 @@ template <class R> struct Sim final : ISim {
         } else if (!strcmp(name, "yield_ratio")) {
             REQUIRE(value > 0.0, "set_param(yield_ratio): yield_stress / (2 mu) must be positive");
             D.mat.yield_c = (R)value;
+        } else if (!strcmp(name, "mu2") || !strcmp(name, "lam2") || !strcmp(name, "yield_ratio2")) {   // entry 1 of the two-entry material table (smac_set_material_ids)
+            REQUIRE(value >= 0.0, "set_param(mu2 | lam2 | yield_ratio2): negative");
+            (name[0] == 'm' ? D.mu2 : (name[0] == 'l' ? D.lam2 : D.yield_c2)) = (R)value;
         } else if (!strcmp(name, "mass_eps")) {
             REQUIRE(value >= 0.0, "set_param(mass_eps): negative");
             D.m_eps = (R)value;
@@ -1242,7 +1263,7 @@ template <class R> struct Sim final : ISim {
         } else if (!strcmp(name, "cloth_hash")) {
             cloth_hash_on = value != 0.0 ? 1 : 0;          // 0: per-chunk search over the whole mesh (round 2), 1: over the broad phase's per-block face lists
             return SMAC_OK;
-        } else REQUIRE(false, "set_param: unknown parameter (plasticity | yield_ratio | mass_eps | cloth_pairs_flat | cloth_hash)");
+        } else REQUIRE(false, "set_param: unknown parameter (plasticity | yield_ratio | mu2 | lam2 | yield_ratio2 | mass_eps | cloth_pairs_flat | cloth_hash)");
         ++config_gen;                                   // the forward grids on file were made with the old value
         return SMAC_OK;
     }
@@ -1272,7 +1293,10 @@ template <class R> struct Sim final : ISim {
     int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,
                      double force_scale, int sticky, double scale) override {
         REQUIRE(!D.cloth.present, "cloth_create: this handle already has a cloth primitive");
-        REQUIRE(D.P == 0, "cloth_create: a handle holds either SDF primitives or the cloth primitive (as the reference's two simulators do)");
+        // SDF primitives AND the sheet in one handle (round 4; BASELINE config C5): forecast contact only, on the unit domain - the SDF primitives live on
+        // [0,1)^3, the sheet on [0,scale)^3.  The reference has no simulator with both; the chain is primitives in index order, then the sheet (k_contact_hits).
+        REQUIRE(D.P == 0 || (cfg.collision_type == CONTACT_MIXED && scale == 1.0),
+                "cloth_create: a handle with SDF primitives takes the cloth primitive only with forecast contact (collision_type 2) and mpm_scale 1");
         REQUIRE(nv > 0 && nf > 0 && faces && nn >= 0 && (nn == 0 || (nbr && nbr_dir)) && scale > 0.0, "cloth_create: bad mesh arguments");
         for (int i = 0; i < 3 * nf; ++i) REQUIRE(faces[i] >= 0 && faces[i] < nv, "cloth_create: face index out of range");
         for (size_t i = 0; i < (size_t)nf * nn; ++i) REQUIRE(nbr[i] >= 0 && nbr[i] < nf, "cloth_create: neighbour face index out of range");
@@ -1539,7 +1563,11 @@ template <class R> struct Sim final : ISim {
             vin_clean = false;
             prof_begin(K_P2G);
             const bool pcon = D.collision_type == CONTACT_PARTICLE && D.any_contact;
-            if (pcon) {
+            if (D.mat_id) {                                     // two-entry material table: its own instantiation (set_material_ids refuses penalty contact)
+                REQUIRE(!pcon, "two materials: not with penalty contact (collision_type 1)");
+                if (store_F) hipLaunchKernelGGL((k_p2g<R, true, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+                else hipLaunchKernelGGL((k_p2g<R, false, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
+            } else if (pcon) {
                 if (store_F) hipLaunchKernelGGL((k_p2g<R, true, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
                 else hipLaunchKernelGGL((k_p2g<R, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
             } else {
@@ -1787,7 +1815,7 @@ template <class R> struct Sim final : ISim {
         if (!pending_adj_zero || rolling() || !fused_grid_bwd(phase) || ck_mode != 0) return false;          // frame f carried a seed / frames come and go
         if (frame_epoch[f - 1] != e || !(adj_epoch[f - 1] < 0 || adj_epoch[f - 1] == e)) return false;        // a re-sort lies between the two substeps
         if (!(ck_arena && ck_epoch[f - 1] == e && ck_gen[f - 1] == config_gen && D.n_control == 0 && D.nchunks > 0)) return false;
-        if (D.collision_type == CONTACT_PARTICLE || D.cloth.present) return false;
+        if (D.collision_type == CONTACT_PARTICLE || D.cloth.present || D.mat_id) return false;
         if (any_contact() && D.collision_type == CONTACT_MIXED && !ck_has_hits[f - 1]) return false;          // (the band test would have to run in between)
         return true;
     }
@@ -1988,7 +2016,10 @@ template <class R> struct Sim final : ISim {
                 g2p_done_paz = paz_prev;
             } else if (D.nchunks > 0) {
                 prof_begin(K_P2G_GRAD);
-                if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);   // :371-374
+                if (D.mat_id) {
+                    if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false, true, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                    else hipLaunchKernelGGL((k_p2g_grad<R, true, true, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
+                } else if (pending_adj_zero) hipLaunchKernelGGL((k_p2g_grad<R, false, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);   // :371-374
                 else hipLaunchKernelGGL((k_p2g_grad<R, true, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                 prof_end();
                 if (D.collision_type == CONTACT_PARTICLE && any_contact()) {      // adjoint of p2g's contact impulse (:203-206)
@@ -2795,6 +2826,7 @@ int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, cons
 int smac_clear_grads(smac_handle h) { return FWD(clear_grads()); }
 int smac_carry_grad(smac_handle h, int src, int dst) { return FWD(carry_grad(src, dst)); }
 int smac_set_control_idx(smac_handle h, const int32_t* idx) { return FWD(set_control_idx(idx)); }
+int smac_set_material_ids(smac_handle h, const int32_t* ids) { return FWD(set_material_ids(ids)); }
 int smac_set_action(smac_handle h, const double* action) { return FWD(set_action_v(action)); }
 int smac_set_segment(smac_handle h, int n_live, int frame_shift) { return FWD(set_segment(n_live, frame_shift)); }
 int smac_compute_grid_m(smac_handle h, int f, double* grid_m) { return FWD(compute_grid_m(f, grid_m)); }

@@ -13,8 +13,28 @@ loss_grip.py:6-170), over the HIP engine.
 """
 import contextlib
 import os
+import weakref
 
 import numpy as np
+
+LIVE_LOSSES = weakref.WeakSet()          # what a `ti.ad.Tape(loss=env.loss.loss)` of the demos can be resolved against (compat/taichi)
+
+
+class ScalarField(float):
+    """`env.loss.loss` as the demos use it (demo_pour.py:171, 200): a number that also answers `.to_numpy()` / `[None]` like the reference's 0-d
+    Taichi field, and knows the loss object it belongs to (`Tape(loss=field)` records on that object)."""
+    owner = None
+
+    def __new__(cls, value=0.0, owner=None):
+        f = super().__new__(cls, value)
+        f.owner = owner
+        return f
+
+    def to_numpy(self):
+        return np.float64(self)
+
+    def __getitem__(self, idx):
+        return float(self)
 
 
 class ChamferPoseLoss:
@@ -25,9 +45,10 @@ class ChamferPoseLoss:
         self.n_particles = mpm_sim.n_particles
         self.rigid_control = mpm_sim.primitives[0] if len(mpm_sim.primitives) else None    # loss_pour.py:13
         self.chamfer_weight = self.pose_weight = self.velocity_weight = 0.0
-        self.loss = 0.0
+        self.loss = ScalarField(0.0, self)
         self._recording = False
         self.target_x = None
+        LIVE_LOSSES.add(self)
 
     # ---- reference surface ------------------------------------------------------------------
     def load_target_position(self, path):                                                    # :29-31
@@ -46,7 +67,7 @@ class ChamferPoseLoss:
             self.load_target_position(path)
 
     def clear(self):                                                                         # :155-158
-        self.loss = 0.0
+        self.loss = ScalarField(0.0, self)
 
     reset = clear
 
@@ -90,7 +111,7 @@ class ChamferPoseLoss:
             if self._recording:
                 self.rigid_control.add_state_grad(f, g)
         total = chamfer * self.chamfer_weight + pose * self.pose_weight + vel * self.velocity_weight
-        self.loss += total                                     # the reference's loss field accumulates until clear()
+        self.loss = ScalarField(self.loss + total, self)       # the reference's loss field accumulates until clear()
         return {"loss": self.loss, "chamfer_loss": chamfer * self.chamfer_weight, "pose_loss": pose * self.pose_weight,
                 "vel_loss": vel * self.velocity_weight}
 

@@ -8,6 +8,8 @@ import contextlib
 
 import numpy as np
 
+from .loss_chamfer import LIVE_LOSSES, ScalarField
+
 
 class _ContactDistanceLoss:
     n_controllers = 1
@@ -20,15 +22,16 @@ class _ContactDistanceLoss:
         self.n_particles_per_controller = self.n_particles // self.n_controllers
         self.rigid = mpm_sim.primitives[0]
         self.pose_weight = self.velocity_weight = self.contact_weight = 0.0
-        self.loss = 0.0
+        self.loss = ScalarField(0.0, self)
         self._recording = False
+        LIVE_LOSSES.add(self)
 
     def initialize(self):
         w = self.cfg.weight
         self.pose_weight, self.velocity_weight, self.contact_weight = float(w[0]), float(w[1]), float(w[2])
 
     def clear(self):
-        self.loss = 0.0
+        self.loss = ScalarField(0.0, self)
 
     reset = clear
 
@@ -62,7 +65,7 @@ class _ContactDistanceLoss:
             g += self.pose_weight * gp
         if self._recording:
             self.rigid.add_state_grad(f, g)
-        self.loss += pose * self.pose_weight + vel * self.velocity_weight + contact * self.contact_weight
+        self.loss = ScalarField(self.loss + pose * self.pose_weight + vel * self.velocity_weight + contact * self.contact_weight, self)
         return {"loss": self.loss, "pose_loss": pose * self.pose_weight, "vel_loss": vel * self.velocity_weight,
                 "contact_loss": contact * self.contact_weight}
 

@@ -9,6 +9,7 @@ by `cfg.precision` ("float32" default / "float64") - see DESIGN.md "precision".
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -42,6 +43,9 @@ class _FrameField:
 
     def to_numpy(self, f):
         return self[f]
+
+
+LIVE_SIMULATORS = weakref.WeakSet()      # what compat/taichi's `ti.ad.clear_all_gradients()` reaches
 
 
 class MPMSimulator:
@@ -117,6 +121,7 @@ class MPMSimulator:
         c.ground_friction = float(self.ground_friction)
         c.yield_stress = float(self._yield_stress)
         self._h = _ffi.Handle(c)                            # raises without a GPU: no CPU fallback
+        LIVE_SIMULATORS.add(self)
 
         for i, p in enumerate(primitives):                  # device-side primitive slots
             p._bind(self._h, i)
@@ -282,6 +287,29 @@ class MPMSimulator:
         if self.n_control == 0:
             idx = idx * 0
         self._h.call("smac_set_control_idx", idx.ctypes.data_as(_ffi.c_int32_p))
+
+    def set_materials(self, ids, E2, nu2, yield_stress2=None):
+        """Two kinds of particles in one cloud (the reference's mu / lam / yield_stress are per-particle fields, mpm_simulator.py:47-49, filled
+        uniformly at :86-90; here: a two-entry table and one selector per particle).  ids[p] = 0: the material of the config; 1: (E2, nu2[,
+        yield_stress2]) through the same rules (:40-45).  ids=None: one material again."""
+        import ctypes as C
+        if ids is None:
+            self._h.call("smac_set_material_ids", None)
+            return
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.shape != (self.n_particles,):
+            raise ValueError(f"set_materials: expected shape ({self.n_particles},), got {ids.shape}")
+        mu2, lam2 = E2 / (2 * (1 + nu2)), E2 * nu2 / ((1 + nu2) * (1 - 2 * nu2))            # :41
+        if self.ptype == 1:
+            mu2, lam2 = 0.3 * mu2, 0.3 * lam2
+        elif self.ptype == 2:
+            mu2 = 0.0
+        scale2 = getattr(self, "scale", 1.0) ** 2                                            # (soft_cloth mirror: unit-domain moduli are E / s^2)
+        self._h.call("smac_set_param", b"mu2", C.c_double(mu2 / scale2))
+        self._h.call("smac_set_param", b"lam2", C.c_double(lam2 / scale2))
+        if yield_stress2 is not None and mu2 > 0:
+            self._h.call("smac_set_param", b"yield_ratio2", C.c_double(float(yield_stress2) / (2.0 * mu2)))
+        self._h.call("smac_set_material_ids", ids.ctypes.data_as(_ffi.c_int32_p))
 
     def compute_grid_m_kernel(self, f):
         out = np.zeros(self.res, dtype=np.float64)

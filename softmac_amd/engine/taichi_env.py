@@ -48,6 +48,12 @@ class TaichiEnv:
             raise NotImplementedError("force-controlled rigid bodies need nimblephysics (Jade), which is not available; "
                                       "use cfg.rigid_velocity_control = True")
         self.renderer = _NullRenderer()
+        # the loss named by the config (reference :49-54 evaluates cfg.ENV.loss_type: PourLoss, GripLoss, DoorLoss, TransportLoss) or one handed in
+        if loss is None and getattr(self.cfg, "loss_type", ""):
+            from . import losses
+            if not hasattr(losses, self.cfg.loss_type):
+                raise ValueError(f"cfg.ENV.loss_type = {self.cfg.loss_type!r}: not one of {losses.__all__}")
+            loss = getattr(losses, self.cfg.loss_type)(self.cfg.loss, self.simulator)
         self.use_loss = loss is not None
         self.loss = loss
         self._is_copy = False

@@ -273,3 +273,31 @@ def s_taco(n_particles=1 << 20, n_grid=128, max_steps=64, precision="float32", d
                         yield_stress=60.0)
     prim = dict(friction=1.0, softness=666.0, cloth_force_scale=1.0, mpm_force_scale=1.0, sticky=True)
     return cfg, 2e-3, scale, np.hstack([x, v, F, C]), V, Fc, prim
+
+
+def s_mixed(n_particles=1 << 20, n_grid=128, max_steps=64, precision="float32", device=0, seed=3, rings=12, palm=None):
+    """S-mixed (BASELINE config C5 "mixed soft-rigid-cloth"): `s_taco` on the unit domain (mpm_scale 1: every length / 5, E and the yield
+    stress / 25, gravity / 5 - the same dimensionless problem) with TWO material blocks (x > 0.5: half the stiffness, a lower yield stress), the sticky
+    sheet under the cylinder and ONE rigid SDF primitive - a box (`palm`: an SDF table spec, e.g. the reference's cached gripper palm) pressed into the
+    cylinder's top at 0.2 m/s.  Returns (cfg, env_dt, state (N, 24), vertices, faces, sheet cfg, rigid spec, rigid state13, mat_id, material-2 dict)."""
+    rng = np.random.default_rng(seed)
+    dx = 1.0 / n_grid
+    r = 40.0 * n_grid / 128 * dx
+    h = n_particles / 8.0 * dx ** 3 / (np.pi * r * r)
+    rr = r * np.sqrt(rng.random(n_particles))
+    th = 2 * np.pi * rng.random(n_particles)
+    x = np.stack([0.5 + rr * np.cos(th), 0.4 + 0.1 * dx + h * rng.random(n_particles), 0.5 + rr * np.sin(th)], 1)
+    v = np.tile([0.0, -0.06, 0.0], (n_particles, 1)) + 0.004 * rng.standard_normal((n_particles, 3))
+    F = np.eye(3).reshape(1, 9) + 5e-3 * rng.standard_normal((n_particles, 9))
+    C = 0.3 * rng.standard_normal((n_particles, 9))
+    V, Fc = tortilla_disc(rings, 0.3)
+    V = V + np.array([0.5, 0.4, 0.5])
+    cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=2e-4, E=200.0, nu=0.2, ptype=0, material_model=0, gravity=(0.0, -1.0, 0.0),
+                        ground_friction=0.0, collision_type=2, n_controllers=0, max_steps=max_steps, precision=precision, device=device,
+                        yield_stress=2.4)
+    sheet = dict(friction=1.0, softness=666.0, cloth_force_scale=1.0, mpm_force_scale=1.0, sticky=True)
+    rigid = None if palm is None else dict(table_spec(palm), friction=0.6, softness=666.0, contact=True)
+    top = 0.4 + 0.1 * dx + h
+    s13 = np.concatenate([[0.5, top + 0.15 - 0.002, 0.5], [1.0, 0.0, 0.0, 0.0], [0.0, -0.2, 0.0], [0.0, 0.0, 0.0]])   # (the palm's half height is 0.15)
+    mat_id = (x[:, 0] > 0.5).astype(np.int32)
+    return cfg, 2e-3, np.hstack([x, v, F, C]), V, Fc, sheet, rigid, s13, mat_id, dict(E=100.0, nu=0.3, yield_stress=1.0)

@@ -21,8 +21,12 @@ from ...engine.mpm_simulator import CONTACT_MIXED, CONTACT_PARTICLE, MAT_PLASTIC
 
 
 class MPMSimulator(_Base):
-    def __init__(self, cfg, primitive, env_dt=2e-3, scale=1.):
+    def __init__(self, cfg, primitive, env_dt=2e-3, scale=1., rigid_primitives=()):
+        """rigid_primitives (this build's extension, BASELINE config C5 "mixed soft-rigid-cloth"): softmac Mesh primitives alongside the sheet - forecast
+        contact only, scale 1 (their SDF tables are unit-domain objects); the contact chain takes them in index order, then the sheet."""
         s = self.scale = float(scale)
+        if len(rigid_primitives) and (s != 1.0 or int(cfg.collision_type) != CONTACT_MIXED):
+            raise ValueError("rigid primitives alongside the sheet need mpm_scale 1 and collision_type 2 (forecast contact)")
         unit = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("dim", "dtype", "quality", "yield_stress", "n_particles", "dt", "ptype",
                                                                      "material_model", "nu", "max_steps", "n_controllers", "collision_type")})
         for k in ("n_grid", "precision", "device", "grad_enabled", "sort_interval", "recompute_backward", "adjoint_frames", "slab_flags"):
@@ -31,7 +35,7 @@ class MPMSimulator(_Base):
         unit.E = cfg.E / (s * s)
         unit.gravity = tuple(float(g) / s for g in cfg.gravity)
         unit.ground_friction = 0.0                         # no floor rule in this variant (:275-286)
-        super().__init__(unit, (), env_dt)
+        super().__init__(unit, rigid_primitives, env_dt)
         self.ground_friction = getattr(cfg, "ground_friction", 0.0)
         self.default_gravity = cfg.gravity
         self._yield_stress = cfg.yield_stress
@@ -59,11 +63,12 @@ class MPMSimulator(_Base):
         a = None if action is None else np.asarray(action, dtype=np.float64) / self.scale ** 3
         super().substep(s, a)
 
-    def substep_grad(self, s, action=None, ext_f_grad=None):
+    def substep_grad(self, s, action=None, ext_f_grad=None, rigid_ext_f_grad=None):
+        """ext_f_grad: the sheet's (V, 3) seed (:343-346); rigid_ext_f_grad: one 6-vector per rigid primitive of a mixed scene (softmac :342-344)"""
         if ext_f_grad is not None:                         # :343-346
             self.primitive.set_ext_f_grad(np.asarray(ext_f_grad, dtype=np.float64).reshape(-1, 3))
         a = None if action is None else np.asarray(action, dtype=np.float64) / self.scale ** 3
-        g = super().substep_grad(s, a, None)
+        g = super().substep_grad(s, a, rigid_ext_f_grad)
         return None if g is None else g / self.scale ** 3
 
     def set_action(self, action):

@@ -29,26 +29,25 @@ def _sample_points(d):
     return np.stack(np.meshgrid(*ax, indexing="ij"), -1)
 
 
-def _compare_with_cache(name, sdf, normal, gap):
-    """The reference's cached table vs ours.  Distances: palm to rounding; the door cache carries ~1e-6 noise on a few
-    samples.  Signs: trimesh's ray containment calls the 206 door samples under / inside the handle legs, which are
-    inside the union of the boxes, 'outside' (coincident faces); everything else must agree.  Normals are compared
-    where the closest triangle is unique (on edges, corners and diagonal planes of a box two faces are equally close
-    and which one trimesh reports is arbitrary)."""
+def _compare_with_cache(name, sdf, normal, ties):
+    """The reference's cached table vs ours.  Distances: palm to rounding; the door cache carries ~1e-6 noise on a few samples.  Signs: EVERY sample,
+    since round 4 (trimesh's closest-triangle choice + plane-side sign: oracle/voxel_oracle.py) - including the 206 door samples inside the handle legs
+    next to the panel, which are inside the union of the boxes and carry a POSITIVE distance in the reference's table (checked below, so that the
+    fixture keeps exercising the rule).  Normals are compared where the closest triangle is unique (on edges, corners and diagonal planes of a box
+    several faces are equally close; with two tied the rule picks by angle, and where the angles tie too the pick is trimesh's r-tree order)."""
     d = _fixture(name)
     ref = d["sdf"]
     tol = 1e-12 if name == "palm" else 5e-6
     assert np.abs(np.abs(sdf) - np.abs(ref)).max() < tol
     flipped = (np.sign(sdf) != np.sign(ref)) & (np.abs(ref) > tol)
-    if name == "palm":
-        assert flipped.sum() == 0
-    else:
-        P = _sample_points(d)[flipped]
-        inside = np.zeros(len(P), dtype=bool)
+    assert flipped.sum() == 0
+    if name == "door":
+        P = _sample_points(d)
+        inside = np.zeros(P.shape[:3], dtype=bool)
         for lo, hi in DOOR_BOXES:
-            inside |= np.all((P >= np.array(lo)) & (P <= np.array(hi)), axis=1)
-        assert flipped.sum() == 206 and inside.all() and (sdf[flipped] < 0).all()
-    unique = gap > 1e-9
+            inside |= np.all((P >= np.array(lo)) & (P <= np.array(hi)), axis=-1)
+        assert (inside & (ref > tol)).sum() == 206 and (sdf[inside & (ref > tol)] > 0).all()
+    unique = ties == 1
     assert unique.mean() > 0.75
     assert np.abs(normal - d["normal"])[unique].max() < 1e-6
 
@@ -74,8 +73,8 @@ def test_merge_vertices_like_trimesh_load():
 @pytest.mark.parametrize("name", ["palm", "door"])
 def test_oracle_reproduces_the_reference_caches(name):
     d = _fixture(name)
-    sdf, normal, gap = V.mesh_to_sdf(d["vertices"], d["faces"], d["lower"], d["res"], float(d["dx"]))
-    _compare_with_cache(name, sdf, normal, gap)
+    sdf, normal, ties = V.mesh_to_sdf(d["vertices"], d["faces"], d["lower"], d["res"], float(d["dx"]))
+    _compare_with_cache(name, sdf, normal, ties)
 
 
 def test_obj_parser_roundtrip(tmp_path):
@@ -109,18 +108,18 @@ def test_kernel_reproduces_the_reference_caches(name):
     d = _fixture(name)
     out = voxelize.mesh_to_sdf(d["vertices"], d["faces"])
     assert (out["res"] == d["res"]).all() and np.abs(out["position"][0] - d["lower"]).max() < 1e-14
-    _, _, gap = V.mesh_to_sdf(d["vertices"], d["faces"], d["lower"], d["res"], float(d["dx"]))
-    _compare_with_cache(name, out["sdf"], out["normal"], gap)
+    _, _, ties = V.mesh_to_sdf(d["vertices"], d["faces"], d["lower"], d["res"], float(d["dx"]))
+    _compare_with_cache(name, out["sdf"], out["normal"], ties)
 
 
 @pytest.mark.gpu
 def test_kernel_vs_oracle_on_a_skew_mesh():
     v, f = _skew_convex_mesh()
     out = voxelize.mesh_to_sdf(v, f)
-    sdf, normal, gap = V.mesh_to_sdf(v, f, out["position"][0], out["res"], float(out["dx"][0]))
+    sdf, normal, ties = V.mesh_to_sdf(v, f, out["position"][0], out["res"], float(out["dx"][0]))
     assert np.abs(out["sdf"] - sdf).max() < 1e-12
     assert (out["sdf"] < 0).sum() > 1000 and (out["sdf"] > 0).sum() > 1000
-    assert np.abs(out["normal"] - normal)[gap > 1e-9].max() < 1e-12
+    assert np.abs(out["normal"] - normal)[ties == 1].max() < 1e-12
 
 
 @pytest.mark.gpu

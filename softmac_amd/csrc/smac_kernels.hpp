@@ -46,21 +46,8 @@ namespace smac {
 #ifndef SMAC_OCC_P2G
 #define SMAC_OCC_P2G 6
 #endif
-#ifndef SMAC_OCC_G2P_PIPE
-#define SMAC_OCC_G2P_PIPE 3
-#endif
-// register-pressure knobs of the two gradient kernels (A/B on MI355X: profiles/scripts/r02_h.sh)
-#ifndef SMAC_DW_RECOMPUTE
-#define SMAC_DW_RECOMPUTE 1      // WGrad::to_fx recomputes dw from fx instead of keeping Stencil::dw live across the gather
-#endif
-#ifndef SMAC_GFN_STASH
-#define SMAC_GFN_STASH 0         // 1: k_p2g_grad parks F.grad[f+1] in the LDS stash (48 KB per workgroup) instead of 9 registers: 100 vs 92 us
-#endif
 #ifndef SMAC_PHASE_CLOCK
 #define SMAC_PHASE_CLOCK 0       // 1 (tools/phase_clock.sh only): 1 workgroup in 16 of the particle kernels files s_memtime at its phase boundaries
-#endif
-#ifndef SMAC_GFX_FROM_A
-#define SMAC_GFX_FROM_A 1        // k_p2g_grad: dpos adjoint from a0,a1,a2 (live anyway) instead of the 9 affine entries
 #endif
 // arithmetic type of the constitutive model (SVD, stress, their adjoint) inside the particle kernels: the storage type R,
 // or double whatever R is (SMAC_CONST_F64=1; measured for the f32 accuracy study, tools/prec_probe.py)
@@ -132,16 +119,9 @@ template <class R> struct DevSim {
     int slab_base_lo, slab_base_hi;   // slab decomposition: stencil bases (x) this rank's grid planes can take deposits for, drift tolerance included
                                       // (a particle beyond them would scatter onto planes nobody exchanges: flagged by k_g2p, drift_flag[2]); lo > hi: no check
     const int* block_active;     // dense per-block flag of the current epoch (halo packing)
-    // Grid checkpoint of the frame being processed, [active slot][vin | vmix | vout][64 cells], or nullptr.
-    // Forward: k_grid_op / k_contact_hits write it directly (no copy kernel).  Backward: the kernels READ the forward grid
-    // from it (no restore kernel); the dense vin / vmix / vout arrays are then not valid for that frame.
-    Vec4<R>* ck;
     const int* block_slot;       // dense per block: its slot in the active list of the current epoch (valid where block_active)
-    struct Hit* hit_ck;          // forward: where k_grid_op files the frame's contact hit list (with its length), or nullptr
-    int* nhit_ck;
-    int hit_cap;
-    // k_g2p<R, true>: the frame's checkpoint save rides in the same launch (its first `save_blocks` workgroups, a multiple of 8) - own names, so that
-    // nothing takes them for the direct-checkpoint modes of `ck` above
+    // k_g2p<R, true>: the frame's checkpoint save ([active slot][vin | vmix | vout][64 cells]) rides in the same launch (its first
+    // `save_blocks` workgroups, a multiple of 8)
     Vec4<R>* save_ck;
     struct Hit* save_hits;
     int* save_nhits;
@@ -234,10 +214,6 @@ template <class R> __device__ __forceinline__ void atomic_add(R* p, R v) { unsaf
 template <class R> __device__ __forceinline__ Vec4<R> gld(const Vec4<R>* base, unsigned cell) {
     return *(const Vec4<R>*)((const char*)base + cell * (unsigned)sizeof(Vec4<R>));
 }
-template <class R> struct DevSim;
-// forward-grid record (field 0: {m,p}, 1: v_mixed, 2: v_out) of a dense block-major cell index: from the frame's checkpoint when
-// the backward pass runs on one, else from the dense array
-template <class R> __device__ __forceinline__ Vec4<R> gval(const DevSim<R>& D, int field, unsigned cell);
 template <class R> __device__ __forceinline__ void gatomic(Vec4<R>* base, unsigned cell, int comp, R v) {
     unsafeAtomicAdd((R*)((char*)base + cell * (unsigned)sizeof(Vec4<R>)) + comp, v);
 }
@@ -445,14 +421,6 @@ __device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, Ve
     }
 }
 
-template <class R> __device__ __forceinline__ Vec4<R> gval(const DevSim<R>& D, int field, unsigned cell) {
-    if (D.ck) {
-        const int slot = D.block_slot[cell >> 6];
-        return D.ck[(size_t)slot * 192 + field * 64 + (cell & 63)];
-    }
-    const Vec4<R>* base = field == 0 ? D.vin : (field == 1 ? D.vmix : D.vout);
-    return gld(base, cell);
-}
 // Stage the 6x6x6 node records of `field` around this chunk's block into LDS (gather tile).
 // Nodes outside the grid read as zero (they are never addressed: bases are clamped).
 template <class R>
@@ -466,20 +434,6 @@ __device__ __forceinline__ void gather_tile_load(const DevSim<R>& D, const Vec4<
         const Vec4<R>* src = (i < D.n && j < D.n && k < D.n) ? field + cell_of(nb, i, j, k) : nullptr;
         if (src) gt[idx] = *src;
         else { gt[idx].x = R(0); gt[idx].y = R(0); gt[idx].z = R(0); gt[idx].w = R(0); }
-    }
-}
-
-// the same for a FORWARD-grid field (0: {m,p}, 1: v_mixed, 2: v_out) in the backward pass: from the checkpoint when there is one
-template <class R>
-__device__ __forceinline__ void gather_tile_load_fwd(const DevSim<R>& D, int field_id, int block, Vec4<R>* gt) {
-    const int nb = D.nb;
-    const int bz = block % nb, by = (block / nb) % nb, bx = block / (nb * nb);
-    for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
-        const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
-        const int i = 4 * bx + li, j = 4 * by + lj, k = 4 * bz + lk;
-        Vec4<R> v = {R(0), R(0), R(0), R(0)};
-        if (i < D.n && j < D.n && k < D.n) v = gval(D, field_id, (unsigned)cell_of(nb, i, j, k));
-        gt[idx] = v;
     }
 }
 
@@ -623,11 +577,6 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     __shared__ double tile_raw[4 * TILE_WORDS];
     __shared__ R smax[4];
     __shared__ R ps_wg[MAX_PRIMS * 13];
-#ifdef SMAC_P2G_LDS_PAD          // experiment: fewer workgroups per CU at unchanged registers (profiles/r02_ao_p2g_occupancy.txt)
-    __shared__ int lds_pad[SMAC_P2G_LDS_PAD / 4];
-    if (D.n < 0) lds_pad[threadIdx.x] = 1;
-    if (D.n < -1) D.pmask[0] = lds_pad[(threadIdx.x * 7) % (SMAC_P2G_LDS_PAD / 4)];
-#endif
     SMAC_PHASE(22, true);                // (entry, every wave)
     if (D.any_contact) {                 // (uniform) primitive states of this frame, converted once per workgroup for the band test
         if (threadIdx.x < D.P * 13)
@@ -895,33 +844,17 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    if (D.hit_ck && phase != 1) {            // the frame's contact hit list (complete since k_p2g) goes on file with the checkpoint
-        int nh = *D.nhits;
-        if (nh > D.hit_cap) {                // more particles in contact bands than a slot holds: never truncated silently (see k_grid_save)
-            if (blockIdx.x == 0 && threadIdx.x == 0) D.drift_flag[1] = 1;
-            nh = 0;
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) *D.nhit_ck = nh;
-        for (int q = blockIdx.x * BLOCK + threadIdx.x; q < nh; q += gridDim.x * BLOCK) D.hit_ck[q] = D.hits[q];
-    }
     Vec4<R> acc = D.vin[cell];                                                          // drift fallback part
     if (phase != 2) {
         slab_reduce(D, b, l, acc);
-        if (phase == 1 || !D.ck) D.vin[cell] = acc;
+        D.vin[cell] = acc;
     }
     if (phase == 1) return;
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-    Vec4<R>* ckp = nullptr;
-    if (D.ck) {                              // {m,p} lives in the checkpoint from here on; the dense array is left ZEROED for the next
-        ckp = D.ck + (size_t)active_slot(D) * 192 + l;           // P2G's drifted atomics (no clear pass)
-        ckp[0] = acc;
-        D.vin[cell] = z;
-    }
     const R m = acc.x;
     if (!(m > D.m_eps)) {                                                             // :286 / :399: no velocity on this node
         if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = z;                       // (written, so the fields need no clear)
         D.vout[cell] = z;
-        if (ckp) { ckp[64] = z; ckp[128] = z; }
         return;
     }
     const R inv = R(1) / m;
@@ -941,7 +874,6 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     const Vec4<R> o = {v[0], v[1], v[2], R(0)};
     if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = o;                            // :403
     D.vout[cell] = o;                                                                   // :404 / :297
-    if (ckp) { ckp[64] = o; ckp[128] = o; }
 }
 
 template <class R> __device__ __forceinline__ void gather_vec(const DevSim<R>& D, const Vec4<R>* field, const Stencil<R>& st,
@@ -999,7 +931,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         bool has = false;
         if (mask && d < 27) {
             vm = gld(D.vmix, cell);
-            has = gval(D, 0, cell).x > D.m_eps;            // ({m,p} is in the checkpoint when there is one: k_grid_op zeroed the array)
+            has = gld(D.vin, cell).x > D.m_eps;
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2
 #pragma unroll
@@ -1054,10 +986,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
             for (int c = 0; c < 3; ++c) {
                 const R val = -R(2) * wn * (R)((double)v_tmp[c] - v_tgt[c]);
                 if (in_tile) lds_add(ctile + tw + c * TILE_WORDS, val);
-                else {
-                    gatomic(D.vout, cell, c, val);
-                    if (D.ck) gatomic(D.ck + (size_t)D.block_slot[cell >> 6] * 192 + 128, cell & 63u, c, val);
-                }
+                else gatomic(D.vout, cell, c, val);
             }
         }
         __syncthreads();
@@ -1070,10 +999,6 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
                     const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
                     const unsigned c2 = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
                     gatomic(D.vout, c2, 0, a0); gatomic(D.vout, c2, 1, a1); gatomic(D.vout, c2, 2, a2);
-                    if (D.ck) {                                 // the checkpoint's copy of v_out gets the same correction
-                        Vec4<R>* co = D.ck + (size_t)D.block_slot[c2 >> 6] * 192 + 128;
-                        gatomic(co, c2 & 63u, 0, a0); gatomic(co, c2 & 63u, 1, a1); gatomic(co, c2 & 63u, 2, a2);
-                    }
                 }
             }
         }
@@ -1221,63 +1146,6 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
     SMAC_PHASE(26, true);
 }
 
-// Persistent, software-pipelined form: a workgroup walks several chunks of its XCD's range; while it computes chunk k from LDS
-// buffer k & 1, the positions and the 216 tile records of chunk k+1 and the descriptor of chunk k+2 are already in flight.  The
-// per-chunk form above spends most of a wave's life in three dependent round trips (descriptor -> x / tile -> compute -> stores).
-template <class R>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P_PIPE : 2)) void k_g2p_pipe(DevSim<R> D, int f) {
-    typedef typename pos_of<R>::type PX;
-    __shared__ Vec4<R> gt[2][TILE_WORDS];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
-        *D.nhits = 0; *D.nhits_next = 0; *D.ncand = 0;
-    }
-    const int t = threadIdx.x;
-    const int per = (D.nchunks + 7) >> 3;                              // the XCD-aware split of xcd_chunk()
-    const int J = (int)(gridDim.x >> 3);
-    const int lo = (int)(blockIdx.x & 7) * per;
-    const int hi = lo + per < D.nchunks ? lo + per : D.nchunks;
-    int c = lo + (int)(blockIdx.x >> 3);
-    if (c >= hi) return;
-    const R* Sf = frame(D.S, f, D.Npad);
-    R* Sn = frame(D.S, f + 1, D.Npad);
-    const int nb = D.nb;
-    auto issue = [&](const Chunk& k, PX* xo, Vec4<R>& tvo) {
-        load_pos(Sf, D.Npad, k.start + (t < k.count ? t : 0), xo);
-        if (t < TILE_WORDS) {
-            const int bz = k.block % nb, by = (k.block / nb) % nb, bx = k.block / (nb * nb);
-            const int i = 4 * bx + t / TSX, j = 4 * by + (t / TSY) % TW, kk = 4 * bz + t % TW;
-            const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-            tvo = (i < D.n && j < D.n && kk < D.n) ? D.vout[cell_of(nb, i, j, kk)] : z;
-        }
-    };
-    Chunk ch = D.chunks[c];
-    int cn = c + J;
-    Chunk chn = cn < hi ? D.chunks[cn] : ch;
-    PX x[3];
-    Vec4<R> tv = {R(0), R(0), R(0), R(0)};
-    issue(ch, x, tv);
-    int buf = 0;
-    for (;;) {
-        if (t < TILE_WORDS) gt[buf][t] = tv;
-        __syncthreads();
-        const bool more = cn < hi;
-        PX xn[3] = {x[0], x[1], x[2]};
-        Vec4<R> tvn = tv;
-        Chunk chnn = chn;
-        if (more) {
-            issue(chn, xn, tvn);
-            if (cn + J < hi) chnn = D.chunks[cn + J];
-        }
-        if (t < ch.count) g2p_particle(D, ch, ch.start + t, x, gt[buf], Sn);
-        if (!more) break;
-        ch = chn; chn = chnn; cn += J;
-        x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
-        tv = tvn;
-        buf ^= 1;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
@@ -1296,17 +1164,12 @@ template <class R> struct WGrad {
         g[k][2] += gw * st.w[i][0] * st.w[j][1];
     }
     __device__ __forceinline__ void to_fx(const Stencil<R>& st, R* gfx) const {
-#if SMAC_DW_RECOMPUTE
         // the weight derivatives are recomputed from fx here (mpm_simulator.py:217) instead of being kept live across the gather
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const R fx = st.fx[d];
             gfx[d] += g[0][d] * (fx - R(1.5)) + g[1][d] * (R(-2) * (fx - R(1))) + g[2][d] * (fx - R(0.5));
         }
-#else
-#pragma unroll
-        for (int d = 0; d < 3; ++d) gfx[d] += g[0][d] * st.dw[0][d] + g[1][d] * st.dw[1][d] + g[2][d] * st.dw[2][d];
-#endif
     }
 };
 
@@ -1377,7 +1240,7 @@ __device__ __forceinline__ void g2p_grad_chunk(const DevSim<R>& D, const Chunk& 
                             const bool in = !MIXED || (okxi & (nd.oky >> j) & (nd.okz >> k) & 1) != 0;
                             const unsigned cell = (unsigned)(cxi + nd.cy[j] + nd.cz[k]);
                             Vec4<R> g = gt[in ? tw : 0];                 // unconditional LDS read (see k_g2p)
-                            if (MIXED && !in) g = gval(D, 2, cell);
+                            if (MIXED && !in) g = gld(D.vout, cell);
                             const R tk[3] = {tj[0] + R(k) * gC1[2], tj[1] + R(k) * gC1[5], tj[2] + R(k) * gC1[8]};
                             const R w = wij * st.w[k][2];
                             if (in) {
@@ -1439,7 +1302,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;
     if (sparse) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
     else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
-    gather_tile_load_fwd(D, 2, ch.block, gt);       // (its barrier is the one inside tile_scale: the particle loads
+    gather_tile_load(D, D.vout, ch.block, gt);        // (its barrier is the one inside tile_scale: the particle loads
                                                     //  that follow are then in flight together with the tile's)
     typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
     R gx1[3] = {R(0), R(0), R(0)}, gnv[3] = {R(0), R(0), R(0)}, gC1[9];
@@ -1581,9 +1444,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         Vec4<R> vm = {R(0), R(0), R(0), R(0)}, G = {R(0), R(0), R(0), R(0)}, vin_n = {R(0), R(0), R(0), R(0)};
         R has = R(0);
         if (mask && d < 27) {
-            vm = gval(D, 1, cell);
+            vm = gld(D.vmix, cell);
             G = gld(D.aout, cell);
-            vin_n = gval(D, 0, cell);
+            vin_n = gld(D.vin, cell);
             has = vin_n.x > D.m_eps ? R(1) : R(0);
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2 forward
@@ -1751,7 +1614,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                     const unsigned cell = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
                     if (DIRECT) {
                         R gn[3] = {a0, a1, a2};
-                        const Vec4<R> o = grid_op_node_adjoint(D, gval(D, 0, cell), 4 * bx + li, 4 * by + lj, 4 * bz + lk, gn);
+                        const Vec4<R> o = grid_op_node_adjoint(D, gld(D.vin, cell), 4 * bx + li, 4 * by + lj, 4 * bz + lk, gn);
                         if (o.x != R(0) || o.y != R(0) || o.z != R(0) || o.w != R(0)) {
                             gatomic(D.ain, cell, 0, o.x); gatomic(D.ain, cell, 1, o.y); gatomic(D.ain, cell, 2, o.z); gatomic(D.ain, cell, 3, o.w);
                         }
@@ -1881,20 +1744,13 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    const Vec4<R> in = D.ck ? D.ck[(size_t)active_slot(D) * 192 + l] : D.vin[cell];
+    const Vec4<R> in = D.vin[cell];
     const Vec4<R> go = D.aout[cell];
     const Vec4<R> zero4 = {R(0), R(0), R(0), R(0)};
     Vec4<R> gm_ = zero4;
     if (D.collision_type == CONTACT_MIXED) gm_ = D.amix[cell];
-    if (D.ck) {          // last readers of grid_v_out.grad / grid_v_mixed.grad in this substep: hand them back zeroed to the next one
-        D.aout[cell] = zero4;                                                          // (there is no restore kernel to do it)
-        if (D.collision_type == CONTACT_MIXED) D.amix[cell] = zero4;
-    }
     const R m = in.x;
-    if (!(m > D.m_eps)) {
-        if (D.ck) D.ain[cell] = zero4;                                                 // k_p2g_grad gathers every node of its tile
-        return;
-    }
+    if (!(m > D.m_eps)) return;
     const R inv = R(1) / m;
     const R vin[3] = {in.y, in.z, in.w};
     R g[3] = {go.x + gm_.x, go.y + gm_.y, go.z + gm_.z};                               // grid_v_out += grid_v_mixed
@@ -1960,7 +1816,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
 // 128 VGPRs together, and at 1 wave/SIMD the kernel is latency-bound.  The SVD factors (kept for the
 // constitutive adjoint) are parked in LDS across the gather loop, and the loop is fenced per x-plane so
 // that at most 9 nodes of loads are in flight: 4 waves/SIMD instead of 1.
-constexpr int STASH = SMAC_GFN_STASH ? 43 : 34;   // U9 V9 e3 ep3 Et9 Jm1 (gFn9): parked in LDS across the gather loop
+constexpr int STASH = 34;   // U9 V9 e3 ep3 Et9 Jm1: parked in LDS across the gather loop
 template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SMAC_OCC_P2GG : 2; };   // waves/SIMD asked of the register allocator
 // p2g.grad + svd_grad + compute_F_tmp.grad of one particle (mpm_simulator.py:371-374): `gt` is the staged grid_v_in.grad / grid_m.grad tile, `stash` the
 // workgroup's LDS parking space.  Writes the adjoint of frame f to D.Af; KEEP: also hands x.grad, v.grad, C.grad of frame f back in registers
@@ -1968,7 +1824,6 @@ template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SM
 template <class R, bool ACC_VCF, bool PCON, bool KEEP, bool MAT2 = false>
 __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, const Chunk& ch, int p, int t, typename const_t<R>::type* stash, const Vec4<R>* gt,
                                                   R* gx_o, R* gv_o, R* gC_o) {
-    constexpr bool STASH_CE = false;      // A/B: reloading C,E (L2 hits) and 3 workgroups/CU beats keeping them in LDS
     typedef typename const_t<R>::type CT;
     const R* Sf = frame(D.S, f, D.Npad);
     const R* An = D.An;
@@ -1977,9 +1832,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
     // C, E and the SVD factors wait in LDS until the constitutive adjoint needs them
     typename pos_of<R>::type x[3];
     R v[3], aff[9];
-#if !SMAC_GFN_STASH
     R gFn[9];
-#endif
     {
         R C[9], E[9];
         CT Et[9], En[9], stress[9];
@@ -1987,10 +1840,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         load_vec(Sf, CF, 9, D.Npad, p, E);
         load_pos(Sf, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
-#if SMAC_GFN_STASH
-        R gFn[9];
-#endif
-        load_vec(An, CF, 9, D.Npad, p, gFn);       // F.grad[f+1]: fetched with the rest (parked in LDS until the constitutive adjoint)
+        load_vec(An, CF, 9, D.Npad, p, gFn);       // F.grad[f+1]: fetched with the rest
         ConstState<CT> cs;
         {
             CT Cc[9], Ec[9];
@@ -2007,15 +1857,10 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
             stash[i * BLOCK + t] = cs.U[i];
             stash[(9 + i) * BLOCK + t] = cs.V[i];
             stash[(24 + i) * BLOCK + t] = Et[i];
-            if (STASH_CE) { stash[(34 + i) * BLOCK + t] = C[i]; stash[(43 + i) * BLOCK + t] = E[i]; }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) { stash[(18 + i) * BLOCK + t] = cs.e[i]; stash[(21 + i) * BLOCK + t] = cs.ep[i]; }
         stash[33 * BLOCK + t] = cs.Jm1;
-#if SMAC_GFN_STASH
-#pragma unroll
-        for (int i = 0; i < 9; ++i) stash[(34 + i) * BLOCK + t] = (CT)gFn[i];
-#endif
     }
     SMAC_PHASE(2, KEEP);                       // rows loaded, forward constitutive model recomputed and parked
     R imp[3] = {R(0), R(0), R(0)};
@@ -2135,14 +1980,9 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         gaff[3 * c + 1] = D.dx * (My[c] - st.fx[1] * M0[c]);
         gaff[3 * c + 2] = D.dx * (Mz[c] - st.fx[2] * M0[c]);
     }
-#if SMAC_GFX_FROM_A
     gfx[0] -= a0[0] * M0[0] + a0[1] * M0[1] + a0[2] * M0[2];                             // dpos = (offset - fx) dx ; a_d = dx affine[:, d]
     gfx[1] -= a1[0] * M0[0] + a1[1] * M0[1] + a1[2] * M0[2];
     gfx[2] -= a2[0] * M0[0] + a2[1] * M0[1] + a2[2] * M0[2];
-#else
-#pragma unroll
-    for (int d = 0; d < 3; ++d) gfx[d] -= D.dx * (aff[d] * M0[0] + aff[3 + d] * M0[1] + aff[6 + d] * M0[2]);   // dpos = (offset - fx) dx
-#endif
     wg.to_fx(st, gfx);
     // impulse adjoint = sum_nodes w gv = gvp  -> action.grad
     if (ci >= 0)
@@ -2172,11 +2012,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         cs.Jm1 = stash[33 * BLOCK + t];
         cs.has_svd = true;
 #pragma unroll
-#if SMAC_GFN_STASH
-        for (int i = 0; i < 9; ++i) { G[i] = (CT)(D.stress_scale * gaff[i]); gFc[i] = stash[(34 + i) * BLOCK + t]; }
-#else
         for (int i = 0; i < 9; ++i) { G[i] = (CT)(D.stress_scale * gaff[i]); gFc[i] = (CT)gFn[i]; }
-#endif
         const Material<CT> mat = particle_material<CT, MAT2>(D, p);
         constitutive_bwd(mat, Et, cs, G, gFc, gEc);
 #pragma unroll
@@ -2185,15 +2021,10 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
     SMAC_PHASE(4, KEEP);                       // constitutive adjoint
     // compute_F_tmp.grad: F_tmp = (I + dt C)(I + E)
     R gC[9], gE[9], Ft[9], A1[9];
-    if (STASH_CE) {
+    load_vec(Sf, CF, 9, D.Npad, p, Ft);          // (C, E come back from L2: cheaper than 18 more stash slots)
+    load_vec(Sf, CC, 9, D.Npad, p, A1);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { Ft[i] = stash[(43 + i) * BLOCK + t]; A1[i] = D.dt * stash[(34 + i) * BLOCK + t]; }
-    } else {
-        load_vec(Sf, CF, 9, D.Npad, p, Ft);
-        load_vec(Sf, CC, 9, D.Npad, p, A1);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) A1[i] *= D.dt;
-    }
+    for (int i = 0; i < 9; ++i) A1[i] *= D.dt;
     Ft[0] += R(1); Ft[4] += R(1); Ft[8] += R(1);
     A1[0] += R(1); A1[4] += R(1); A1[8] += R(1);
     mmt(gEt, Ft, gC);          // gEt (I+E)^T
@@ -2248,7 +2079,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? occ<R>::heavy : 1)) void k
     if (sizeof(R) == 4 && ch.count <= SPARSE_MAX) { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile64[i] = 0.0; }
     else { for (int i = t; i < 3 * TILE_WORDS; i += BLOCK) tile[i] = W(0); }
     gather_tile_load(D, D.ain, ch.block, gt);
-    gather_tile_load_fwd(D, 2, ch.block, gtv);
+    gather_tile_load(D, D.vout, ch.block, gtv);
     typename pos_of<R>::type xp[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
     if (valid) load_pos(frame(D.S, f - 1, D.Npad), D.Npad, p, xp);
     __syncthreads();

@@ -44,9 +44,6 @@ enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_G
 static const char* kDriftMessage =
     "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort "
     "interval): the frames after that substep are invalid - lower sort_interval or dt";
-static const char* kHitOverflowMessage =
-    "more than 1/8 of the particles were inside a contact band in one substep: its hit list does not fit the grid "
-    "checkpoint, which the direct-checkpoint modes (SMAC_CK_MODE=1/2) walk in place (use the default mode, or flags bit 0 - recompute_backward)";
 static const char* kSlabLeftMessage =
     "slab decomposition: a particle's stencil left the x-planes this rank shares with its neighbours (its deposits there would be lost): "
     "migrate more often (SlabRunner.migrate at every re-sort) or widen the shared band (nplanes = 2 + 2 * drift tolerance)";
@@ -223,18 +220,12 @@ template <class R> struct Sim final : ISim {
     int ck_skip_empty = getenv("SMAC_CK_SKIP_EMPTY") ? atoi(getenv("SMAC_CK_SKIP_EMPTY")) : 1;
     // the flags of frame f for the backward grid pass: only while the frame's checkpoint (and with it the flags) is the one this epoch filed
     unsigned char* reduce_flags(int f, int e) { return (ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen) ? ck_flags_of(f) : (unsigned char*)nullptr; }
-    unsigned char* ck_flags_of(int f) { return (ck_empty && ck_skip_empty && ck_mode == 0) ? ck_empty + (size_t)f * ck_slot_blocks : (unsigned char*)nullptr; }
+    unsigned char* ck_flags_of(int f) { return (ck_empty && ck_skip_empty) ? ck_empty + (size_t)f * ck_slot_blocks : (unsigned char*)nullptr; }
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
     bool vin_clean = false;          // {m,p} of every active block is zero (saves the clear pass before P2G)
-    bool adj_grid_clean = true;      // grid_v_out.grad / grid_v_mixed.grad of every active block are zero (direct-checkpoint backward)
-    // grid checkpoint traffic.  0 (default): copy kernels both ways (k_grid_save / k_grid_restore, 10 us each at 1M particles).
-    // 1: k_grid_op / k_contact_hits write the checkpoint and the backward kernels read it in place (gval / gather_tile_load_fwd);
-    // 2: written in place by the forward pass, restored by k_grid_restore.  Measured (profiles/scripts/r02_h.sh, r02_i.sh: 3 interleaved runs,
-    // per-kernel minima): mode 1 costs k_g2p_grad a dependent slot lookup per tile record (+13 us) and the contact kernels +3 us
-    // each - 369 vs 364 us per substep pair; mode 2 equals mode 0 (363 vs 364).  Kept selectable, not a win.
-    int ck_mode = getenv("SMAC_CK_MODE") ? atoi(getenv("SMAC_CK_MODE")) : 0;
-    int g2p_pipe = getenv("SMAC_G2P_PIPE") ? atoi(getenv("SMAC_G2P_PIPE")) : 0;   // > 0: persistent pipelined k_g2p, this many workgroups per XCD
+    // (The forward grid reaches the checkpoint through copy work riding in k_g2p's launch and comes back through the restore riding in the grid-adjoint
+    // reduction's.  Writing / reading the checkpoint in place was measured in round 2 and was slower or equal: profiles/r02_x_checkpoint_in_place.txt.)
     std::vector<int> ck_epoch;       // epoch the slot of frame f was saved in (-1: invalid)
     std::vector<char> ck_has_hits;   // the frame's contact hit list is on file too
     std::vector<long long> ck_gen;   // configuration generation at save time
@@ -308,11 +299,7 @@ template <class R> struct Sim final : ISim {
         D.Npad = (c.n_particles + 255) / 256 * 256;
         // component rows are Npad scalars apart: keep that stride off large powers of two (1M particles would put all
         // 24 rows of a particle on the same HBM channel phase).  SMAC_ROW_SKEW scalars, a multiple of 64 (256 B).
-        {
-            const char* sk = getenv("SMAC_ROW_SKEW");
-            const int skew = sk ? atoi(sk) : 4160;
-            if (D.Npad >= 65536) D.Npad += (skew / 64) * 64;
-        }
+        if (D.Npad >= 65536) D.Npad += 4160;            // (65 x 64 scalars; profiles/r02_f_frame_layout.txt)
         if (SMAC_TILE_P) D.Npad = (c.n_particles + SMAC_TILE_P - 1) / SMAC_TILE_P * SMAC_TILE_P;       // AoSoA tiles (smac_math.hpp "Frame layout")
         D.n = c.n_grid;
         D.G = (size_t)c.n_grid * c.n_grid * c.n_grid;
@@ -1142,7 +1129,7 @@ template <class R> struct Sim final : ISim {
             Do.nactive = epochs[grid_epoch].nactive;
             hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 6);
         }
-        if (e != grid_epoch) { vin_clean = false; adj_grid_clean = true; }   // (the old epoch's blocks were zeroed just above; the rest always is)
+        if (e != grid_epoch) vin_clean = false;              // (the old epoch's blocks were zeroed just above; the rest always is)
         grid_epoch = e;
         const Epoch& ep = epochs[e];
         D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
@@ -1191,10 +1178,9 @@ template <class R> struct Sim final : ISim {
     }
     // A substep had more particles inside contact bands than a checkpoint slot holds (max(8192, N/8)): its list was not filed.  The host does
     // not know which frame it was, so every frame on file loses its list and substep_grad repeats the band test for them (k_contact_mask, as it
-    // does when the lists do not fit in memory at all) - slower, never wrong.  The direct-checkpoint modes walk the filed list in place: error.
+    // does when the lists do not fit in memory at all) - slower, never wrong.
     int hit_overflows = 0;
     int hit_overflow() {
-        REQUIRE(ck_mode == 0, kHitOverflowMessage);
         std::fill(ck_has_hits.begin(), ck_has_hits.end(), (char)0);
         ++hit_overflows;
         return SMAC_OK;
@@ -1672,34 +1658,16 @@ template <class R> struct Sim final : ISim {
             nhits_zero_frame = -1;
             if ((rc = bind_epoch(e))) return rc;
             ck_epoch[f] = -1;
-            // whole substep on one GPU: k_grid_op / k_contact_hits file the forward grid in the frame's checkpoint slot themselves
-            // (the slab decomposition exchanges halo planes of the dense arrays in between and keeps the copy kernel)
-            const bool direct = ck_mode != 0 && phase < 0 && D.nchunks > 0 && D.n_control == 0 && ck_prepare();
-            if (direct) {
-                const bool keep_hits = ck_hits && any_contact() && D.collision_type == CONTACT_MIXED;
-                D.ck = ck_slot(f);
-                D.hit_ck = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
-                D.nhit_ck = keep_hits ? ck_nhits + f : (int*)nullptr;
-                D.hit_cap = ck_hit_cap;
-            }
             // whole substep with particles: forward_kinematics rides in k_g2p's launch instead of a launch of its own (SMAC_FK_RIDE=0: own kernel)
-            fk_rides_g2p = fk_ride_env && phase < 0 && !g2p_pipe && cfg.rigid_velocity_control && D.P > 0 && D.nchunks > 0 && D.nactive > 0;
-            rc = forward_grid(f, true, false, phase < 0 ? 0 : 1);
-            D.ck = nullptr; D.hit_ck = nullptr; D.nhit_ck = nullptr;
-            if (rc) return rc;
-            if (direct) {
-                ck_epoch[f] = e;
-                ck_gen[f] = config_gen;
-                ck_has_hits[f] = (ck_hits && any_contact() && D.collision_type == CONTACT_MIXED) ? 1 : 0;
-                vin_clean = true;
-            }
+            fk_rides_g2p = fk_ride_env && phase < 0 && cfg.rigid_velocity_control && D.P > 0 && D.nchunks > 0 && D.nactive > 0;
+            if ((rc = forward_grid(f, true, false, phase < 0 ? 0 : 1))) return rc;
         }
         if (phase == 1 && (rc = forward_grid(f, true, false, 2))) return rc;
         if (phase < 0 || phase == 2) {
             const int e = frame_epoch[f];
             const bool save = ck_epoch[f] != e && D.nchunks > 0 && D.n_control == 0 && ck_prepare();   // keep the forward grid for substep_grad
             const bool keep_hits = save && ck_hits && any_contact();
-            const bool save_in_g2p = save && save_in_g2p_env && !g2p_pipe;                  // the save rides in k_g2p's launch (SMAC_SAVE_IN_G2P=0: own kernel)
+            const bool save_in_g2p = save && save_in_g2p_env;                              // the save rides in k_g2p's launch (SMAC_SAVE_IN_G2P=0: own kernel)
             if (save) {
                 ck_has_hits[f] = keep_hits ? 1 : 0;
                 if (!save_in_g2p) {
@@ -1717,10 +1685,7 @@ template <class R> struct Sim final : ISim {
             if (D.nchunks > 0) {
                 prof_begin(K_G2P);
                 D.check_next = (f + 1 - epochs[e].frame < epochs[e].interval) ? 1 : 0;     // else substep(f+1) re-bins first
-                if (g2p_pipe) {
-                    const int per = (D.nchunks + 7) / 8, J = per < g2p_pipe ? per : g2p_pipe;
-                    hipLaunchKernelGGL(k_g2p_pipe<R>, dim3(8 * J), dim3(BLOCK), 0, stream, D, f);
-                } else if (save_in_g2p) {
+                if (save_in_g2p) {
                     DevSim<R> Dg = D;
                     if (fk_rides_g2p) { Dg.fk_ride = D.P; Dg.fk_stride = (size_t)cfg.max_frames * 13; }
                     Dg.save_ck = ck_slot(f);
@@ -1753,7 +1718,6 @@ template <class R> struct Sim final : ISim {
     // 1: contact adjoint; 2: grid_op.grad, kinematics adjoint, p2g.grad.  Halo sums of grid_v_out.grad follow phase 0,
     // of grid_v_mixed.grad phase 1.
     bool pending_adj_zero = false;
-    bool direct_bwd = false;
     // Fused backward step (k_p2g_g2p_grad): when the batched loop (smac_substeps_grad) announces that substep f - 1 is reversed next, the
     // p2g.grad launch of substep f also does the G2P adjoint of substep f - 1 - its forward grid is restored first - and the call for f - 1
     // resumes at the slab reduction.  SMAC_FUSED_PG=0 keeps the two kernels apart.
@@ -1802,7 +1766,6 @@ template <class R> struct Sim final : ISim {
         if (grid_set != 0) {
             use_grid_set(0);
             vin_clean = false;
-            adj_grid_clean = false;
         }
     }
     int nhits_zero_frame = -1;           // forward frame whose hit counter is known to be empty (k_g2p<R, true> of the frame before emptied it)
@@ -1812,7 +1775,7 @@ template <class R> struct Sim final : ISim {
     void hint_backward_next(int f) override { bwd_hint = f; }
     bool can_fuse_prev(int f, int e, int phase, const double* action_grad_out) {
         if (!fused_pg_env || sizeof(R) != 4 || phase >= 0 || bwd_hint != f - 1 || f < 1 || action_grad_out) return false;   // (f64: 256 VGPRs + 88 KB of LDS, one workgroup per CU)
-        if (!pending_adj_zero || rolling() || !fused_grid_bwd(phase) || ck_mode != 0) return false;          // frame f carried a seed / frames come and go
+        if (!pending_adj_zero || rolling() || !fused_grid_bwd(phase)) return false;                          // frame f carried a seed / frames come and go
         if (frame_epoch[f - 1] != e || !(adj_epoch[f - 1] < 0 || adj_epoch[f - 1] == e)) return false;        // a re-sort lies between the two substeps
         if (!(ck_arena && ck_epoch[f - 1] == e && ck_gen[f - 1] == config_gen && D.n_control == 0 && D.nchunks > 0)) return false;
         if (D.collision_type == CONTACT_PARTICLE || D.cloth.present || D.mat_id) return false;
@@ -1823,13 +1786,13 @@ template <class R> struct Sim final : ISim {
     // (SMAC_FUSED_GRID_BWD=0 keeps the three-kernel sequence the slab phases use)
     int fused_bwd_env = getenv("SMAC_FUSED_GRID_BWD") ? atoi(getenv("SMAC_FUSED_GRID_BWD")) : 1;
     bool fused_grid_bwd(int phase) const {
-        return fused_bwd_env && phase < 0 && ck_mode != 1 && !(D.collision_type == CONTACT_GRID && any_contact());
+        return fused_bwd_env && phase < 0 && !(D.collision_type == CONTACT_GRID && any_contact());
     }
     int substep_grad_phase(int f, const double* action, const double* ext_f_grad, double* action_grad_out, int phase) {
         int rc;
         ++launch_counter;
         if ((rc = need_grad())) return rc;
-        if (!direct_bwd) D.nhits = d_nhits;  // (the backward pass uses one counter; the forward pass re-binds and re-empties its pair)
+        D.nhits = d_nhits;                   // (the backward pass uses one counter; the forward pass re-binds and re-empties its pair)
         nhits_zero_frame = -1;
         if (phase <= 0) fk_grad_rode = false;
         if (phase <= 0 && !bwd_since_fwd) {                 // first backward substep after a forward pass: a drifted epoch is repaired (or reported) now
@@ -1892,32 +1855,10 @@ template <class R> struct Sim final : ISim {
             adj_stale[f] = 0;                                                     // write mode overwrites every row
             D.An = An;
             const bool ck_ok = ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0;
-            if (ck_ok && ck_mode == 1 && phase < 0) {
-                // forward grid of this frame is on file and the kernels read it THERE (gval / gather_tile_load_fwd): no restore
-                // kernel.  The grid adjoints start from zero because k_grid_op_grad hands them back zeroed.
-                D.any_contact = any_contact() ? 1 : 0;
-                D.cur_frame = f;
-                if (!adj_grid_clean) {
-                    prof_begin(K_CLEAR);
-                    hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block + 3 * D.G, 3);
-                    prof_end();
-                }
-                D.ck = ck_slot(f);
-                const bool have_hits = ck_has_hits[f] && D.any_contact && D.collision_type == CONTACT_MIXED;
-                if (have_hits) {
-                    D.hits = ck_hits + (size_t)f * ck_hit_cap;                    // the contact adjoint walks the filed list in place
-                    D.nhits = ck_nhits + f;
-                } else if (D.any_contact && D.collision_type != CONTACT_GRID) {
-                    HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
-                    if (D.cloth.present) hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
-                    else hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
-                }
-                direct_bwd = true;
-            } else if (ck_ok) {
+            if (ck_ok) {
                 // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing
                 D.any_contact = any_contact() ? 1 : 0;
                 D.cur_frame = f;
-                adj_grid_clean = false;
                 prof_begin(K_CKPT);
                 const bool have_hits = ck_has_hits[f] && D.any_contact && D.collision_type == CONTACT_MIXED;
                 vin_clean = false;
@@ -1934,7 +1875,6 @@ template <class R> struct Sim final : ISim {
             } else {
                 REQUIRE(phase < 0, "slab-decomposed substep_grad needs the forward-grid checkpoint of this frame "
                                    "(recomputing it would need the forward halo exchanges again)");
-                adj_grid_clean = false;
                 if ((rc = forward_grid(f, false, true))) return rc;               // :347-359 (clears values + adjoints, recomputes)
             }
             if (D.nchunks > 0) {
@@ -2010,7 +1950,6 @@ template <class R> struct Sim final : ISim {
                 prof_end();
                 adj_epoch[f - 1] = e;
                 adj_stale[f - 1] = 0;
-                adj_grid_clean = false;
                 vin_clean = false;
                 g2p_done_frame = f - 1;
                 g2p_done_paz = paz_prev;
@@ -2038,11 +1977,6 @@ template <class R> struct Sim final : ISim {
             }
             adj_release(f + 2);                    // rolling storage: the sweep has passed frame f+2 two substeps ago
             if (g2p_done_frame < 0) normalize_grid_set();   // the sweep does not continue inside this epoch: back to buffer set 0
-            if (direct_bwd) {
-                D.ck = nullptr; D.hits = d_hits; D.nhits = d_nhits;
-                direct_bwd = false;
-                adj_grid_clean = true;             // k_grid_op_grad zeroed what it read
-            }
         }
         return check_launch();
     }
@@ -2088,7 +2022,29 @@ template <class R> struct Sim final : ISim {
     struct SlabCfg { bool on = false; int left0 = 0, right0 = 0, np = 2, peer_l = -1, peer_r = -1; bool contact_l = false, contact_r = false, self_loop = false; } sc;
     Vec4<R>* halo_buf = nullptr;        // [send L | send R | recv L | recv R], np * n * n records each
     size_t halo_records = 0;
-    int comm_stub = getenv("SMAC_COMM_STUB") ? atoi(getenv("SMAC_COMM_STUB")) : 0;   // 1: pack / events / unpack without the RCCL calls (host-enqueue measurements on one GPU)
+    // 1: pack / events / unpack without the RCCL calls (world-1 self loop: host-enqueue measurements on one GPU).  2: the IPC link of smac_comm.hpp -
+    // DIFFERENT ranks that may share one GPU, messages through exported device mailboxes, host-synchronous (the test transport of the distinct-peer code)
+    int comm_stub = getenv("SMAC_COMM_STUB") ? atoi(getenv("SMAC_COMM_STUB")) : 0;
+    IpcLink ipc;
+    // both directions of one neighbour exchange over the IPC link: send[s] / recv[s], s = 0 left, 1 right; a side takes part when either message is non-empty
+    int ipc_sendrecv(const void* const send[2], const size_t out[2], void* const recv[2], const size_t in[2]) {
+        const int peers[2] = {sc.peer_l, sc.peer_r};
+        bool act[2];
+        for (int s = 0; s < 2; ++s) {
+            act[s] = peers[s] >= 0 && (out[s] > 0 || in[s] > 0);
+            REQUIRE(out[s] <= ipc.slot_bytes && in[s] <= ipc.slot_bytes, "IPC link: a message exceeds the mailbox slot");
+            if (act[s] && out[s]) HIP_TRY(hipMemcpyAsync(ipc.mailbox + (size_t)s * ipc.slot_bytes, send[s], out[s], hipMemcpyDeviceToDevice, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int s = 0; s < 2; ++s)
+            if (act[s] && !sc.self_loop && !ipc.sync_pair(s)) { err = ipc.err; return SMAC_ERR_INVALID; }
+        for (int s = 0; s < 2; ++s)        // from the left neighbour its RIGHT slot, from the right neighbour its LEFT slot
+            if (act[s] && in[s]) HIP_TRY(hipMemcpyAsync(recv[s], ipc.peer_box[s] + (size_t)(1 - s) * ipc.slot_bytes, in[s], hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int s = 0; s < 2; ++s)
+            if (act[s] && !sc.self_loop && !ipc.sync_pair(s)) { err = ipc.err; return SMAC_ERR_INVALID; }
+        return SMAC_OK;
+    }
     // 0 (default): the RCCL group is enqueued on the kernels' own stream - in order, no event hand-off.  1: on the communication stream behind
     // two events.  Measured on one GPU (tools/exchange_overhead.py, profiles/r03_h_exchange_overhead.txt): a cross-stream hand-off costs more than
     // the 2 x 0.5 MB exchange itself, and until interior chunks are launched beside it there is nothing for the second stream to overlap with.
@@ -2105,6 +2061,14 @@ template <class R> struct Sim final : ISim {
     int comm_init(const char* id128, int rank, int world) override {
         REQUIRE(id128 && world >= 1 && rank >= 0 && rank < world, "comm_init: bad rank / world / id");
         REQUIRE(!comm, "comm_init: this handle already has a communicator");
+        if (comm_stub == 2) {                                 // the IPC link: the id names a shared-memory segment (smac_comm_unique_id made it)
+            REQUIRE(!ipc.shm, "comm_init: this handle already has an IPC link");
+            HIP_TRY(hipSetDevice(cfg.device));
+            if (!ipc.attach(id128, rank, world)) { err = ipc.err; return SMAC_ERR_INVALID; }
+            if (!ipc.sync_all()) { err = ipc.err; return SMAC_ERR_INVALID; }
+            c_rank = rank; c_world = world;
+            return SMAC_OK;
+        }
         Rccl& L = Rccl::get();
         if (!L.load()) { err = L.err; return SMAC_ERR_INVALID; }
         ncclUniqueId id;
@@ -2140,6 +2104,13 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipMalloc((void**)&halo_buf, 4 * rec * sizeof(Vec4<R>)));
             halo_records = rec;
         }
+        if (comm_stub == 2) {
+            REQUIRE(ipc.shm, "comm_slab: no IPC link (smac_comm_init with SMAC_COMM_STUB=2)");
+            size_t bytes = rec * sizeof(Vec4<R>);
+            if (mig_bytes(cfg.n_particles) > bytes) bytes = mig_bytes(cfg.n_particles);      // (a migration can hand over at most the handle's capacity)
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (!ipc.open_boxes(bytes, sc.peer_l, sc.peer_r, sc.self_loop)) { err = ipc.err; return SMAC_ERR_HIP; }
+        }
         if (!comm_stream) {                                   // (stub mode without a communicator)
             HIP_TRY(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ev_kernels, hipEventDisableTiming));
@@ -2165,7 +2136,17 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipEventRecord(ev_kernels, stream));
             HIP_TRY(hipStreamWaitEvent(comm_stream, ev_kernels, 0));
         }
-        if (!comm_stub) {
+        if (comm_stub == 2) {
+            const void* snd[2] = {nullptr, nullptr};
+            void* rcv[2] = {nullptr, nullptr};
+            size_t nb[2] = {0, 0};
+            for (int s = 0; s < hs.count; ++s) {
+                const int side = hs.slot[s];                  // slot 0 = left neighbour, 1 = right neighbour
+                snd[side] = send + (size_t)side * rec; rcv[side] = recv + (size_t)side * rec; nb[side] = rec * sizeof(Vec4<R>);
+            }
+            int rc = ipc_sendrecv(snd, nb, rcv, nb);
+            if (rc) return rc;
+        } else if (!comm_stub) {
             Rccl& L = Rccl::get();
             const size_t count = rec * 4;
             NCCL_TRY(L.GroupStart());
@@ -2243,6 +2224,24 @@ template <class R> struct Sim final : ISim {
     // SUM over the ranks of the per-rank partial wrench sums / primitive-state adjoints, in place - once per env step, where the reference
     // consumes them (rigid_simulator.py:92-93, 203-208): 6 P and 13 P substeps scalars, not grid traffic
     int comm_allreduce(double* buf, size_t n) {
+        if (comm_stub == 2 && c_world > 1 && n > 0) {         // IPC link: through the host array of the shared segment, REDUCE_CAP doubles per round
+            std::vector<double> mine(IpcLink::REDUCE_CAP);
+            for (size_t at = 0; at < n; at += IpcLink::REDUCE_CAP) {
+                const size_t m = n - at < IpcLink::REDUCE_CAP ? n - at : IpcLink::REDUCE_CAP;
+                HIP_TRY(hipMemcpyAsync(ipc.shm->reduce[c_rank], buf + at, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (!ipc.sync_all()) { err = ipc.err; return SMAC_ERR_INVALID; }
+                for (size_t i = 0; i < m; ++i) {
+                    double acc = 0.0;
+                    for (int r = 0; r < c_world; ++r) acc += ipc.shm->reduce[r][i];
+                    mine[i] = acc;
+                }
+                if (!ipc.sync_all()) { err = ipc.err; return SMAC_ERR_INVALID; }          // (everybody has read every slot before the next round overwrites them)
+                HIP_TRY(hipMemcpyAsync(buf + at, mine.data(), m * sizeof(double), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
+            return SMAC_OK;
+        }
         if (comm_stub || c_world == 1 || n == 0) return SMAC_OK;
         REQUIRE(comm, "no communicator (smac_comm_init)");
         Rccl& L = Rccl::get();
@@ -2278,6 +2277,7 @@ template <class R> struct Sim final : ISim {
         if (stream) HIP_TRY(hipStreamSynchronize(stream));
         if (comm_stream) HIP_TRY(hipStreamSynchronize(comm_stream));
         if (comm) { Rccl::get().CommDestroy(comm); comm = nullptr; }
+        ipc.detach();
         if (comm_stream) { hipStreamDestroy(comm_stream); comm_stream = nullptr; }
         if (ev_kernels) { hipEventDestroy(ev_kernels); ev_kernels = nullptr; }
         if (ev_comm) { hipEventDestroy(ev_comm); ev_comm = nullptr; }
@@ -2333,6 +2333,7 @@ template <class R> struct Sim final : ISim {
     // self loop: what leaves on the left arrives on the right and vice versa (the stub moves it with device copies)
     int neighbour_exchange(const void* const send[2], const size_t bytes_out[2], void* const recv[2], const size_t bytes_in[2]) {
         const int peers[2] = {sc.peer_l, sc.peer_r};
+        if (comm_stub == 2) return ipc_sendrecv(send, bytes_out, recv, bytes_in);
         if (comm_stub) {
             for (int s = 0; s < 2; ++s)
                 if (peers[s] >= 0 && bytes_out[s]) HIP_TRY(hipMemcpyAsync(recv[1 - s], send[s], bytes_out[s], hipMemcpyDeviceToDevice, stream));
@@ -2929,6 +2930,11 @@ int smac_substep_phase(smac_handle h, int f, int phase) { return FWD(substep_pha
 int smac_substep_grad_phase(smac_handle h, int f, const double* ext_f_grad, int phase) { return FWD(substep_grad_phase_v(f, ext_f_grad, phase)); }
 int smac_comm_unique_id(char id128[128]) {
     if (!id128) { g_create_error = "null argument"; return SMAC_ERR_INVALID; }
+    if (getenv("SMAC_COMM_STUB") && atoi(getenv("SMAC_COMM_STUB")) == 2) {      // the IPC test transport: the id names its shared-memory segment
+        std::string e;
+        if (!IpcLink::make_id(id128, e)) { g_create_error = e; return SMAC_ERR_INVALID; }
+        return SMAC_OK;
+    }
     Rccl& L = Rccl::get();
     if (!L.load()) { g_create_error = L.err; return SMAC_ERR_INVALID; }
     ncclUniqueId id;

@@ -5,6 +5,8 @@ import pathlib
 import sys
 import types
 
+import os
+
 import numpy as np
 import torch
 
@@ -50,6 +52,16 @@ def load_palm():
     d = np.load(GOLDEN / "palm_sdf.npz")
     return dict(sdf=d["sdf"], normal=d["normal"], lower=d["lower"], upper=d["upper"], dx=float(d["dx"]),
                 res=np.asarray(d["res"]))
+
+
+def note(tag, measured, bound):
+    """with SMAC_PRINT_ERRS=<file>: append `tag measured bound` (the measured value behind every float32 bound that is not F32_TOL,
+    collected in one run and committed under profiles/)"""
+    path = os.environ.get("SMAC_PRINT_ERRS")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(f"{tag}\t{float(measured):.3e}\t{float(bound):.3e}\n")
+    return measured
 
 
 def rel_err(a, b):

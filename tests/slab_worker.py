@@ -52,6 +52,31 @@ def main():
         out = dict(x=x.numpy(), v=v.numpy(), C=C.numpy(), F=F.numpy(), gx=g[0].numpy(), gv=g[1].numpy(), gC=g[2].numpy(), gF=g[3].numpy(),
                    ext=np.array([e.numpy() for e in eng.ext]) if sc["specs"] else np.zeros((0, 6)),
                    pgrad=np.array([eng.pgrad.get(f, [np.zeros(13)] * len(sc["specs"])) for f in range(nsteps)]))
+    elif a.engine == "lib":
+        # the slab loop INSIDE the library between two real ranks on the one GPU: SMAC_COMM_STUB=2 (set by the test) swaps RCCL for the IPC link of
+        # smac_comm.hpp - distinct peers, left / right slot mapping, two-sided pack / unpack-add, the reductions of the primitives' sums
+        from softmac_amd.parallel import LibSlabRunner, rendezvous_unique_id
+        assert os.environ.get("SMAC_COMM_STUB") == "2"
+        cfg = sc["cfg"]
+        cfg.n_particles = len(state)
+        sim, prims = H.build_engine(cfg, sc["env_dt"], sc["specs"], sc["pstates"])
+        sim.reset(state)
+        run = LibSlabRunner(sim, a.rank, a.world, sc["split"], sc["split"], 2, has_contact=(True, True), unique_id=rendezvous_unique_id(a.rank))
+        run.run_substeps(0, nsteps)
+        sim.clear_grads()
+        for f, s in seeds.items():
+            sim.add_grad(f, **{k: (None if s[i] is None else s[i][idx]) for i, k in enumerate(("gx", "gv", "gC", "gF"))})
+        run.run_substeps_grad(0, nsteps, sc["ext_f_grad"])
+        st = sim.get_state(nsteps)
+        N = len(state)
+        gx, gv, gF, gC = sim.get_grad_full(0)
+        out = dict(x=st[:, 0:3], v=st[:, 3:6], F=st[:, 6:15].reshape(N, 3, 3), C=st[:, 15:24].reshape(N, 3, 3), gx=gx, gv=gv, gC=gC, gF=gF,
+                   ext=np.array([m.ext_f.to_numpy() for m in prims]), pgrad=np.array([[m.get_all_states_grad(f) for m in prims] for f in range(nsteps)]),
+                   exchanges=run.exchanges())
+        out["ext_total"] = run.allreduce_ext_f()                  # the all-reduces over the link: every rank then holds the sums
+        run.allreduce_state_grad(0, nsteps)
+        out["pgrad_total"] = np.array([[m.get_all_states_grad(f) for m in prims] for f in range(nsteps)])
+        run.close()
     else:
         from softmac_amd.parallel import HipSlabEngine
         cfg = sc["cfg"]
@@ -180,6 +205,8 @@ def moving(a):
         sim.set_segment(len(state), 0)
         sim.reset(state)
         eng = HipSlabEngine(sim, use_torch_stream=True)
+    if a.engine == "lib":
+        return moving_lib(a, sc, sim, ids0, (lo, hi), left0, right0, npl, n, M)
     run = SlabRunner(eng, a.rank, a.world, left0, right0, npl, has_contact=False, own=(lo, hi), ids=ids0)
     f, starts = 0, []
     for seg in range(n // M):
@@ -207,6 +234,45 @@ def moving(a):
     g0 = eng.get_grad_rows(0)
     moved = int(len(np.setdiff1d(ids_end, ids0)))
     np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", ids0=ids0, ids_end=ids_end, st_end=st_end, g0=g0, moved=moved)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def moving_lib(a, sc, sim, ids0, own, left0, right0, npl, n, M):
+    """the migration scene through smac_substeps_slab / smac_migrate between two real ranks (IPC link): particles, their global ids and - on the way
+    back - their adjoint rows change hands as device-side byte messages"""
+    from softmac_amd.parallel import LibSlabRunner, rendezvous_unique_id
+    assert os.environ.get("SMAC_COMM_STUB") == "2"
+    run = LibSlabRunner(sim, a.rank, a.world, left0, right0, npl, has_contact=(False, False), own=own, unique_id=rendezvous_unique_id(a.rank))
+    run.set_ids(ids0)
+    f, starts = 0, []
+    for seg in range(n // M):
+        starts.append(f)
+        run.run_substeps(f, M)
+        f += M
+        if seg < n // M - 1:
+            f = run.migrate(f, own)
+    ids_end = run.ids().copy()
+    st_end = sim.get_state(f)
+    rng = np.random.default_rng(77)
+    N = len(sc["state"])
+    seed_end = np.hstack([rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), 0.01 * rng.standard_normal((N, 9)), 0.01 * rng.standard_normal((N, 9))])
+    seed_1 = np.hstack([rng.standard_normal((N, 3)), np.zeros((N, 21))])
+    rows = lambda r: dict(gx=r[:, 0:3], gv=r[:, 3:6], gF=r[:, 6:15].reshape(-1, 3, 3), gC=r[:, 15:24].reshape(-1, 3, 3))
+    sim.clear_grads()
+    sim.add_grad(f, **rows(seed_end[ids_end]))
+    for seg in range(n // M - 1, -1, -1):
+        if seg == 0:
+            sim.add_grad(1, gx=seed_1[ids0][:, 0:3])
+        run.run_substeps_grad(starts[seg], M)
+        if seg > 0:
+            run.migrate_grad()
+    assert (run.ids() == ids0).all()
+    gx, gv, gF, gC = sim.get_grad_full(0)
+    g0 = np.hstack([gx, gv, gF.reshape(-1, 9), gC.reshape(-1, 9)])
+    moved = int(len(np.setdiff1d(ids_end, ids0)))
+    np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", ids0=ids0, ids_end=ids_end, st_end=st_end, g0=g0, moved=moved)
+    run.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -75,7 +75,7 @@ def test_velocity_control_rollout_and_action_gradients(precision, ts, tg):
     (gA,) = torch.autograd.grad(L, A)
     assert H.rel_err(x_got, x.detach().numpy()) < ts
     assert np.abs(gA[-1]).max() == 0 and np.abs(got[-1]).max() == 0          # the last action only sets the next step's velocities
-    assert H.rel_err(got, gA.numpy()) < tg, (got, gA)
+    assert H.note(f"env action.grad {precision}", H.rel_err(got, gA.numpy()), tg) < tg, (got, gA)
     # pose reached through device forward kinematics
     st = mesh.get_state(T)
     assert np.abs(st[:3] - pos.detach().numpy()).max() < ts * 10 and np.abs(st[3:7] - rot.detach().numpy()).max() < max(ts * 10, 1e-6)

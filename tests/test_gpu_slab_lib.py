@@ -224,7 +224,7 @@ def test_device_side_migration_round_trip(precision, tol):
     assert f == 8 and sorted(ids2.tolist()) == list(range(N))
     run.run_substeps(8, 2)
     end = sim.get_state(10)
-    assert H.rel_err(end, ref_end[ids2]) < tol
+    assert H.note(f"migration state {precision}", H.rel_err(end, ref_end[ids2]), tol) < tol
     sim.clear_grads()
     sim.add_grad(10, gx=seed[0][ids2], gv=seed[1][ids2])
     run.run_substeps_grad(8, 2)
@@ -235,5 +235,5 @@ def test_device_side_migration_round_trip(precision, tol):
     assert (run.ids() == np.arange(N)).all()
     run.run_substeps_grad(0, 3)
     g = np.hstack(sim.get_grad(0))
-    assert H.rel_err(g, ref_g) < tol, H.rel_err(g, ref_g)
+    assert H.note(f"migration grad {precision}", H.rel_err(g, ref_g), tol) < tol, H.rel_err(g, ref_g)
     run.close()

@@ -43,7 +43,7 @@ def test_windowed_episode_equals_the_resident_one(precision, tol):
     got, got_prim = ep.backward(seeds)
     for name, a, b in zip(("gx", "gv", "gF", "gC"), got, want):
         if precision == "float64":
-            assert H.rel_err(a, b) < tol, (name, H.rel_err(a, b))
+            assert H.note(f"windowed episode {name} {precision}", H.rel_err(a, b), tol) < tol, (name, H.rel_err(a, b))
         else:
             # the windowed run re-bins at every window start: another particle order, float32 roundings apart over 23 substeps with contact and a
             # yield surface - 99th percentile tight, the few particles on the other side of a branch loose (tests/test_gpu_fused_backward.py)
@@ -121,4 +121,4 @@ def test_windowed_env_episode_equals_the_resident_env(precision, tol):
     assert H.rel_err(env2.simulator.get_x(ep.frame), want_x) < (1e-9 if precision == "float64" else 1e-5)
     assert np.abs(mesh2.get_state(ep.frame) - want_pose).max() < 1e-8
     got = ep.backward(seeds).numpy()
-    assert H.rel_err(got, want) < tol, (got, want)
+    assert H.note(f"windowed env action.grad {precision}", H.rel_err(got, want), tol) < tol, (got, want)

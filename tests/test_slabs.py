@@ -21,10 +21,12 @@ def _free_port():
     return p
 
 
-def _run_ranks(engine, precision, tmp_path, world=2, scene="static"):
+def _run_ranks(engine, precision, tmp_path, world=2, scene="static", env=None):
     port = _free_port()
+    import os
     procs = [subprocess.Popen([sys.executable, str(HERE / "slab_worker.py"), "--engine", engine, "--rank", str(r), "--world", str(world),
-                               "--port", str(port), "--out", str(tmp_path), "--precision", precision, "--scene", scene]) for r in range(world)]
+                               "--port", str(port), "--out", str(tmp_path), "--precision", precision, "--scene", scene],
+                              env=None if env is None else dict(os.environ, **env)) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=900) == 0
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
@@ -133,6 +135,31 @@ def test_two_slabs_match_single_domain_cpu(tmp_path):
 @pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-8), ("float32", H.F32_TOL["state"], H.F32_TOL["grad"])])
 def test_two_slabs_match_single_domain_gpu(tmp_path, precision, ts, tg):
     _check(_run_two_ranks("hip", precision, tmp_path), ts, tg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-8), ("float32", H.F32_TOL["state"], H.F32_TOL["grad"])])
+def test_in_library_slab_loop_between_two_ranks_gpu(tmp_path, precision, ts, tg):
+    """`smac_substeps_slab[_grad]` had only ever run as a world-1 self exchange (two RCCL ranks cannot share the one GPU of a
+    development box).  SMAC_COMM_STUB=2 swaps RCCL for the IPC link of smac_comm.hpp - exported device mailboxes, host-synchronous - and runs the SAME
+    loop between two processes: rank 0 has only a right neighbour, rank 1 only a left one, so the left / right slot mapping, the one-sided pack and
+    unpack-add and the 2 + 2 exchanges per substep pair run as they would over RCCL.  Same scene and same bar as the Python loop: every particle, every
+    adjoint, the wrench and the palm's state adjoints against the single-domain oracle; the link's all-reduces give every rank the sums."""
+    parts = _run_ranks("lib", precision, tmp_path, env={"SMAC_COMM_STUB": "2"})
+    _check(parts, ts, tg)
+    sc = S.build()
+    assert all(int(p["exchanges"]) == 4 * sc["nsteps"] for p in parts)
+    ext, pgr = sum(p["ext"] for p in parts), sum(p["pgrad"] for p in parts)
+    for p in parts:
+        assert np.abs(p["ext_total"] - ext).max() <= 1e-12 * np.abs(ext).max() and np.abs(p["pgrad_total"] - pgr).max() <= 1e-12 * np.abs(pgr).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-8), ("float32", H.F32_TOL["state"], H.F32_TOL["grad"])])
+def test_device_side_migration_between_two_ranks_gpu(tmp_path, precision, ts, tg):
+    """`smac_migrate` / `smac_migrate_grad` between two real ranks (IPC link): counts, rows + global ids and, backwards, adjoint rows cross as device-side
+    byte messages - against the single-domain oracle, as the host-staged Python migration is"""
+    _check_moving(_run_ranks("lib", precision, tmp_path, 2, "moving", env={"SMAC_COMM_STUB": "2"}), 2, ts, tg)
 
 
 @pytest.mark.gpu

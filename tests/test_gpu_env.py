@@ -31,7 +31,7 @@ def _scene(precision):
     return cfg, state, pose, vel
 
 
-@pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-7), ("float32", H.F32_TOL["state"], 1e-4)])
+@pytest.mark.parametrize("precision,ts,tg", [("float64", 1e-9, 1e-7), ("float32", H.F32_TOL["state"], H.F32_TOL["grad"])])      # (measured 6.7e-7: profiles/r04_g_f32_bounds.txt)
 def test_velocity_control_rollout_and_action_gradients(precision, ts, tg):
     from softmac_amd.config import CfgNode
     from softmac_amd.engine.primitive import Mesh, Primitives

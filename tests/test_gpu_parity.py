@@ -64,7 +64,7 @@ def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None
         for i, m in enumerate(prims):
             got = m.ext_f.to_numpy()
             scale = max(np.abs(ext_ref[i]).max(), 1e-12)
-            assert H.note(f"ext_f prim {i} {cfg.precision} N={N}", np.abs(got - ext_ref[i]).max() / scale, max(tol["state"] * 50, 1e-8)) < max(tol["state"] * 50, 1e-8), (i, got, ext_ref[i])
+            assert H.note(f"ext_f prim {i} {cfg.precision} N={N}", np.abs(got - ext_ref[i]).max() / scale, max(tol["state"], 1e-8)) < max(tol["state"], 1e-8), (i, got, ext_ref[i])
     # ---- backward: seed all four adjoints at the last frame, x adjoint at a middle frame too
     rng = np.random.default_rng(seed + 100)
     seeds = {nsteps: (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), 0.01 * rng.standard_normal((N, 3, 3)),
@@ -114,7 +114,7 @@ def _compare_rollout(cfg, env_dt, state, nsteps, prim_specs=(), prim_states=None
                 ref = pg[f][i]
                 got = m.get_all_states_grad(f)
                 scale = max(np.abs(ref).max(), 1e-9)
-                assert H.note(f"prim state.grad {i} frame {f} {cfg.precision} N={N}", np.abs(got - ref).max() / scale, tol["grad"] * 10) < tol["grad"] * 10, (i, f, got, ref)
+                assert H.note(f"prim state.grad {i} frame {f} {cfg.precision} N={N}", np.abs(got - ref).max() / scale, tol["grad"] * 5) < tol["grad"] * 5, (i, f, got, ref)
     if actions is not None:
         for f in range(nsteps):
             assert H.rel_err(got_ag[f], ag[f]) < tol["grad"], (f, got_ag[f], ag[f])

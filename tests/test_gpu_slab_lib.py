@@ -183,7 +183,7 @@ def test_cloth_variant_under_the_slab_loop():
     runner.close()
 
 
-@pytest.mark.parametrize("precision,tol", [("float64", 1e-10), ("float32", 1e-4)])
+@pytest.mark.parametrize("precision,tol", [("float64", 1e-10), ("float32", H.F32_TOL["state"])])      # (measured 1.1e-6 / 5.9e-7: profiles/r04_g_f32_bounds.txt)
 def test_device_side_migration_round_trip(precision, tol):
     """smac_migrate / smac_migrate_grad (VERDICT r2 missing #3: migration went through get_state on the host).  World-1 self exchange: what leaves
     on one side re-enters on the other with the SAME coordinates, so the particle set is unchanged and only its order, its segment bookkeeping and

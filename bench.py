@@ -48,6 +48,9 @@ def build_sim(args, rank, world, precision=None, frames=None):
     from softmac_amd.engine.primitive import Mesh, Primitives
     precision = precision or args.precision
     frames = frames or (args.warmup + args.steps + 2)
+    mig = getattr(args, "migrate_every", 0) if world > 1 else 0
+    if mig > 0:
+        frames += (args.warmup + args.steps) // mig + 2           # a migration starts a new segment one frame further on
     dev = int(os.environ.get("SMAC_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0))) if world > 1 else 0
     slab = _own = None
     tables = gripper_tables(dev) if args.workload == "s-grip" else None
@@ -68,7 +71,14 @@ def build_sim(args, rank, world, precision=None, frames=None):
         pc = CfgNode(); pc.friction = s["friction"]; pc.enable_external_force = True; pc.urdf_path = ""
         meshes.append(Mesh(sdf=s, cfg=pc, max_timesteps=frames))
     prims = Primitives(primitives=meshes)
+    n_own = len(state)
+    if mig > 0 and slab is not None:
+        if not (args.scaling == "strong" and args.slab_runner == "lib"):
+            sys.exit("bench.py: --migrate-every needs --scaling strong and --slab-runner lib (device-side migration)")
+        cfg.n_particles = n_own + n_own // 4 + 1024               # capacity: room for arrivals
     sim = MPMSimulator(cfg, prims, env_dt)
+    if mig > 0 and slab is not None:
+        sim.set_segment(n_own, 0)
     prims.initialize()
     for m, s in zip(meshes, specs):
         m.friction[None] = s["friction"]
@@ -114,6 +124,11 @@ def build_sim(args, rank, world, precision=None, frames=None):
             runner = SlabRunner(HipSlabEngine(sim, use_torch_stream=True), rank, world, slab[0], slab[1], slab[2], has_contact=sides)
         runner.contact_sides_note = sides
         runner.fallback_note = fallback
+        if mig > 0:
+            if fallback is not None:
+                sys.exit("bench.py: --migrate-every: the in-library runner did not come up")
+            runner.own_range = own
+            runner.set_ids(np.asarray(_own, dtype=np.int64))
     return sim, runner, cfg
 
 
@@ -303,6 +318,9 @@ def parse_args(argv=None):
     ap.add_argument("--slab-runner", default=os.environ.get("SMAC_SLAB_RUNNER", "python"), choices=["lib", "python"],
                     help="N > 1: python (default) = parallel.SlabRunner on torch.distributed (RCCL through torch); lib = smac_substeps_slab (RCCL inside "
                          "the library) - selectable, not the default, until it has run between two different ranks (it has only run as a world-1 self exchange)")
+    ap.add_argument("--migrate-every", type=int, default=0,
+                    help="N > 1, strong scaling, --slab-runner lib: hand particles over between the slabs (smac_migrate, device side) every k substeps INSIDE the "
+                         "timed window; the handles get 25 %% spare capacity and one extra frame per migration")
     ap.add_argument("--launch-check", action="store_true",
                     help="spawn the ranks, rendezvous (gloo), report - no simulator, no GPU call (CPU test of the launcher)")
     return ap.parse_args(argv)
@@ -343,36 +361,64 @@ def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist):
     K, W = args.steps, args.warmup
     env = max(sim.substeps, 1)
 
+    M = getattr(args, "migrate_every", 0) if reducer is not None else 0
+    segs = []                                                # (first frame, substeps) of the segments of the last forward pass; a migration between two of them
+
     def forward(f0, n):
         if reducer is None:
             run.run_substeps(f0, n)
-            return
+            return f0 + n
+        if M > 0:                                            # migrating window: k substeps, hand-over (frame index + 1), k substeps, ...
+            del segs[:]
+            f, done = f0, 0
+            while done < n:
+                m = min(M, n - done)
+                run.run_substeps(f, m)
+                segs.append((f, m))
+                f, done = f + m, done + m
+                reducer.allreduce_ext_f(clear=True)
+                if done < n:
+                    f = run.migrate(f, run.own_range)
+            return f
         f = f0
         while f < f0 + n:                                   # per env step: substeps, then the wrench sums of all slabs
             m = min(env - f % env, f0 + n - f)
             run.run_substeps(f, m)
             f += m
             reducer.allreduce_ext_f(clear=True)
+        return f
 
     def backward(f0, n):
+        if M > 0 and reducer is not None:
+            for i in range(len(segs) - 1, -1, -1):
+                run.run_substeps_grad(*segs[i])
+                reducer.allreduce_state_grad(segs[i][0], segs[i][0] + segs[i][1])
+                if i > 0:
+                    run.migrate_grad()
+            return
         run.run_substeps_grad(f0, n)
         if reducer is not None:
             reducer.allreduce_state_grad(f0, f0 + n)
 
-    forward(0, W)
-    sim.clear_grads()
-    sim.add_grad(W, gx=seed_gx)
+    def seed(f_end):
+        sim.clear_grads()
+        n_now = sim.n_particles                              # (a migrating window ends with another particle count than it started with)
+        sim.add_grad(f_end, gx=seed_gx[:n_now] if n_now <= len(seed_gx) else np.vstack([seed_gx, seed_gx[:n_now - len(seed_gx)]]))
+
+    seed(forward(0, W))
     backward(0, W)
     walls, devs = [], []
     for _ in range(max(args.repeats, 1)):
-        sim.clear_grads()
-        sim.add_grad(W + K, gx=seed_gx)
         for m in sim.primitives:
             m.clear_ext_f()
+        if M == 0:
+            seed(W + K)                                      # (without migrations the end frame is known before the window; the seed stays outside the timed region)
         barrier()
         t0 = time.perf_counter()
         sim.timer_start()
-        forward(W, K)
+        f_end = forward(W, K)
+        if M > 0:
+            seed(f_end)
         backward(W, K)
         dev_ms = sim.timer_stop()
         barrier()
@@ -384,6 +430,17 @@ def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist):
             wall = float(t.item())
         walls.append(wall)
         devs.append(dev_ms)
+    timed_windows.migrations = max(len(segs) - 1, 0)
+    timed_windows.moved = int(getattr(run, "moved", 0))
+
+    def pair(f0, n):                                         # one window outside the timed region (profile pass): seed wherever the window ends
+        if M == 0:
+            seed(f0 + n)
+        f_end = forward(f0, n)
+        if M > 0:
+            seed(f_end)
+        backward(f0, n)
+    timed_windows.pair = pair
     return walls, devs, forward, backward
 
 
@@ -450,11 +507,8 @@ def main():
     value = (1 if (strong or world == 1) else world) * K / wall
 
     # per-kernel HIP-event profile over one more identical pass (kept out of the timed region)
-    sim.clear_grads()
-    sim.add_grad(W + K, gx=seed_gx)
     sim.profile(True)
-    forward(W, K)
-    backward(W, K)
+    timed_windows.pair(W, K)
     prof = sim.profile_report()
     sim.profile(False)
     # SURVEY 8(d) asks for the two directions separately as well: one more pass with a sync between them
@@ -533,9 +587,12 @@ def main():
                        else "forward grid restored from the per-frame checkpoint saved by substep",
                        "resort_interval": args.sort_interval, "resorts_in_window": int(kern.get("sort", (0, 0))[1]),
                        "parallelism": par},
-            "slab_runner": None if world == 1 else (getattr(run, "fallback_note", None) or ("in-library RCCL loop" if args.slab_runner == "lib" else "Python SlabRunner")),
-            "multi_gpu_note": None if world == 1 else ("the in-library RCCL slab loop has run on ONE GPU only (world-1 self exchange, tests/test_gpu_slab_lib.py) "
-                                                         "and the Python SlabRunner under gloo; no N > 1 result existed when this code was committed"),
+            "slab_runner": None if world == 1 else (getattr(run, "fallback_note", None) or (("in-library slab loop over the IPC test transport" if os.environ.get("SMAC_COMM_STUB") == "2" else "in-library RCCL loop") if args.slab_runner == "lib" else "Python SlabRunner")),
+            "transport": None if world == 1 else ("IPC link between processes sharing GPUs (SMAC_COMM_STUB=2: a test transport, host-synchronous - NOT a scaling number)"
+                                                    if os.environ.get("SMAC_COMM_STUB") == "2" else "RCCL"),
+            "migrations_in_window": int(getattr(timed_windows, "migrations", 0)), "particles_migrated": int(getattr(timed_windows, "moved", 0)),
+            "multi_gpu_note": None if world == 1 else ("no N > 1 run on N GPUs existed when this code was committed: the in-library slab loop has run between two ranks "
+                                                         "over the IPC test transport on one GPU (tests/test_slabs.py) and as a world-1 RCCL self exchange"),
             "repeats": len(walls), "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
             "spread": (max(walls) - min(walls)) / wall,
             "device_ms_per_step": dev_ms / K,

@@ -162,16 +162,21 @@ struct IpcLink {
     // the mailbox of this rank (2 x bytes) and its neighbours' (self_loop: this rank's own)
     bool open_boxes(size_t bytes, int peer_l, int peer_r, bool self_loop) {
         close_boxes();
+        const bool alone = self_loop || world == 1;
+        if (!alone) {                                              // one slot size for everybody: the largest any rank asks for (capacities differ per slab)
+            shm->slot_bytes[rank] = bytes;
+            if (!sync_all()) return false;
+            for (int r = 0; r < world; ++r) bytes = shm->slot_bytes[r] > bytes ? shm->slot_bytes[r] : bytes;
+            if (!sync_all()) return false;                         // (everybody has read the sizes before anybody publishes again)
+        }
         if (hipMalloc((void**)&mailbox, 2 * bytes) != hipSuccess) { err = "hipMalloc failed for the IPC mailbox"; return false; }
         slot_bytes = bytes;
-        if (self_loop || world == 1) { peer_box[0] = peer_box[1] = mailbox; return true; }
+        if (alone) { peer_box[0] = peer_box[1] = mailbox; return true; }
         if (hipIpcGetMemHandle(&shm->handle[rank], mailbox) != hipSuccess) { err = "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)"; return false; }
-        shm->slot_bytes[rank] = bytes;
         if (!sync_all()) return false;
         const int peers[2] = {peer_l, peer_r};
         for (int s = 0; s < 2; ++s) {
             if (peers[s] < 0) continue;
-            if (shm->slot_bytes[peers[s]] != bytes) { err = "IPC link: the neighbours' mailboxes differ in size (different slab geometry?)"; return false; }
             if (hipIpcOpenMemHandle((void**)&peer_box[s], shm->handle[peers[s]], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
                 err = "hipIpcOpenMemHandle failed"; return false;
             }

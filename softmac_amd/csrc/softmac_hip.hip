@@ -985,7 +985,7 @@ template <class R> struct Sim final : ISim {
     }
     int repair_drift(int f_end, int e_bad) {
         // (the cloth variant is not replayed: its contact-face search and penetration tracing run on the host's schedule between the substeps)
-        if (repairing || bwd_since_fwd || slab_phase_used || D.n_control > 0 || D.cloth.present || e_bad <= 0 || !epochs[e_bad].live || !ext_snap)
+        if (repairing || bwd_since_fwd || slab_phase_used || D.cloth.present || e_bad <= 0 || !epochs[e_bad].live || !ext_snap)
             return SMAC_ERR_INVALID;
         const int fs = epochs[e_bad].frame;
         if (!(fs < f_end) || frame_epoch[fs] != e_bad) return SMAC_ERR_INVALID;
@@ -1000,7 +1000,13 @@ template <class R> struct Sim final : ISim {
         const int keep = sort_interval;
         sort_interval = 1;
         epochs[e_bad].interval = 1;                          // frame fs keeps its (fresh) binning; every later frame is re-binned before it is used
-        for (int g = fs; g < f_end && !rc; ++g) rc = substep_phase(g, nullptr, -1);
+        const std::vector<double> action_keep = action_now;
+        for (int g = fs; g < f_end && !rc; ++g) {
+            // the action frame g's substep ran with (particle controllers); action.grad is a backward quantity and no backward substep has run since
+            const bool has = D.n_control > 0 && g < (int)action_of_frame.size() && !action_of_frame[g].empty();
+            rc = substep_phase(g, has ? action_of_frame[g].data() : nullptr, -1);
+        }
+        if (!rc && D.n_control > 0 && !action_keep.empty()) rc = set_action(action_keep.data());
         replay_count_from = -1;
         sort_interval = keep;
         repairing = false;
@@ -1485,9 +1491,14 @@ template <class R> struct Sim final : ISim {
         REQUIRE(action, "null action");
         return set_action(action);
     }
+    // The particle action in force (host copy) and, per frame, the one its forward substep ran with: a drift repair replays an epoch that may span
+    // several env steps, each with its own action (round 4: before, scenes with particle controllers reported a drifted epoch as an error)
+    std::vector<double> action_now;
+    std::vector<std::vector<double>> action_of_frame;
     int set_action(const double* action) {                                    // :579-592
         REQUIRE(D.n_control > 0, "action given but n_control == 0");
         REQUIRE(D.n_control <= 64, "n_control > 64");
+        action_now.assign(action, action + 3 * D.n_control);
         // the values travel in the kernel's argument block (copied at launch): no staging buffer whose lifetime a stream sync would have to guard
         SmallArgs<R, 3 * 64> a;
         for (int i = 0; i < 3 * D.n_control; ++i) a.v[i] = (R)action[i];
@@ -1641,6 +1652,10 @@ template <class R> struct Sim final : ISim {
         if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
+            if (D.n_control > 0) {                              // remember what this frame's substep runs with (repair_drift)
+                if ((int)action_of_frame.size() < cfg.max_frames) action_of_frame.resize(cfg.max_frames);
+                action_of_frame[f] = action_now;
+            }
             int e = frame_epoch[f];
             const int repairs_before = drift_repairs;
             if (e == 0 || f - epochs[e].frame >= epochs[e].interval || f < epochs[e].frame) {

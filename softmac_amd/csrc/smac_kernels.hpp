@@ -46,10 +46,6 @@ namespace smac {
 #ifndef SMAC_OCC_P2G
 #define SMAC_OCC_P2G 6
 #endif
-#ifndef SMAC_EXP
-#define SMAC_EXP 0               // round-4 experiments on the fused backward kernel (profiles/r04_j_phase_overlap.txt): 1 / 2 wave priority by phase, 3 staggered start
-#endif
-#define SMAC_PRIO(p) do { if (SMAC_EXP == 1) __builtin_amdgcn_s_setprio(p); else if (SMAC_EXP == 2) __builtin_amdgcn_s_setprio(3 - (p)); } while (0)
 #ifndef SMAC_PHASE_CLOCK
 #define SMAC_PHASE_CLOCK 0       // 1 (tools/phase_clock.sh only): 1 workgroup in 16 of the particle kernels files s_memtime at its phase boundaries
 #endif
@@ -1199,7 +1195,6 @@ __device__ __forceinline__ void g2p_grad_chunk(const DevSim<R>& D, const Chunk& 
     (void)fused_;
     tile_scale<R>(bound, smax, to_tile, from_tile);                                        // one barrier (all threads)
     SMAC_PHASE(6, valid && fused_);
-    SMAC_PRIO(3);                              // (LDS gather + scatter phase)
     if (valid) {
         Stencil<R> st;
         Nodes nd;
@@ -1868,7 +1863,6 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         stash[33 * BLOCK + t] = cs.Jm1;
     }
     SMAC_PHASE(2, KEEP);                       // rows loaded, forward constitutive model recomputed and parked
-    if (KEEP) SMAC_PRIO(3);                    // (LDS gather phase)
     R imp[3] = {R(0), R(0), R(0)};
     int ci = -1;
     if (D.n_control > 0) {
@@ -1979,7 +1973,6 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
     if (__all(all_in)) gather(std::false_type{});
     else gather(std::true_type{});
     SMAC_PHASE(3, KEEP);                       // 27-node gather of grid_v_in.grad
-    if (KEEP) SMAC_PRIO(0);                    // (constitutive adjoint: VALU phase)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         gvp[c] = M0[c];
@@ -2078,11 +2071,6 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? occ<R>::heavy : 1)) void k
     __shared__ Vec4<R> gtv[TILE_WORDS];         // grid_v_out of substep f - 1
     __shared__ R smax[4];
     SMAC_PHASE(10, true);
-    if (SMAC_EXP == 3 && blockIdx.x < 768u) {             // the first round of workgroups starts in three groups 3 us apart (phases of a CU's workgroups decorrelated)
-        const unsigned g = (blockIdx.x >> 8) % 3u;
-        if (g >= 1) __builtin_amdgcn_s_sleep(100);
-        if (g >= 2) __builtin_amdgcn_s_sleep(100);
-    }
     SMAC_CHUNK_PROLOGUE
     SMAC_PHASE(11, ch.count >= 0);
     W* const tile = (W*)tile_raw;

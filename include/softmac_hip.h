@@ -193,7 +193,8 @@ int smac_contact_counts(smac_handle h, int32_t* nhits, int32_t* nchunks_hit); /*
  *               culled per chunk first; same result) */
 int smac_set_param(smac_handle h, const char* name, double value);
 /* reads a parameter back; also "drift_repairs": how many times an epoch was recomputed because a particle out-ran its binning (no reference
- * counterpart: the reference's dense grid has no binning) */
+ * counterpart: the reference's dense grid has no binning); "contact_skips": backward substeps that launched no contact adjoint because the hit list
+ * filed with the frame's grid checkpoint was empty */
 int smac_get_param(smac_handle h, const char* name, double* value);
 
 /* ---- cloth primitive: replaces soft_cloth/engine/primitive/primitive_cloth.py (Primitive_Cloth) and the contact bookkeeping of

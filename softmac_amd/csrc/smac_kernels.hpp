@@ -125,6 +125,7 @@ template <class R> struct DevSim {
     Vec4<R>* save_ck;
     struct Hit* save_hits;
     int* save_nhits;
+    int* save_nhits_host;
     int save_hit_cap;
     int save_blocks;
     // One byte per active slot of the frame whose checkpoint this launch files or restores (nullptr: off): 1 = the block held no mass - {m,p} all zero,
@@ -518,11 +519,16 @@ template <class R>
 __device__ __forceinline__ void grid_save_block(const DevSim<R>& D, int nblocks, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
     if (hit_ck) {
         int nh = *D.nhits;
+        bool fits = true;
         if (nh > hit_cap) {                  // more particles in contact bands than a checkpoint slot holds: never truncated silently - the host is
             if (blockIdx.x == 0 && threadIdx.x == 0) D.drift_flag[1] = 1;      // told (second flag word) and substep_grad repeats the band test instead
             nh = 0;
+            fits = false;
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) *nhit_ck = nh;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *nhit_ck = nh;
+            if (D.save_nhits_host) *D.save_nhits_host = fits ? nh : -1;  // (pinned host memory: substep_grad skips the contact adjoint of a frame without hits)
+        }
         for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nh; i += nblocks * BLOCK) hit_ck[i] = D.hits[i];
     }
     const int a = active_slot(D);

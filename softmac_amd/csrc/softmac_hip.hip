@@ -216,6 +216,11 @@ template <class R> struct Sim final : ISim {
     Hit* ck_hits = nullptr;          // per frame: the contact hit list of that substep (capacity ck_hit_cap), with its length
     int ck_hit_cap = 0;
     int* ck_nhits = nullptr;
+    // pinned, device-visible: the hit count filed with each frame's checkpoint, written by the saving launch (-1: unknown).  substep_grad reads it after
+    // the synchronisation every backward pass starts with: a frame whose list is empty needs no contact adjoint launch (20 us of fixed latency).
+    int* h_nhits = nullptr;
+    int hits_from_ck_frame = -1;         // frame whose hit list the current substep_grad call took from the checkpoint (copied or in place)
+    int contact_skips = 0;               // contact adjoint launches saved that way (smac_get_param "contact_skips")
     unsigned char* ck_empty = nullptr;   // [frame][active slot]: the block held no mass and nothing was filed for it (DevSim::ck_flags)
     int ck_skip_empty = getenv("SMAC_CK_SKIP_EMPTY") ? atoi(getenv("SMAC_CK_SKIP_EMPTY")) : 1;
     // the flags of frame f for the backward grid pass: only while the frame's checkpoint (and with it the flags) is the one this epoch filed
@@ -271,6 +276,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
         hipFree(d_mat_id);
         hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
+        if (h_nhits) hipHostFree(h_nhits);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
             if ((void*)prim_tables64[i][0] != (void*)prim_tables[i][0]) { hipFree(prim_tables64[i][0]); hipFree(prim_tables64[i][1]); }
             hipFree(prim_tables[i][0]); hipFree(prim_tables[i][1]);
@@ -393,6 +399,8 @@ template <class R> struct Sim final : ISim {
         // [0]: a particle out-ran its binning; [1]: a contact hit list did not fit its checkpoint slot; [2]: a particle left its slab's shared planes
         HIP_TRY(hipMalloc((void**)&d_drift, 4 * sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_drift, 0, 4 * sizeof(int), stream));
+        HIP_TRY(hipHostMalloc((void**)&h_nhits, (size_t)c.max_frames * sizeof(int), hipHostMallocDefault));
+        for (int i = 0; i < c.max_frames; ++i) h_nhits[i] = -1;
         D.slab_base_lo = 1; D.slab_base_hi = 0;                        // no slab range check until smac_comm_slab / smac_set_slab_range says so
         D.drift_flag = d_drift;
         epochs.clear();
@@ -1264,6 +1272,7 @@ template <class R> struct Sim final : ISim {
         if (!strcmp(name, "drift_repairs")) *value = (double)drift_repairs;             // epochs recomputed because a particle out-ran its binning
         else if (!strcmp(name, "cloth_hash_entries")) *value = hash_total_host ? (double)*hash_total_host : 0.0;   // (face, block) pairs of the last broad-phase build
         else if (!strcmp(name, "exchanges")) *value = (double)exchanges_done;          // halo exchanges run by smac_substeps_slab[_grad] so far
+        else if (!strcmp(name, "contact_skips")) *value = (double)contact_skips;        // backward substeps that needed no contact adjoint launch (empty filed hit list)
         else if (!strcmp(name, "hit_overflows")) *value = (double)hit_overflows;      // times a contact hit list did not fit its checkpoint slot (backward then repeats the band test)
         else if (!strcmp(name, "plasticity")) *value = (double)D.mat.plast;
         else if (!strcmp(name, "yield_ratio")) *value = (double)D.mat.yield_c;
@@ -1685,10 +1694,12 @@ template <class R> struct Sim final : ISim {
             const bool save_in_g2p = save && save_in_g2p_env;                              // the save rides in k_g2p's launch (SMAC_SAVE_IN_G2P=0: own kernel)
             if (save) {
                 ck_has_hits[f] = keep_hits ? 1 : 0;
+                h_nhits[f] = -1;                                   // (unknown until the saving launch has run)
                 if (!save_in_g2p) {
                     prof_begin(K_CKPT);
                     DevSim<R> Ds = D;
                     Ds.ck_flags = ck_flags_of(f);
+                    Ds.save_nhits_host = keep_hits ? h_nhits + f : nullptr;
                     hipLaunchKernelGGL(k_grid_save<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Ds, ck_slot(f),
                                        keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr, keep_hits ? ck_nhits + f : (int*)nullptr, ck_hit_cap);
                     prof_end();
@@ -1706,6 +1717,7 @@ template <class R> struct Sim final : ISim {
                     Dg.save_ck = ck_slot(f);
                     Dg.save_hits = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
                     Dg.save_nhits = keep_hits ? ck_nhits + f : (int*)nullptr;
+                    Dg.save_nhits_host = keep_hits ? h_nhits + f : nullptr;
                     Dg.save_hit_cap = ck_hit_cap;
                     Dg.ck_flags = ck_flags_of(f);
                     Dg.save_blocks = (ngrid_blocks() + 7) & ~7;                              // (a multiple of 8: the chunk -> XCD dealing of the g2p part stays aligned)
@@ -1845,6 +1857,7 @@ template <class R> struct Sim final : ISim {
                 hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr);
             prof_end();
         } else if (phase <= 0) {
+            hits_from_ck_frame = -1;
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
             if ((rc = stage_ext_f_grad(ext_f_grad))) return rc;                   // :342-344
@@ -1882,6 +1895,7 @@ template <class R> struct Sim final : ISim {
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dk, (const Vec4<R>*)ck_slot(f),
                                    have_hits ? (const Hit*)(ck_hits + (size_t)f * ck_hit_cap) : (const Hit*)nullptr,
                                    have_hits ? (const int*)(ck_nhits + f) : (const int*)nullptr, fused_grid_bwd(phase) ? 0 : 1);
+                if (have_hits) hits_from_ck_frame = f;
                 if (D.any_contact && D.collision_type != CONTACT_GRID && !have_hits) {
                     if (D.cloth.present) hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
                     else hipLaunchKernelGGL(k_contact_mask<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D, f);
@@ -1908,7 +1922,10 @@ template <class R> struct Sim final : ISim {
                 prof_end();
             }
         }
-        if ((phase < 0 || phase == 1) && D.nchunks > 0 && D.collision_type == CONTACT_MIXED && any_contact()) {   // :362-363, 389-393
+        if (hits_in_place_frame == f) hits_from_ck_frame = f;
+        const bool no_hits = hits_from_ck_frame == f && h_nhits[f] == 0;        // the frame's filed hit list is empty: nothing to reverse
+        if (no_hits && (phase < 0 || phase == 1)) ++contact_skips;
+        if ((phase < 0 || phase == 1) && D.nchunks > 0 && D.collision_type == CONTACT_MIXED && any_contact() && !no_hits) {   // :362-363, 389-393
             prof_begin(K_CONTACT_GRAD);
             DevSim<R> Dc = D;
             if (hits_in_place_frame == f) {                // (restored ahead: the hit list was not copied out of the checkpoint)
@@ -1956,6 +1973,7 @@ template <class R> struct Sim final : ISim {
                                        have_hits ? (const int*)(ck_nhits + (f - 1)) : (const int*)nullptr, 0);
                     prof_end();
                     hits_in_place_frame = -1;
+                    hits_from_ck_frame = have_hits ? f - 1 : -1;
                 }
                 DevSim<R> D2 = D;
                 D2.Af_prev = Af_prev;

@@ -177,6 +177,27 @@ def test_grip_fixture_forecast_contact(precision):
     _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg)
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_a_primitive_out_of_reach_costs_no_contact_adjoint_launch(batched, monkeypatch):
+    """Round 4: the hit count of every frame is filed with its grid checkpoint and copied to pinned host memory by the saving launch; substep_grad does
+    not launch the contact adjoint (20 us of fixed latency: a chain of dependent loads, however few the hits) for a frame whose list is empty.  Same
+    result as the oracle, whose contact pass finds nothing either."""
+    state = np.load(H.GOLDEN / "grip_state_2k.npz")["state"]
+    specs, pstates = _palm_scene(state, 8)
+    for f in range(len(pstates)):
+        pstates[f][0] = pstates[f][0].copy()
+        pstates[f][0][1] += 0.2                                  # lifted clear of the block: no particle inside the contact band
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, material_model=0, ground_friction=20.0, precision="float32", sort_interval=4)
+    seen = {}
+    real = H.build_engine
+    def build(*a, **k):
+        seen["sim"], prims = real(*a, **k)
+        return seen["sim"], prims
+    monkeypatch.setattr(H, "build_engine", build)
+    _compare_rollout(cfg, 2e-3, state, 7, specs, pstates, ext_f_grad=[np.full(6, 1e-2)], batched=batched, expect_fused=True if batched else None)
+    assert seen["sim"].get_param("contact_skips") == 7
+
+
 @pytest.mark.parametrize("precision", ["float64", "float32"])
 @pytest.mark.parametrize("scene", ["plastic_cloud", "grip_contact", "grip_contact_golden"])
 def test_batched_sweep_against_the_oracle(scene, precision):

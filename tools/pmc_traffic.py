@@ -17,7 +17,9 @@ NAMES = {"k_p2g<float, true, false>": "p2g", "k_p2g_grad<float, false, true>": "
          "k_grid_save<float>": "grid_checkpoint", "k_p2g_g2p_grad<float, false>": "p2g_g2p_grad", "k_reduce_grid_grad<float>": "reduce_agvout",
          "k_contact_hits<float, false>": "contact", "k_contact_grad<float, true, false>": "contact_grad", "k_grid_restore<float>": "grid_restore",
          # round 3: the checkpoint save rides in k_g2p's launch, the next restore in the grid-adjoint reduction's
-         "k_g2p<float, false>": "g2p", "k_g2p<float, true>": "g2p", "k_reduce_grid_grad_ahead<float>": "reduce_agvout"}
+         "k_g2p<float, false>": "g2p", "k_g2p<float, true>": "g2p", "k_reduce_grid_grad_ahead<float>": "reduce_agvout",
+         # round 4: the two-entry material table added a template parameter (false = one material, the benchmarked instantiations)
+         "k_p2g<float, true, false, false>": "p2g", "k_p2g_grad<float, false, true, false>": "p2g_grad"}
 
 
 def mean_by_kernel(path, counter):
@@ -40,7 +42,7 @@ for k, short in NAMES.items():
 import hashlib, os, subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha1()
-for name in ("smac_kernels.hpp", "smac_math.hpp", "smac_sort.hpp"):
+for name in ("smac_kernels.hpp", "smac_math.hpp", "smac_sort.hpp", "softmac_hip.hip", "smac_cloth.hpp", "smac_cloth_kernels.hpp", "smac_migrate.hpp", "smac_comm.hpp"):   # = bench.py:kernel_sources_sha1
     h.update(open(os.path.join(root, "softmac_amd", "csrc", name), "rb").read())
 out["kernel_sources_sha1"] = h.hexdigest()
 try:

@@ -120,7 +120,7 @@ template <class R> struct DevSim {
                                       // (a particle beyond them would scatter onto planes nobody exchanges: flagged by k_g2p, drift_flag[2]); lo > hi: no check
     const int* block_active;     // dense per-block flag of the current epoch (halo packing)
     const int* block_slot;       // dense per block: its slot in the active list of the current epoch (valid where block_active)
-    // k_g2p<R, true>: the frame's checkpoint save ([active slot][vin | vmix | vout][64 cells], DESIGN 6) rides in the same launch (its first
+    // k_g2p<R, true>: the frame's checkpoint save ([active slot][vin | vmix | vout][64 cells], DESIGN 4) rides in the same launch (its first
     // `save_blocks` workgroups, a multiple of 8)
     Vec4<R>* save_ck;
     struct Hit* save_hits;

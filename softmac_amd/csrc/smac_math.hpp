@@ -26,7 +26,7 @@
 // SMAC_PRECISE=1: the SVD, the constitutive update and its adjoint keep their operation order and exact reciprocals inside the
 // -ffast-math build (`#pragma clang fp`; `#pragma float_control` is not supported on amdgcn).  Measured (tools/prec_probe.py):
 // it only matters for particles inside the reference's backward_svd clamp, whose gradient is ill-conditioned in any case
-// (DESIGN 3), and costs 11 % more instructions in k_p2g_grad - off by default.
+// (profiles/HISTORY.md 3), and costs 11 % more instructions in k_p2g_grad - off by default.
 #if defined(__clang__) && defined(SMAC_PRECISE) && SMAC_PRECISE
 #define SMAC_PRECISE_FP _Pragma("clang fp reassociate(off) reciprocal(off)")
 #else

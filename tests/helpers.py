@@ -78,7 +78,7 @@ def rel_err(a, b):
 #   clamp  : particles that enter the reference's backward_svd clamp (|s_j^2 - s_i^2| < 1e-6, mpm_simulator.py:184-192) at some
 #            frame of the window.  There K = 1e6 multiplies the singular-value difference itself, so rounding F to float32
 #            (3e-10) moves the REFERENCE's own f64 gradient of that particle by 1e-4 ... 2e-3, while a particle just outside the
-#            clamp moves by 1e-9 (measured) - no float32-storage implementation can do better; they are bounded separately.
+#            clamp moves by 1e-9 (measured, profiles/HISTORY.md 3) - no float32-storage implementation can do better; they are bounded separately.
 #   near   : particles whose stencil shares a grid node with a clamp-zone particle's in a frame where it is in the zone.  Over a multi-substep
 #            window the zone particle's ill-conditioned adjoint reaches them through the grid, attenuated: on the grip fixture particle 79
 #            (gap 3.3e-7) is off by 3.1e-5 / 4.5e-5 in two builds of the same source and its neighbours 1878, 521 by 8.9e-6 / 1.3e-5 - the

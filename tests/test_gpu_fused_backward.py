@@ -54,7 +54,7 @@ def _rollout(fused, n_sub, seeds, sort_interval, batched=True, n=1 << 16, grid=6
     sim.profile(False)
     if want_zone:
         # particles inside the reference's SVD-adjoint clamp at some frame of the window, and their grid neighbours (helpers.F32_TOL): their
-        # adjoints are ill-conditioned by construction (1e-4 for 3e-10 of input noise in f64 arithmetic), so two runs of the SAME
+        # adjoints are ill-conditioned by construction (1e-4 for 3e-10 of input noise in f64 arithmetic, DESIGN 3 / profiles/HISTORY.md 3), so two runs of the SAME
         # path differ there by more than anywhere else; they are bounded separately, as everywhere in the parity suite
         st = [sim.get_state(f) for f in range(n_sub)]
         shim = types.SimpleNamespace(frames=[tuple(torch.as_tensor(a) for a in (s[:, 0:3], s[:, 3:6], s[:, 15:24].reshape(N, 3, 3), s[:, 6:15].reshape(N, 3, 3)))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of several builds of libsoftmac_hip.so, 3 interleaved rounds (the particle kernels are bimodal PER PROCESS): prints per
+# A/B of several builds of libsoftmac_hip.so, 3 interleaved rounds (the particle kernels are bimodal PER PROCESS, profiles/HISTORY.md 7): prints per
 # variant the best substeps/s and the per-kernel minima over its runs.   tools/ab3.sh out_dir label=lib.so[,ENV=V...] ...
 O=$1; shift
 mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # like ab3.sh, but prints EVERY run (value and the per-kernel times that are bimodal per process) - for variants whose point is to be
-# insensitive to the fast/slow mode of DESIGN 7.   tools/ab_runs.sh out_dir rounds label=lib.so[,ENV=V...] ...
+# insensitive to the fast/slow mode of profiles/HISTORY.md 7.   tools/ab_runs.sh out_dir rounds label=lib.so[,ENV=V...] ...
 O=$1; R=$2; shift 2
 mkdir -p $O
 for round in $(seq 1 $R); do

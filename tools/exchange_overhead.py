@@ -1,4 +1,4 @@
-"""What the slab loop costs per substep pair BEFORE any byte crosses a link, on one GPU at the bench's size (DESIGN 8):
+"""What the slab loop costs per substep pair BEFORE any byte crosses a link, on one GPU at the bench's size (DESIGN 7):
 
   batched C loop          smac_substeps / smac_substeps_grad, no slabs                                      (the single-GPU path)
   python phase loop       parallel.SlabRunner: 3 phase calls + pack / unpack per side from Python, communication faked     (round 2's slab loop)

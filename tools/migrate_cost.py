@@ -1,4 +1,4 @@
-"""What one particle migration costs on the device (smac_migrate, DESIGN 8) at the bench's size, against the host path of round 2
+"""What one particle migration costs on the device (smac_migrate, DESIGN 7) at the bench's size, against the host path of round 2
 (SlabRunner.migrate: get_state of the slab frame, numpy masks, set_state).  One GPU, world-1 self exchange: the particles that leave on one side
 re-enter on the other, so rows and ids really cross RCCL as bytes."""
 import sys, time, pathlib

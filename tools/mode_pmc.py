@@ -1,4 +1,4 @@
-"""One process of the fast/slow-mode study of k_g2p: builds the bench scene, runs a few forward substeps and prints the
+"""One process of the fast/slow-mode study of k_g2p (profiles/HISTORY.md 7): builds the bench scene, runs a few forward substeps and prints the
 mean k_g2p time measured with HIP events (run under `rocprofv3 --pmc ...` the kernel trace carries durations and counters too)."""
 import sys, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))

@@ -22,11 +22,34 @@ import numpy as np
 
 
 class WindowedEpisode:
-    def __init__(self, sim, window, prim_state=None):
+    """`particle_action(e)` (optional; control_mode "mpm", the door demo's controller - mpm_simulator.py:208-213, 579-602): the (n_control, 3) action
+    held over env step e (substeps e n .. e n + n - 1, n = sim.substeps, as TaichiEnv.step holds it: taichi_env.py:99-102).  backward() then also returns
+    {e: action.grad summed over the env step's substeps} - what TaichiEnv.step_grad accumulates (taichi_env.py:128-133)."""
+
+    def __init__(self, sim, window, prim_state=None, particle_action=None):
         assert window >= 1 and window % max(sim.substeps, 1) == 0, "window must be a multiple of the env step's substeps"
-        self.sim, self.K, self.prim_state = sim, int(window), prim_state
+        self.sim, self.K, self.prim_state, self.particle_action = sim, int(window), prim_state, particle_action
         self.windows = []                     # substeps of each simulated window (all K except possibly the last)
         assert sim.max_steps >= self.K + 3, "the handle needs window + 1 working frames and at least two filed ones"
+        assert particle_action is None or sim.n_control > 0, "particle actions need a handle with n_control > 0"
+
+    def _run(self, t0, n):
+        """substeps t0 .. t0 + n - 1 of the episode, in slots 0 .. n"""
+        if self.particle_action is None:
+            self.sim.run_substeps(0, n)
+            return
+        m = max(self.sim.substeps, 1)
+        for j in range(0, n, m):                            # one batched call per env step: the action is constant inside it
+            self.sim.run_substeps(j, min(m, n - j), self.particle_action((t0 + j) // m))
+
+    def _run_grad(self, t0, n, action_grads):
+        if self.particle_action is None:
+            self.sim.run_substeps_grad(0, n)
+            return
+        m = max(self.sim.substeps, 1)
+        for j in range(((n - 1) // m) * m, -1, -m):
+            e = (t0 + j) // m
+            action_grads[e] = self.sim.run_substeps_grad(j, min(m, n - j), action=self.particle_action(e))
 
     # ---- helpers
     def _file_slot(self, w):
@@ -61,7 +84,7 @@ class WindowedEpisode:
                 self.sim.copyframe(self.K, 0)              # (the previous window was a full one)
             self.sim.copyframe(0, self._file_slot(w))
             self._upload_primitives(w * self.K, n)
-            self.sim.run_substeps(0, n)
+            self._run(w * self.K, n)
             self.windows.append(n)
             left -= n
         return self.end_slot
@@ -77,15 +100,16 @@ class WindowedEpisode:
         """seeds: {logical frame t: dict(gx=, gv=, gF=, gC=)} (any subset).  seed_fn(t0, n) (optional) is called once per window, after its frames
         [t0, t0 + n] have been recomputed into slots 0 .. n and before they are reversed: a loss evaluated on the device adds its gradients there
         (e.g. `smac_loss_chamfer(slot, add_grad=1)` through engine/losses: logical frame t lives in slot t - t0).  Returns (adjoint of frame 0 as
-        (gx, gv, gF, gC), {t: [13-vector per primitive]} adjoints of the prescribed primitive states of every frame)."""
+        (gx, gv, gF, gC), {t: [13-vector per primitive]} adjoints of the prescribed primitive states of every frame) and, with particle actions,
+        {env step: action gradient} as a third value."""
         sim, K = self.sim, self.K
         carried = False
-        prim_grads = {}
+        prim_grads, action_grads = {}, {}
         for w in range(len(self.windows) - 1, -1, -1):
             n, t0 = self.windows[w], w * K
             sim.copyframe(self._file_slot(w), 0)
             self._upload_primitives(t0, n)
-            sim.run_substeps(0, n)                          # recompute: states, grid checkpoints and hit lists of this window
+            self._run(t0, n)                                # recompute: states, grid checkpoints and hit lists of this window
             if carried:
                 sim.carry_grad(0, n)                        # the adjoint the later window left on its first frame seeds this window's last (on the device)
             else:
@@ -95,11 +119,13 @@ class WindowedEpisode:
                     sim.add_grad(t - t0, **g)
             if seed_fn is not None:
                 seed_fn(t0, n)
-            sim.run_substeps_grad(0, n)
+            self._run_grad(t0, n, action_grads)
             carried = True
             pg = [m.get_states_grad_trajectory(0, n) for m in sim.primitives]
             for j in range(n):
                 prim_grads[t0 + j] = [g[j] for g in pg]
+        if self.particle_action is not None:
+            return sim.get_grad_full(0), prim_grads, action_grads
         return sim.get_grad_full(0), prim_grads
 
 

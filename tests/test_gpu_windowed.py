@@ -75,6 +75,35 @@ def test_windowed_episode_needs_few_frames():
         ep2.forward(90)                                # six windows: one filed frame too many for this handle
 
 
+def test_windowed_episode_with_particle_actions_equals_the_oracle():
+    """control_mode "mpm" (the door demo's particle controllers, mpm_simulator.py:208-213): a different action per env step, held over its substeps;
+    three windows of two env steps each.  States and the adjoint of frame 0 against the oracle's resident rollout, the action gradient of every env
+    step against the oracle's per-substep action gradients summed over the env step (taichi_env.py:130-133)."""
+    n_grid, N, m, T, K = 32, 2000, 2, 12, 4               # env step = 2 substeps; windows of 4 substeps
+    cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, material_model=0, ground_friction=0.0, n_controllers=2, precision="float64", max_steps=K + 1 + 4)
+    env_dt = m * cfg.dt
+    state = H.make_cloud(N, n_grid, seed=21)
+    rng = np.random.default_rng(8)
+    idx = rng.integers(-1, 2, N)
+    acts = [rng.standard_normal((2, 3)) for _ in range(T // m)]
+    per_substep = [acts[t // m] for t in range(T)]
+    orc = H.OracleRollout(H.oracle_params(cfg, env_dt), state, control_idx=idx).forward(T, per_substep)
+    seeds = {T: (rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), None, None), 5: (rng.standard_normal((N, 3)), None, None, None)}
+    adj, _, ag = orc.backward(seeds, None, per_substep)
+    sim, _ = H.build_engine(cfg, env_dt)
+    sim.set_control_idx(np.asarray(idx, dtype=np.int32))
+    ep = WindowedEpisode(sim, K, particle_action=lambda e: acts[e])
+    ep.reset(state)
+    ep.forward(T)
+    assert ep.windows == [4, 4, 4]
+    assert H.rel_err(ep.get_state()[:, :3], orc.frames[T][0].numpy()) < 1e-9
+    got, _, got_ag = ep.backward({T: dict(gx=seeds[T][0], gv=seeds[T][1]), 5: dict(gx=seeds[5][0])})
+    assert H.rel_err(got[0], adj[0][0].numpy()) < 1e-8 and H.rel_err(got[1], adj[0][1].numpy()) < 1e-8
+    want_ag = np.array([np.sum(ag[e * m:(e + 1) * m], axis=0) for e in range(T // m)])
+    assert sorted(got_ag) == list(range(T // m))
+    assert H.rel_err(np.array([got_ag[e] for e in range(T // m)]), want_ag) < 1e-8
+
+
 @pytest.mark.parametrize("precision,tol", [("float64", 1e-8), ("float32", H.F32_TOL["grad"])])      # (measured 2.6e-7: profiles/r04_g_f32_bounds.txt)
 def test_windowed_env_episode_equals_the_resident_env(precision, tol):
     """The reference's env loop (velocity-controlled palm pressing on a block, tests/test_gpu_env.py's scene): 6 env steps of 2 substeps in windows of 2

@@ -163,6 +163,13 @@ def test_device_side_migration_between_two_ranks_gpu(tmp_path, precision, ts, tg
 
 
 @pytest.mark.gpu
+def test_in_library_loop_and_migration_among_three_ranks_gpu(tmp_path):
+    """World 3 over the IPC link: rank 1 is a MIDDLE slab - two different peers, both slots of every pack / unpack-add in use, arrivals from both sides
+    in one migration - which neither the world-1 self exchange (both neighbours = this rank) nor the two-rank runs (one neighbour each) execute."""
+    _check_moving(_run_ranks("lib", "float64", tmp_path, 3, "moving", env={"SMAC_COMM_STUB": "2"}), 3, 1e-9, 1e-8)
+
+
+@pytest.mark.gpu
 def test_contact_exchange_shortcut_keeps_the_single_domain_result_gpu(tmp_path):
     """`parallel.contact_sides`: a boundary no primitive can reach skips the two contact exchanges.  The strong-scaling bench scene at
     262,144 particles cut in two at the block's centre (the fingers grip its x ends): both ranks drop them, contact still happens inside

@@ -48,37 +48,38 @@ def get_cfg_defaults():
     return C
 
 
-def make_cls_config(self, cfg=None, **kwargs):
-    _cfg = self.default_config()
-    if cfg is not None:
-        if isinstance(cfg, str):
-            _cfg.merge_from_file(cfg)
-        else:
-            _cfg.merge_from_other_cfg(cfg)
-    if len(kwargs) > 0:
-        _cfg.merge_from_list(sum(list(kwargs.items()), ()))
-    return _cfg
+def make_cls_config(owner, cfg=None, **overrides):
+    """a class's default config tree (`owner.default_config()`) with a file name or another tree, then keyword overrides, laid over it
+    (/root/reference/softmac/config/utils.py:4-13; the keyword form is `merge_from_list`'s flat key / value sequence)"""
+    tree = owner.default_config()
+    if isinstance(cfg, str):
+        tree.merge_from_file(cfg)
+    elif cfg is not None:
+        tree.merge_from_other_cfg(cfg)
+    if overrides:
+        flat = []
+        for key, value in overrides.items():
+            flat += [key, value]
+        tree.merge_from_list(flat)
+    return tree
 
 
 def purge_cfg(cfg):
-    target_key = cfg.get('TYPE', None)
-    removed = []
-    for k, v in cfg.items():
-        if isinstance(v, CfgNode):
-            if target_key is not None and (k != target_key):
-                removed.append(k)
-            else:
-                purge_cfg(v)
-    for k in removed:
-        del cfg[k]
+    """a node that names its variant in `TYPE` keeps, of its sub-trees, only the one of that name (utils.py:15-30); applied recursively"""
+    keep = cfg.get("TYPE", None)
+    for name in [k for k, v in cfg.items() if isinstance(v, CfgNode)]:
+        if keep is None or name == keep:
+            purge_cfg(cfg[name])
+        else:
+            del cfg[name]
 
 
 def load(path=None, opts=None):
+    """defaults <- yaml file <- flat option list, purged and frozen (utils.py:32-40)"""
     cfg = get_cfg_defaults()
-    if path is not None:
-        cfg.merge_from_file(path)
-    if opts is not None:
-        cfg.merge_from_list(opts)
+    for source, merge in ((path, cfg.merge_from_file), (opts, cfg.merge_from_list)):
+        if source is not None:
+            merge(source)
     purge_cfg(cfg)
     cfg.freeze()
     return cfg

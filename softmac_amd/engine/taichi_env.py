@@ -62,23 +62,27 @@ class TaichiEnv:
     def set_copy(self, is_copy: bool):
         self._is_copy = is_copy
 
-    def initialize(self):                                        # :64-73
-        self.primitives.initialize()
-        self.simulator.initialize()
-        self.rigid_simulator.initialize()
-        self.renderer.initialize()
-        if self.loss:
-            self.loss.initialize()
+    def _parts(self):
+        """what initialize / reset walk, in the reference's order (:64-82): primitives, particles, rigid bodies, renderer, loss"""
+        parts = [self.primitives, self.simulator, self.rigid_simulator, self.renderer]
+        return parts + ([self.loss] if self.loss else [])
+
+    def initialize(self):
+        for part in self._parts():
+            part.initialize()
         self.reset()
 
-    def reset(self):                                             # :75-82
-        self.primitives.reset()
-        self.simulator.reset(self.init_particles)
-        self.rigid_simulator.reset()
-        self.renderer.reset()
-        if self.loss:
-            self.loss.reset()
+    def reset(self):
+        for part in self._parts():
+            if part is self.simulator:
+                part.reset(self.init_particles)
+            else:
+                part.reset()
         self.action_list = []
+
+    def _route(self, action):
+        """(particle action, rigid action): an env's action drives either the particle controllers or the rigid bodies (:95-96)"""
+        return (action, None) if self.control_mode == "mpm" else (None, action)
 
     def render(self, f=None):
         return self.renderer.render()
@@ -86,8 +90,7 @@ class TaichiEnv:
     def step(self, action=None):                                 # :93-115
         start = 0 if self._is_copy else self.simulator.cur
         self.simulator.cur = start + self.substeps
-        mpm_action = action if self.control_mode == "mpm" else None
-        rigid_action = action if self.control_mode == "rigid" else None
+        mpm_action, rigid_action = self._route(action)
         self.action_list.append(action)
         self.simulator.run_substeps(start, self.substeps, mpm_action)    # one FFI call for the env step's substeps (:101-102)
         self.rigid_simulator.step(start // self.substeps, rigid_action)
@@ -98,8 +101,7 @@ class TaichiEnv:
     def step_grad(self, action=None):                            # :117-137
         start = self.simulator.cur
         self.simulator.cur = start - self.substeps
-        mpm_action = action if self.control_mode == "mpm" else None
-        rigid_action = action if self.control_mode == "rigid" else None
+        mpm_action, rigid_action = self._route(action)
         rigid_action_grad, ext_f_grad_list = self.rigid_simulator.step_grad(self.simulator.cur // self.substeps, rigid_action)
         # the reverse loop of :128-133 as ONE call: the library runs the env step's substeps back to back (no host round trip, no stream
         # sync per substep; in float32 it reverses substep f's P2G and substep f-1's G2P in one launch) and sums action.grad on the device

@@ -100,7 +100,10 @@ template <class R> struct DevSim {
     const int* active;
     int nactive;
     const int* orig_id;          // sorted slot -> original particle id
-    const R* An;                 // adjoint of frame f+1 in THIS epoch's particle order (A[f+1] or a re-ordered copy)
+    const R* An;                 // adjoint of frame f+1 in THIS epoch's particle order (A[f+1] or a re-ordered copy) ...
+    const int* An_map;           // ... or (round 4) A[f+1] as it lies, binned differently: particle p's rows are at An_map[p] (nullptr: at p).  The backward sweep
+                                 // crosses a re-sort through the sort's own destination map INSIDE the two kernels that read frame f+1's adjoint, instead of
+                                 // a gather pass over the whole frame first (k_gather_rows: 24 rows read + 24 written, 40-76 us per crossing)
     Vec4<R>* slab;               // [nchunks][TILE_WORDS] per-chunk tiles (P2G: {m,p} ; G2P adjoint: {grid_v_out.grad,0})
     struct Hit* hits;            // particles inside a contact band this frame (written by k_p2g)
     int* nhits;
@@ -1317,11 +1320,12 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
     if (valid) {
         const R* Sf = frame(D.S, f, D.Npad);
         const R* An = D.An;
+        const int pa = D.An_map ? D.An_map[p] : p;
         R gv1[3];
         load_pos(Sf, D.Npad, p, x);
-        load_vec(An, CX, 3, D.Npad, p, gx1);
-        load_vec(An, CV, 3, D.Npad, p, gv1);
-        load_vec(An, CC, 9, D.Npad, p, gC1);
+        load_vec(An, CX, 3, D.Npad, pa, gx1);
+        load_vec(An, CV, 3, D.Npad, pa, gv1);
+        load_vec(An, CC, 9, D.Npad, pa, gC1);
         const R four_inv_dx = R(4) * D.inv_dx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) gnv[c] = gv1[c] + D.dt * gx1[c];                        // x' = x + dt v'
@@ -1829,7 +1833,7 @@ template <class R> struct occ { static constexpr int heavy = sizeof(R) == 4 ? SM
 // (k_p2g_g2p_grad feeds them to the G2P adjoint of the substep before) - only with ACC_VCF = false, i.e. when frame f carried no seed.
 template <class R, bool ACC_VCF, bool PCON, bool KEEP, bool MAT2 = false>
 __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, const Chunk& ch, int p, int t, typename const_t<R>::type* stash, const Vec4<R>* gt,
-                                                  R* gx_o, R* gv_o, R* gC_o) {
+                                                  R* gx_o, R* gv_o, R* gC_o, int pa) {      // pa: where particle p's rows lie in D.An (p, or An_map[p])
     typedef typename const_t<R>::type CT;
     const R* Sf = frame(D.S, f, D.Npad);
     const R* An = D.An;
@@ -1846,7 +1850,7 @@ __device__ __forceinline__ void p2g_grad_particle(const DevSim<R>& D, int f, con
         load_vec(Sf, CF, 9, D.Npad, p, E);
         load_pos(Sf, D.Npad, p, x);
         load_vec(Sf, CV, 3, D.Npad, p, v);
-        load_vec(An, CF, 9, D.Npad, p, gFn);       // F.grad[f+1]: fetched with the rest
+        load_vec(An, CF, 9, D.Npad, pa, gFn);      // F.grad[f+1]: fetched with the rest
         ConstState<CT> cs;
         {
             CT Cc[9], Ec[9];
@@ -2059,7 +2063,7 @@ __global__ __launch_bounds__(BLOCK, occ<R>::heavy) void k_p2g_grad(DevSim<R> D, 
     gather_tile_load(D, D.ain, ch.block, gt);
     __syncthreads();
     if (!valid) return;
-    p2g_grad_particle<R, ACC_VCF, PCON, false, MAT2>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr);
+    p2g_grad_particle<R, ACC_VCF, PCON, false, MAT2>(D, f, ch, p, t, stash, gt, (R*)nullptr, (R*)nullptr, (R*)nullptr, D.An_map ? D.An_map[p] : p);
 }
 
 // k_p2g_grad of substep f and k_g2p_grad of substep f - 1 in one launch.  Between two re-sorts a particle keeps its chunk, and the adjoint of
@@ -2095,7 +2099,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? occ<R>::heavy : 1)) void k
     for (int c = 0; c < 9; ++c) gC1[c] = R(0);
     if (valid) {
         R gv[3];
-        p2g_grad_particle<R, false, true, true>(D, f, ch, p, t, stash, gt, gx, gv, gC1);
+        p2g_grad_particle<R, false, true, true>(D, f, ch, p, t, stash, gt, gx, gv, gC1, D.An_map ? D.An_map[p] : p);
         const R four_inv_dx = R(4) * D.inv_dx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) gnv[c] = gv[c] + D.dt * gx[c];                           // x' = x + dt v'

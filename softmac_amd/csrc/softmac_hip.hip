@@ -1163,6 +1163,25 @@ template <class R> struct Sim final : ISim {
         }
         return check_launch();
     }
+    // Where the rows of adjoint frame f lie for the particles of epoch `to`, when a table the epochs keep says so without scratch space: the destination
+    // map of the re-sort the sweep is crossing, `orig` (frame in identity order) or an inverse table.  The kernels that read frame f + 1's adjoint take
+    // such a map (DevSim::An_map) instead of a re-ordered copy of the frame.  *direct = false: no such table (two unrelated epochs: adjoint_in_order composes one).
+    int an_map_env = getenv("SMAC_AN_MAP") ? atoi(getenv("SMAC_AN_MAP")) : 1;
+    int adjoint_direct_map(int f, int to, const int** map, bool* direct) {
+        *map = nullptr;
+        *direct = true;
+        const int from = adj_epoch[f];
+        if (from < 0 || from == to) return SMAC_OK;                      // same order (all-zero frames have none)
+        if (!an_map_env) { *direct = false; return SMAC_OK; }
+        if (from > 0 && to > 0 && epochs[from].prev == to && epochs[from].prev_serial == epochs[to].serial && epochs[from].from_prev) *map = epochs[from].from_prev;
+        else if (from == 0) *map = epochs[to].orig;
+        else if (to == 0) {
+            int rc = ensure_inverse(from);
+            if (rc) return rc;
+            *map = epochs[from].inv;
+        } else *direct = false;
+        return SMAC_OK;
+    }
     // adjoint frame f re-ordered from its own epoch into epoch `to` -> tmp_frame (returns pointer to use)
     int adjoint_in_order(int f, int to, const R** out, R* dst = nullptr) {
         if (!dst) dst = tmp_frame;
@@ -1840,6 +1859,7 @@ template <class R> struct Sim final : ISim {
             if ((rc = stage_ext_f_grad(ext_f_grad))) return rc;
             D.Af = adj_ptr(f);
             D.An = adj_ptr(f + 1);                          // same epoch (can_fuse_prev): in this order already
+            D.An_map = nullptr;
             pending_adj_zero = g2p_done_paz;
             D.cur_frame = f;
             prof_begin(K_REDUCE);
@@ -1865,7 +1885,12 @@ template <class R> struct Sim final : ISim {
             // adjoint of frame f+1 in this epoch's particle order; adjoint of frame f must be in it too
             const R* An = nullptr;
             if (adj_epoch[f + 1] < 0 && (rc = adj_make_zero(f + 1))) return rc;  // no seed and no later substep: zero adjoint
-            if ((rc = adjoint_in_order(f + 1, e, &An))) return rc;
+            const int* An_map = nullptr;
+            bool direct = false;
+            if ((rc = adjoint_direct_map(f + 1, e, &An_map, &direct))) return rc;
+            if (direct) An = adj_ptr(f + 1);                                      // read in place, through the map where the binning differs
+            else if ((rc = adjoint_in_order(f + 1, e, &An))) return rc;
+            REQUIRE(An, kPoolMessage);
             if (adj_epoch[f] >= 0 && adj_epoch[f] != e) {                         // seeds stored in another order: convert in place
                 const R* tmp = nullptr;
                 R* dst = tmp_frame;
@@ -1882,6 +1907,7 @@ template <class R> struct Sim final : ISim {
             adj_epoch[f] = e;
             adj_stale[f] = 0;                                                     // write mode overwrites every row
             D.An = An;
+            D.An_map = An_map;
             const bool ck_ok = ck_arena && ck_epoch[f] == e && ck_gen[f] == config_gen && D.n_control == 0 && D.nchunks > 0;
             if (ck_ok) {
                 // forward grid of this frame is on file: restore it (and zero the grid adjoints) instead of recomputing

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, session Q (and S: with the composed map): the backward sweep crosses a re-sort through a map inside the kernels (SMAC_AN_MAP) instead of a gather pass - parity, then A/B
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04q; mkdir -p $O
+O=gpurun_out/r04s; mkdir -p $O
 timeout -k 10 1000 python3 -m pytest tests/test_gpu_fused_backward.py tests/test_gpu_parity.py tests/test_gpu_resort.py tests/test_gpu_long_rollout.py -x -q > $O/pytest.log 2>&1
 rc=$?; echo "pytest rc $rc"; tail -8 $O/pytest.log
 [ $rc -ne 0 ] && exit $rc

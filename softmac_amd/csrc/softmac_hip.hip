@@ -262,7 +262,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_bin_mask); hipFree(d_over_prefix); hipFree(d_vmax); hipFree(d_vmax_part);
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
         hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
-        hipFree(d_map); hipFree(d_cub); hipFree(tmp_frame); hipFree(tmp_frame2); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
+        hipFree(d_map); hipFree(d_map_an); hipFree(d_cub); hipFree(tmp_frame); hipFree(tmp_frame2); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
         hipFree(d_io); hipFree(ext_snap); hipFree(cloth_ext_snap);
         for (auto& m : migs) { hipFree(m.src_slot); hipFree(m.ids_old); }
@@ -1165,7 +1165,7 @@ template <class R> struct Sim final : ISim {
     }
     // Where the rows of adjoint frame f lie for the particles of epoch `to`, when a table the epochs keep says so without scratch space: the destination
     // map of the re-sort the sweep is crossing, `orig` (frame in identity order) or an inverse table.  The kernels that read frame f + 1's adjoint take
-    // such a map (DevSim::An_map) instead of a re-ordered copy of the frame.  *direct = false: no such table (two unrelated epochs: adjoint_in_order composes one).
+    // such a map (DevSim::An_map) instead of a re-ordered copy of the frame.  *direct = false: SMAC_AN_MAP=0 (adjoint_in_order gathers the frame as before).
     int an_map_env = getenv("SMAC_AN_MAP") ? atoi(getenv("SMAC_AN_MAP")) : 1;
     int adjoint_direct_map(int f, int to, const int** map, bool* direct) {
         *map = nullptr;
@@ -1179,9 +1179,19 @@ template <class R> struct Sim final : ISim {
             int rc = ensure_inverse(from);
             if (rc) return rc;
             *map = epochs[from].inv;
-        } else *direct = false;
+        } else {
+            // two epochs that do not follow one another (a seed stored under an earlier binning of the frame: the loss ran, then the window was simulated again):
+            // compose the map once (k_compose, 10 us) and let the kernels read through it - not a gather of the frame on top (44 us).  The composed map lives
+            // in scratch of its own: d_map is adjoint_in_order's.
+            int rc = ensure_inverse(from);
+            if (rc) return rc;
+            if (!d_map_an) HIP_TRY(hipMalloc((void**)&d_map_an, D.Npad * sizeof(int)));
+            hipLaunchKernelGGL(k_compose, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)epochs[to].orig, (const int*)epochs[from].inv, d_map_an);
+            *map = d_map_an;
+        }
         return SMAC_OK;
     }
+    int* d_map_an = nullptr;
     // adjoint frame f re-ordered from its own epoch into epoch `to` -> tmp_frame (returns pointer to use)
     int adjoint_in_order(int f, int to, const R** out, R* dst = nullptr) {
         if (!dst) dst = tmp_frame;

@@ -992,8 +992,9 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     int repair_drift(int f_end, int e_bad) {
-        // (the cloth variant is not replayed: its contact-face search and penetration tracing run on the host's schedule between the substeps)
-        if (repairing || bwd_since_fwd || slab_phase_used || D.cloth.present || e_bad <= 0 || !epochs[e_bad].live || !ext_snap)
+        // (the cloth variant: its contact-face search and penetration tracing run on the host's schedule between the substeps - the calls made on every
+        //  frame of the epoch are on file, cloth_ops_of_frame, and are made again on the recomputed frame; round 4)
+        if (repairing || bwd_since_fwd || slab_phase_used || e_bad <= 0 || !epochs[e_bad].live || !ext_snap || (D.cloth.present && !cloth_ext_snap))
             return SMAC_ERR_INVALID;
         const int fs = epochs[e_bad].frame;
         if (!(fs < f_end) || frame_epoch[fs] != e_bad) return SMAC_ERR_INVALID;
@@ -1005,6 +1006,8 @@ template <class R> struct Sim final : ISim {
         // replayed BEFORE that frame send their wrench sums to the scratch slot (as the backward recompute does); from that frame on they count.
         replay_count_from = snap_frame < fs ? fs : snap_frame;
         if (hipMemcpyAsync(D.ext_f, ext_snap, Pn * 6 * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) rc = SMAC_ERR_HIP;
+        if (D.cloth.present && hipMemcpyAsync(D.cloth.ext_f, cloth_ext_snap, (size_t)D.cloth.V * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+            rc = SMAC_ERR_HIP;
         const int keep = sort_interval;
         sort_interval = 1;
         epochs[e_bad].interval = 1;                          // frame fs keeps its (fresh) binning; every later frame is re-binned before it is used
@@ -1013,6 +1016,9 @@ template <class R> struct Sim final : ISim {
             // the action frame g's substep ran with (particle controllers); action.grad is a backward quantity and no backward substep has run since
             const bool has = D.n_control > 0 && g < (int)action_of_frame.size() && !action_of_frame[g].empty();
             rc = substep_phase(g, has ? action_of_frame[g].data() : nullptr, -1);
+            // the host's calls on the frame this substep produced, in their order (soft_cloth/engine/taichi_env.py:95-98: get_contact_pair, trace_penetration...)
+            if (!rc && D.cloth.present && g + 1 < (int)cloth_ops_of_frame.size())
+                for (size_t i = 0; i < cloth_ops_of_frame[g + 1].size() && !rc; ++i) rc = cloth_contact_run(cloth_ops_of_frame[g + 1][i], g + 1);
         }
         if (!rc && D.n_control > 0 && !action_keep.empty()) rc = set_action(action_keep.data());
         replay_count_from = -1;
@@ -1432,10 +1438,13 @@ template <class R> struct Sim final : ISim {
         const size_t b = (size_t)D.cloth.V * 3 * sizeof(double);
         if (op == 0) {
             REQUIRE(buf, "null argument");
+            if ((rc = check_drift())) return rc;                                      // a drifted epoch is repaired BEFORE the host consumes the sheet's force
             HIP_TRY(hipMemcpyAsync(buf, D.cloth.ext_f, b, hipMemcpyDeviceToHost, stream));
         } else if (op == 1) {
+            if (fwd_head >= 0 && !bwd_since_fwd && (rc = check_drift())) return rc;       // (repairs with the accumulator as the forward pass left it)
             HIP_TRY(hipMemsetAsync(D.cloth.ext_f, 0, b, stream));
             HIP_TRY(hipMemsetAsync(D.cloth.ext_f_grad, 0, b, stream));
+            if (ext_snap && fwd_head >= 0 && !repairing && (rc = snapshot_ext(fwd_head))) return rc;   // a later repair re-accumulates from here
         } else if (op == 2) {
             REQUIRE(buf, "null argument");
             HIP_TRY(hipMemcpyAsync(D.cloth.ext_f_grad, buf, b, hipMemcpyHostToDevice, stream));
@@ -1454,9 +1463,19 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     // 0: get_contact_pair :447-469; 1: backup_contact_pair :471-482; 2: trace_penetration_after_mpm :484-518; 3: ..._after_cloth :520-553
+    // the calls the host made on each frame since its last forward substep produced it (op codes, in order): what a drift repair makes again
+    std::vector<std::vector<signed char>> cloth_ops_of_frame;
     int cloth_contact(int op, int f) override {
         int rc;
         if ((rc = cloth_need()) || (rc = check_frame(f)) || (rc = check_drift())) return rc;
+        REQUIRE(op >= 0 && op <= 3, "cloth_contact: unknown op");
+        if ((int)cloth_ops_of_frame.size() < cfg.max_frames) cloth_ops_of_frame.resize(cfg.max_frames);
+        if (cloth_ops_of_frame[f].size() >= 16) cloth_ops_of_frame[f].erase(cloth_ops_of_frame[f].begin());   // (frame 0 is never produced by a substep: bounded)
+        cloth_ops_of_frame[f].push_back((signed char)op);
+        return cloth_contact_run(op, f);
+    }
+    int cloth_contact_run(int op, int f) {
+        int rc;
         REQUIRE(frame_epoch[f] >= 0, "cloth contact: frame holds no particle state");
         const ClothDev& C = D.cloth;
         const size_t at = (size_t)f * C.n_ids;
@@ -1502,6 +1521,7 @@ template <class R> struct Sim final : ISim {
         if (pen) HIP_TRY(hipMemcpyAsync(D.cloth.penetration + at, pen, (size_t)D.N, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         ck_epoch[f] = -1;
+        if (f < (int)cloth_ops_of_frame.size()) cloth_ops_of_frame[f].clear();      // (the host's values stand: a drift repair does not search this frame again)
         return SMAC_OK;
     }
     int cloth_check_penetration(int f, int32_t* total, int32_t* warnings) override {           // check_penetration :555-561
@@ -1586,7 +1606,7 @@ template <class R> struct Sim final : ISim {
         D.cur_frame = f;
         DevSim<R> Dc = D;                                       // the recompute pass must not double-count ext_f
         if (is_recompute || (repairing && f < replay_count_from)) Dc.ext_f = scratch_ext();
-        if (is_recompute && D.cloth.present) Dc.cloth.ext_f = d_cloth_ext_scratch;
+        if ((is_recompute || (repairing && f < replay_count_from)) && D.cloth.present) Dc.cloth.ext_f = d_cloth_ext_scratch;
         if (stage != 2) {
             // grid_op rewrites v_mixed / v_out of every active cell; {m,p} must start from zero (drifted particles add to
             // it atomically) and is left zeroed by the checkpoint save of the previous substep
@@ -1761,6 +1781,7 @@ template <class R> struct Sim final : ISim {
                 prof_end();
             }
             frame_epoch[f + 1] = e;
+            if (!repairing && f + 1 < (int)cloth_ops_of_frame.size()) cloth_ops_of_frame[f + 1].clear();   // a new frame f + 1: the host's calls on it start over
             fwd_head = f + 1;
             bwd_since_fwd = false;
             g2p_done_frame = -1;

@@ -21,6 +21,25 @@ from __future__ import annotations
 import numpy as np
 
 
+def loss_seeds(loss, frames):
+    """`seed_fn` for WindowedEpisode.backward / WindowedEnvEpisode.backward out of one of engine/losses' loss objects: the reference's
+
+        with ti.ad.Tape(loss=env.loss.loss):            # demo_pour.py:171-176
+            for f in frames: env.compute_loss(f)
+
+    evaluated window by window on the way back - a frame of the episode only exists (again) while its window is being reversed.  Logical frame t of the
+    window [t0, t0 + n] lives in slot t - t0; frame t0 belongs to the window before it (where it is slot n of that window), except frame 0.  The loss value
+    accumulates over the windows as it does over the reference's frames: read `loss.loss` after backward()."""
+    frames = sorted(int(t) for t in frames)
+
+    def seed(t0, n):
+        with loss.tape():
+            for t in frames:
+                if t0 < t <= t0 + n or (t == 0 and t0 == 0):
+                    loss.compute_loss(t - t0)
+    return seed
+
+
 class WindowedEpisode:
     """`particle_action(e)` (optional; control_mode "mpm", the door demo's controller - mpm_simulator.py:208-213, 579-602): the (n_control, 3) action
     held over env step e (substeps e n .. e n + n - 1, n = sim.substeps, as TaichiEnv.step holds it: taichi_env.py:99-102).  backward() then also returns
@@ -121,9 +140,11 @@ class WindowedEpisode:
                 seed_fn(t0, n)
             self._run_grad(t0, n, action_grads)
             carried = True
-            pg = [m.get_states_grad_trajectory(0, n) for m in sim.primitives]
-            for j in range(n):
-                prim_grads[t0 + j] = [g[j] for g in pg]
+            pg = [m.get_states_grad_trajectory(0, n + 1) for m in sim.primitives]
+            for j in range(n + 1):
+                # (slot n is the next window's slot 0: that window has filed the adjoint its substeps left on the frame, this one adds what a loss seeded on it)
+                row = [np.asarray(g[j], dtype=np.float64) for g in pg]
+                prim_grads[t0 + j] = [a + b for a, b in zip(prim_grads[t0 + j], row)] if (t0 + j) in prim_grads else row
         if self.particle_action is not None:
             return sim.get_grad_full(0), prim_grads, action_grads
         return sim.get_grad_full(0), prim_grads

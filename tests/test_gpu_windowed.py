@@ -75,6 +75,49 @@ def test_windowed_episode_needs_few_frames():
         ep2.forward(90)                                # six windows: one filed frame too many for this handle
 
 
+def test_windowed_episode_with_a_loss_tape_equals_the_resident_one():
+    """VERDICT r3 missing 5: the reference's episode is loss-seeded at many frames inside `with ti.ad.Tape(loss=...)` (demo_pour.py:171-176).  In a
+    windowed episode those frames only exist while their window is being reversed: `windowed.loss_seeds(loss, frames)` evaluates the loss there - chamfer
+    seeds on the device, pose / velocity penalties into the prescribed palm's state adjoint.  Loss value, the adjoint of frame 0 and the palm's state
+    adjoints against the resident episode with the same tape."""
+    import types
+    from softmac_amd.engine.losses import PourLoss
+    from softmac_amd.engine.windowed import loss_seeds
+    d = np.load(H.GOLDEN / "grip_state_2k.npz")
+    state = d["state"]
+    N, T, K = len(state), 15, 5                           # env step = 5 substeps; three windows
+    specs, pstates = _palm_scene(state, T + 1)
+    frames = [15, 10, 7, 5, 1]                            # the end, a window boundary, inside windows
+    target = state[:, :3] + np.array([0.02, -0.01, 0.015])
+    mk = lambda steps: H.sim_cfg(N, n_grid=64, dt=2e-4, ptype=0, material_model=0, ground_friction=20.0, precision="float64", max_steps=steps, sort_interval=4)
+
+    ref, prims = H.build_engine(mk(T + 2), 1e-3, specs, pstates)
+    lref = PourLoss(types.SimpleNamespace(weight=(1.5, 0.3, 0.2), target_path=None), ref)
+    lref.set_target(target); lref.initialize()
+    ref.reset(state)
+    ref.run_substeps(0, T)
+    ref.clear_grads()
+    with lref.tape():
+        for t in frames:
+            lref.compute_loss(t)
+    ref.run_substeps_grad(0, T)
+    want = ref.get_grad_full(0)
+    want_prim = np.array([prims[0].get_all_states_grad(t) for t in range(T)])
+
+    sim, _ = H.build_engine(mk(K + 1 + 5), 1e-3, specs, None)
+    lw = PourLoss(types.SimpleNamespace(weight=(1.5, 0.3, 0.2), target_path=None), sim)
+    lw.set_target(target); lw.initialize()
+    ep = WindowedEpisode(sim, K, prim_state=lambda t: pstates[t])
+    ep.reset(state)
+    ep.forward(T)
+    got, got_prim = ep.backward({}, seed_fn=loss_seeds(lw, frames))
+    assert abs(float(lw.loss) - float(lref.loss)) <= 1e-10 * abs(float(lref.loss)) and float(lref.loss) > 0
+    for name, a, b in zip(("gx", "gv", "gF", "gC"), got, want):
+        assert H.rel_err(a, b) < 1e-9, (name, H.rel_err(a, b))
+    scale = np.abs(want_prim).max()
+    assert scale > 0 and np.abs(np.array([got_prim[t][0] for t in range(T)]) - want_prim).max() / scale < 1e-8
+
+
 def test_windowed_episode_with_particle_actions_equals_the_oracle():
     """control_mode "mpm" (the door demo's particle controllers, mpm_simulator.py:208-213): a different action per env step, held over its substeps;
     three windows of two env steps each.  States and the adjoint of frame 0 against the oracle's resident rollout, the action gradient of every env

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -20,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LIB_SORT_INTERVAL = 40        # the library's default re-sort interval (softmac_hip.hip: smac_config.sort_interval = 0)
 
 
 def baseline_metric():
@@ -301,7 +303,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); spawned here when not already under torchrun")
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--repeats", type=int, default=3, help="the K-step window is timed this many times; the median is reported")
+    ap.add_argument("--repeats", type=int, default=0, help="number of K-step windows (0: window_plan - as many as give the re-sorts their steady-state share, at least 8)")
     ap.add_argument("--workload", default="s-grip", choices=["s-grip", "s-elastic"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the metric's one 1M-particle scene cut into N slabs; weak = N bars of 1M particles each")
@@ -314,7 +316,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-env-loop", action="store_true", help="skip the env_loop sub-record (the reference's TaichiEnv.step / backward loop on the same workload)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
-    ap.add_argument("--sort-interval", type=int, default=0, help="0: min(32, steps), so that every timed window holds a re-sort")
+    ap.add_argument("--sort-interval", type=int, default=0, help="0: the library's default")
     ap.add_argument("--slab-runner", default=os.environ.get("SMAC_SLAB_RUNNER", "python"), choices=["lib", "python"],
                     help="N > 1: python (default) = parallel.SlabRunner on torch.distributed (RCCL through torch); lib = smac_substeps_slab (RCCL inside "
                          "the library) - selectable, not the default, until it has run between two different ranks (it has only run as a world-1 self exchange)")
@@ -355,11 +357,29 @@ def launch_check(args, world, rank):
     dist.destroy_process_group()
 
 
-def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist):
-    """W warm-up substep pairs, then `repeats` windows of EXACTLY K forward + K backward substeps on frames [W, W+K).
-    Returns (per-window wall seconds after MAX over ranks, per-window device ms)."""
+def window_plan(K, interval):
+    """Windows of EXACTLY K substep pairs that advance through the episode, as many of them as it takes for the re-sorts inside them to have their
+    steady-state share: R * K is a multiple of the re-sort interval (so K = 20 at an interval of 40 alternates windows without and with a re-sort),
+    and R >= 8 so that the GPU's clocks have settled for most of them (the first two windows after a cold start run 5-8 % slower:
+    profiles/r04_z_first_pass.txt).  Every window is timed and counted - nothing is dropped, `value` comes from their sum."""
+    block = math.lcm(K, max(interval, 1)) // K
+    if block * K > 640:                                       # (an interval that shares no factor with K: fall back to whole windows, share approximate)
+        block = 1
+    return block * -(-8 // block)
+
+
+def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist, windows=None):
+    """W warm-up substep pairs, then R windows of EXACTLY K forward + K backward substeps; window r covers frames [W + r K, W + (r + 1) K) - the
+    episode goes on, it is not the same K frames again and again (frames that were simulated before keep their binning, an adjoint seed stored under
+    it and warm pages: profiles/r04_z_first_pass.txt).  The loss seed of a window is added INSIDE its timed region, after the forward pass, from a
+    buffer that is resident in HBM (smac_add_grad_device) - the reference's loss kernels write x.grad on the device after the forward pass too
+    (losses/loss_pour.py:130-140).  Returns (per-window wall seconds after MAX over ranks, per-window device ms)."""
+    import torch
     K, W = args.steps, args.warmup
+    R = windows or window_plan(K, args.sort_interval)
     env = max(sim.substeps, 1)
+    seed_dev = torch.from_numpy(np.ascontiguousarray(np.vstack([seed_gx, seed_gx[: max(len(seed_gx) // 4, 1) + 1024]]), dtype=np.float64)).to(f"cuda:{sim.device}")
+    torch.cuda.synchronize()
 
     M = getattr(args, "migrate_every", 0) if reducer is not None else 0
     segs = []                                                # (first frame, substeps) of the segments of the last forward pass; a migration between two of them
@@ -400,47 +420,43 @@ def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist):
         if reducer is not None:
             reducer.allreduce_state_grad(f0, f0 + n)
 
-    def seed(f_end):
-        sim.clear_grads()
-        n_now = sim.n_particles                              # (a migrating window ends with another particle count than it started with)
-        sim.add_grad(f_end, gx=seed_gx[:n_now] if n_now <= len(seed_gx) else np.vstack([seed_gx, seed_gx[:n_now - len(seed_gx)]]))
+    def seed(f_end):                                         # x.grad[f_end] += seed, device to device on the handle's stream
+        sim.add_grad_device(f_end, gx=seed_dev[: sim.n_particles])
 
-    seed(forward(0, W))
-    backward(0, W)
+    def pair(f0, n):                                         # one window: forward, the loss seed, backward
+        f_end = forward(f0, n)
+        seed(f_end)
+        backward(f0, n)
+        return f_end
+
+    sim.clear_grads()
+    pair(0, W)
     walls, devs = [], []
-    for _ in range(max(args.repeats, 1)):
+    f0 = W
+    starts = []
+    for _ in range(R):
+        sim.clear_grads()                                    # (ti.ad.clear_all_gradients() between episodes; outside the timed region as the reference's is outside its tape)
         for m in sim.primitives:
             m.clear_ext_f()
-        if M == 0:
-            seed(W + K)                                      # (without migrations the end frame is known before the window; the seed stays outside the timed region)
         barrier()
         t0 = time.perf_counter()
         sim.timer_start()
-        f_end = forward(W, K)
-        if M > 0:
-            seed(f_end)
-        backward(W, K)
+        f_end = pair(f0, K)
         dev_ms = sim.timer_stop()
         barrier()
         wall = time.perf_counter() - t0
         if dist is not None:
-            import torch
             t = torch.tensor([wall], device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         walls.append(wall)
         devs.append(dev_ms)
+        starts.append(f0)
+        f0 = f_end
     timed_windows.migrations = max(len(segs) - 1, 0)
     timed_windows.moved = int(getattr(run, "moved", 0))
-
-    def pair(f0, n):                                         # one window outside the timed region (profile pass): seed wherever the window ends
-        if M == 0:
-            seed(f0 + n)
-        f_end = forward(f0, n)
-        if M > 0:
-            seed(f_end)
-        backward(f0, n)
     timed_windows.pair = pair
+    timed_windows.starts = starts
     return walls, devs, forward, backward
 
 
@@ -457,16 +473,18 @@ def main():
     if args.launch_check:
         return launch_check(args, world, rank)
     if args.sort_interval <= 0:
-        args.sort_interval = min(32, max(args.steps, 1))
+        args.sort_interval = LIB_SORT_INTERVAL              # the library's default (smac_config.sort_interval = 0): what a caller of the engine gets
     dist = None
+    import torch
+    torch.cuda.init()           # torch's HIP runtime comes up BEFORE libsoftmac_hip loads the system's (the other order leaves torch without a device)
     if world > 1:
-        import torch
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("SMAC_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0))))
         # in-library runner: the data path's RCCL communicator lives in libsoftmac_hip; torch.distributed is the control plane only (gloo)
         dist.init_process_group(os.environ.get("SMAC_DIST_BACKEND", "gloo" if args.slab_runner == "lib" else "nccl"))      # "nccl" is RCCL on ROCm
 
-    sim, run, cfg = build_sim(args, rank, world)
+    R = args.repeats if args.repeats > 0 else window_plan(args.steps, args.sort_interval)
+    sim, run, cfg = build_sim(args, rank, world, frames=args.warmup + R * args.steps + 2)
     N_local, K, W = int(cfg.n_particles), args.steps, args.warmup
     N = args.particles
     sbytes = 4 if args.precision == "float32" else 8
@@ -485,7 +503,7 @@ def main():
             torch.cuda.synchronize()
 
     try:
-        walls, devs, forward, backward = timed_windows(args, sim, run, reducer, seed_gx, barrier, dist)
+        walls, devs, forward, backward = timed_windows(args, sim, run, reducer, seed_gx, barrier, dist, windows=R)
     except Exception as e:                                  # noqa: BLE001
         if world == 1:
             raise
@@ -500,31 +518,41 @@ def main():
             pass
         sys.stdout.flush()
         os._exit(1)
-    order = sorted(range(len(walls)), key=lambda i: walls[i])
-    mid = order[len(order) // 2]
-    wall, dev_ms = walls[mid], devs[mid]
+    # every window counts: K / (mean window time) - the windows without and with a re-sort in their steady-state proportion
+    wall, dev_ms = sum(walls) / len(walls), sum(devs) / len(devs)
     strong = world > 1 and args.scaling == "strong" and args.workload == "s-grip"
     value = (1 if (strong or world == 1) else world) * K / wall
 
-    # per-kernel HIP-event profile over one more identical pass (kept out of the timed region)
+    # per-kernel HIP-event profile over the same R windows once more (out of the timed region; the frames keep their binning, the launches are the same)
+    M_ = getattr(args, "migrate_every", 0) if reducer is not None else 0
+    again = timed_windows.starts if M_ == 0 else timed_windows.starts[-1:]      # (a migrated window cannot be replayed from its first frame's old segment)
     sim.profile(True)
-    timed_windows.pair(W, K)
+    for f0 in again:
+        sim.clear_grads()
+        timed_windows.pair(f0, K)
     prof = sim.profile_report()
     sim.profile(False)
-    # SURVEY 8(d) asks for the two directions separately as well: one more pass with a sync between them
+    prof_substeps = K * len(again)
+    # SURVEY 8(d) asks for the two directions separately as well: the same windows with a sync between the two directions
     split = None
     if world == 1:
-        sim.clear_grads()
-        sim.add_grad(W + K, gx=seed_gx)
-        barrier()
-        t0 = time.perf_counter()
-        forward(W, K)
-        barrier()
-        t1 = time.perf_counter()
-        backward(W, K)
-        barrier()
-        t2 = time.perf_counter()
-        split = (t1 - t0, t2 - t1)
+        import torch
+        sdev = torch.from_numpy(np.ascontiguousarray(seed_gx, dtype=np.float64)).to(f"cuda:{sim.device}")
+        torch.cuda.synchronize()
+        tf = tb = 0.0
+        for f0 in again:
+            sim.clear_grads()
+            barrier()
+            t0 = time.perf_counter()
+            forward(f0, K)
+            barrier()
+            t1 = time.perf_counter()
+            sim.add_grad_device(f0 + K, gx=sdev)
+            backward(f0, K)
+            barrier()
+            t2 = time.perf_counter()
+            tf, tb = tf + (t1 - t0) / len(again), tb + (t2 - t1) / len(again)
+        split = (tf, tb)
     G_t = sim.count_active_cells(W)
     n_hits, n_hit_chunks = sim.contact_counts()
     counts = [N_local, G_t, n_hits]
@@ -536,7 +564,7 @@ def main():
 
     if rank == 0:
         kern = {k: v for k, v in prof.items() if v[1] > 0}
-        per_step = {k: v[0] / K for k, v in kern.items()}                        # ms per substep pair, amortised (sort: 1 per interval)
+        per_step = {k: v[0] / prof_substeps for k, v in kern.items()}            # ms per substep pair, amortised (sort: 1 per interval)
         dom = max((k for k in kern if k not in ("sort", "reorder_adjoint")), key=lambda k: kern[k][0])
         avg_ms = kern[dom][0] / kern[dom][1]
         pp, pc = KERNEL_BYTES[dom]
@@ -585,7 +613,9 @@ def main():
                        "touched_cells": Gsum if world > 1 else G_t, "contact_particles": sum(c[2] for c in allc),
                        "backward": "forward grid recomputed in substep_grad (reference style)" if args.recompute_backward
                        else "forward grid restored from the per-frame checkpoint saved by substep",
-                       "resort_interval": args.sort_interval, "resorts_in_window": int(kern.get("sort", (0, 0))[1]),
+                       "resort_interval": args.sort_interval, "resorts_in_windows": int(kern.get("sort", (0, 0))[1]), "substeps_in_windows": prof_substeps,
+                       "windows": (f"{len(walls)} windows of exactly {K} substep pairs each, advancing through one episode (frames {W} .. {W + len(walls) * K}); "
+                                   "the loss seed is added from HBM inside each window; value = K / mean window time, no window dropped"),
                        "parallelism": par},
             "slab_runner": None if world == 1 else (getattr(run, "fallback_note", None) or (("in-library slab loop over the IPC test transport" if os.environ.get("SMAC_COMM_STUB") == "2" else "in-library RCCL loop") if args.slab_runner == "lib" else "Python SlabRunner")),
             "transport": None if world == 1 else ("IPC link between processes sharing GPUs (SMAC_COMM_STUB=2: a test transport, host-synchronous - NOT a scaling number)"
@@ -593,7 +623,7 @@ def main():
             "migrations_in_window": int(getattr(timed_windows, "migrations", 0)), "particles_migrated": int(getattr(timed_windows, "moved", 0)),
             "multi_gpu_note": None if world == 1 else ("no N > 1 run on N GPUs existed when this code was committed: the in-library slab loop has run between two ranks "
                                                          "over the IPC test transport on one GPU (tests/test_slabs.py) and as a world-1 RCCL self exchange"),
-            "repeats": len(walls), "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
+            "repeats": len(walls), "aggregate": "mean", "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
             "spread": (max(walls) - min(walls)) / wall,
             "device_ms_per_step": dev_ms / K,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -616,9 +646,11 @@ def main():
         sim._h.close()
         del sim
         a64 = argparse.Namespace(**vars(args))
-        a64.precision, a64.repeats = "float64", 1
-        sim, run, cfg = build_sim(a64, rank, world)
-        w64, d64, _, _ = timed_windows(a64, sim, run, None, seed_gx, lambda: sim.sync(), None)
+        a64.precision = "float64"
+        R64 = math.lcm(K, args.sort_interval) // K if math.lcm(K, args.sort_interval) <= 640 else 1      # one block of windows with the re-sorts' share
+        sim, run, cfg = build_sim(a64, rank, world, frames=W + R64 * K + 2)
+        w64, d64, _, _ = timed_windows(a64, sim, run, None, seed_gx, lambda: sim.sync(), None, windows=R64)
+        w64, d64 = [sum(w64) / len(w64)], [sum(d64) / len(d64)]
         out["f64"] = {"value": K / w64[0], "unit": "substeps/s", "ms_per_step": 1e3 * w64[0] / K, "device_ms_per_step": d64[0] / K,
                       "dtype": "f64", "note": "same workload, arithmetic and storage in float64 (parity 1e-9 state / 1e-8 gradients)"}
     if world == 1 and not args.no_env_loop and args.workload == "s-grip":

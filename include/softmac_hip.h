@@ -62,7 +62,7 @@ typedef struct smac_config {
     int32_t n_control;        /* cfg.n_controllers (:74-77) */
     int32_t n_primitives;     /* <= SMAC_MAX_PRIMS */
     int32_t rigid_velocity_control; /* 1: substep() advances primitive poses with forward_kinematics (:329-331, 367-369) */
-    int32_t sort_interval;    /* re-bin particles at most every this many substeps (0 = default 32; shortened by the library when
+    int32_t sort_interval;    /* re-bin particles at most every this many substeps (0 = default 40; shortened by the library when
                                  particles are fast enough to leave their block's halo sooner); no reference counterpart */
     int32_t flags;            /* bit 0: substep_grad recomputes the forward grid like the reference (:352-359) instead of
                                  restoring the copy saved by substep (DESIGN.md "grid checkpoint");
@@ -103,6 +103,11 @@ int smac_get_state(smac_handle h, int f, double* state24);                      
 int smac_copy_frame(smac_handle h, int src, int dst);                         /* copyframe :468-479 (particles + primitives) */
 int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC);   /* get_grad :570-574 (+F,C) */
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC); /* loss kernels' `x.grad[f,i] +=` */
+/* The same from DEVICE memory (round 4): gx ... are device pointers to C-contiguous float64 (n_particles, 3 | 3 | 9 | 9) arrays on the handle's device, in the
+ * caller's particle order (NULL: none).  This is the reference's own flow - its loss kernels add to `x.grad[f, i]` on the device after the forward pass
+ * (losses/loss_pour.py:130-140) - for losses the caller evaluates on the GPU (torch autograd glue): no host round trip, no synchronisation; the adds are
+ * enqueued on the handle's stream (smac_stream_handle), and the caller orders the buffers' producer before this call. */
+int smac_add_grad_device(smac_handle h, int f, const double* gx_dev, const double* gv_dev, const double* gF_dev, const double* gC_dev);
 int smac_clear_grads(smac_handle h);                                          /* ti.ad.clear_all_gradients() */
 /* Windowed episodes (checkpoint-every-K state frames with recompute; no reference counterpart: the reference keeps every frame resident).
  * smac_clear_grads, except that the particle adjoint of frame `src` survives as the adjoint of frame `dst` (with its particle order): the adjoint a

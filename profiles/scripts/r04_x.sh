@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4, session X: WIDE tiles (8^3 nodes, one node of slack around the block's 6^3, shell flushed with global atomics) + 21-slot stash
+# against the 6^3 tiles: parity on the new library, then interleaved bench A/B
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04x; mkdir -p $O
+timeout -k 10 1000 python3 -m pytest tests/test_gpu_fused_backward.py tests/test_gpu_parity.py tests/test_gpu_resort.py -x -q > $O/pytest.log 2>&1
+rc=$?; echo "pytest (wide) rc $rc"; tail -5 $O/pytest.log
+[ $rc -ne 0 ] && exit $rc
+for round in 1 2; do
+  for v in base wide; do
+    lib=libsoftmac_hip.so; [ $v != wide ] && lib=libsoftmac_hip_$v.so
+    for cfg in "20 20" "40 40"; do
+      set -- $cfg
+      SMAC_LIB=$PWD/softmac_amd/lib/$lib timeout -k 10 200 python3 bench.py --steps $1 --sort-interval $2 --warmup 5 --no-cpu-baseline --no-f64 --no-cloth --no-env-loop --repeats 3 > $O/bench_${v}_$1_$round.json 2> $O/bench_${v}_$1_$round.err || exit 1
+      python3 -c "
+import json;d=json.loads([l for l in open('$O/bench_${v}_$1_$round.json') if l.startswith('{')][-1]); print('$v steps $1 round $round', round(d['value'],1), d['ms_per_step_all'], 'fwd', round(d['fwd_only']['ms_per_step']*1e3,1), 'bwd', round(d['bwd_only']['ms_per_step']*1e3,1), {k: round(x*1e3,1) for k,x in d['kernels_ms_per_step'].items()}, 'launch', round(d['roofline']['avg_launch_ms']*1e3,1))"
+    done
+  done
+done

@@ -53,6 +53,7 @@ SIGNATURES = {
     "smac_copy_frame": (C.c_int, [H, C.c_int, C.c_int]),
     "smac_get_grad": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
     "smac_add_grad": (C.c_int, [H, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "smac_add_grad_device": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "smac_clear_grads": (C.c_int, [H]),
     "smac_carry_grad": (C.c_int, [H, C.c_int, C.c_int]),
     "smac_set_control_idx": (C.c_int, [H, c_int32_p]),

@@ -72,6 +72,7 @@ struct ISim {
     virtual int copy_frame(int src, int dst) = 0;
     virtual int get_grad(int f, double* gx, double* gv, double* gF, double* gC) = 0;
     virtual int add_grad(int f, const double* gx, const double* gv, const double* gF, const double* gC) = 0;
+    virtual int add_grad_device(int f, const double* gx, const double* gv, const double* gF, const double* gC) = 0;
     virtual int clear_grads() = 0;
     virtual int carry_grad(int src, int dst) = 0;
     virtual int set_control_idx(const int32_t* idx) = 0;
@@ -378,7 +379,7 @@ template <class R> struct Sim final : ISim {
         D.open_x = (c.flags >> 1) & 3;                               // flags bits 1,2: neighbour slab at the low / high x end
         D.nb = c.n_grid / 4;
         nblocks = D.nb * D.nb * D.nb;
-        sort_interval = c.sort_interval > 0 ? c.sort_interval : 32;
+        sort_interval = c.sort_interval > 0 ? c.sort_interval : 40;      // (32 until the wide tiles of round 4: a particle that crosses a block face no longer costs its wave the slow path)
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_vmax, sizeof(unsigned)));
         HIP_TRY(hipMalloc((void**)&d_vmax_part, ((size_t)D.Npad / 64 + 8) * sizeof(float)));
@@ -681,6 +682,25 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipStreamSynchronize(stream));                            // d_io is reused by the next component
         }
         return SMAC_OK;
+    }
+    // `x.grad[f, i] += ...` from arrays that already lie in device memory (a loss evaluated on the GPU, as the reference's loss kernels are:
+    // losses/loss_pour.py:130-140): no staging copy, no synchronisation
+    int add_grad_device(int f, const double* gx, const double* gv, const double* gF, const double* gC) override {
+        int rc;
+        if ((rc = need_grad()) || (rc = check_frame(f))) return rc;
+        if (adj_epoch[f] < 0 && (rc = adj_make_zero(f))) return rc;
+        if (adj_epoch[f] < 0) adj_epoch[f] = frame_epoch[f] < 0 ? 0 : frame_epoch[f];   // empty adjoint frame: adopt the state's order
+        const int e = adj_epoch[f];
+        const double* src[4] = {gx, gv, gC, gF};
+        const int c0[4] = {CX, CV, CC, CF}, cnt[4] = {3, 3, 9, 9};
+        for (int a = 0; a < 4; ++a) {
+            if (!src[a]) continue;
+            hipPointerAttribute_t at;
+            REQUIRE(hipPointerGetAttributes(&at, src[a]) == hipSuccess && at.type == hipMemoryTypeDevice, "add_grad_device: not a device pointer");
+            hipLaunchKernelGGL(k_rows_add_aos<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, D.Npad, src[a], cnt[a],
+                               e > 0 ? (const int*)epochs[e].orig : (const int*)nullptr, adj_ptr(f) + rowbase(c0[a], D.Npad));
+        }
+        return check_launch();
     }
     int clear_grads() override {
         if (D.A) adj_stale.assign(cfg.max_frames, 1);                              // zeroed on demand (adj_make_zero)
@@ -2914,6 +2934,7 @@ int smac_get_frame(smac_handle h, int f, double* x, double* v, double* F, double
 int smac_copy_frame(smac_handle h, int src, int dst) { return FWD(copy_frame(src, dst)); }
 int smac_get_grad(smac_handle h, int f, double* gx, double* gv, double* gF, double* gC) { return FWD(get_grad(f, gx, gv, gF, gC)); }
 int smac_add_grad(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC) { return FWD(add_grad(f, gx, gv, gF, gC)); }
+int smac_add_grad_device(smac_handle h, int f, const double* gx, const double* gv, const double* gF, const double* gC) { return FWD(add_grad_device(f, gx, gv, gF, gC)); }
 int smac_clear_grads(smac_handle h) { return FWD(clear_grads()); }
 int smac_carry_grad(smac_handle h, int src, int dst) { return FWD(carry_grad(src, dst)); }
 int smac_set_control_idx(smac_handle h, const int32_t* idx) { return FWD(set_control_idx(idx)); }

@@ -268,6 +268,20 @@ class MPMSimulator:
                 for a, shp in zip((gx, gv, gF, gC), ((N, 3), (N, 3), (N, 3, 3), (N, 3, 3)))]
         self._h.call("smac_add_grad", int(f), *[_ffi.dptr(a) for a in arrs])
 
+    def add_grad_device(self, f, gx=None, gv=None, gF=None, gC=None):
+        """add_grad from arrays that already live on the GPU: each argument is a device pointer (int) or anything with `.data_ptr()` (a contiguous
+        float64 torch tensor of shape (N, 3 | 3 | 9 | 9) on this handle's device).  No host round trip, no synchronisation: a loss evaluated on the
+        device seeds the backward pass the way the reference's Taichi loss kernels do (loss_pour.py:130-140)."""
+        def ptr(a):
+            if a is None:
+                return None
+            if hasattr(a, "data_ptr"):
+                if str(getattr(a, "dtype", "")) != "torch.float64" or not a.is_contiguous():
+                    raise ValueError("add_grad_device: contiguous float64 tensors")
+                return int(a.data_ptr())
+            return int(a)
+        self._h.call("smac_add_grad_device", int(f), ptr(gx), ptr(gv), ptr(gF), ptr(gC))
+
     def clear_grads(self):
         self._h.call("smac_clear_grads")
 

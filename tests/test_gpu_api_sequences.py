@@ -105,3 +105,29 @@ def test_random_call_sequences_agree_with_the_plain_launch_structure(case):
     _agree(fast.get_state(cur), plain.get_state(cur), (log, "final state", cur))
     print(f"\n[api sequence {case}] re-sort every {sort_interval}: " + " ".join(f"{o}->{c}" for o, c in log))
     assert fast.get_param("hit_overflows") == 0 and fast.get_param("drift_repairs") == plain.get_param("drift_repairs")
+
+
+def test_a_seed_from_device_memory_equals_the_host_seed():
+    """smac_add_grad_device (round 4): the loss kernels of the reference add to x.grad on the device (losses/loss_pour.py:130-140); a seed handed over as
+    device pointers must be the seed handed over as host arrays - before the frame exists (identity order) and after (the frame's binning), all four fields."""
+    import torch
+    rng = np.random.default_rng(3)
+    sim, prm, n = _engine({}, 4)
+    g = {k: rng.standard_normal((n,) + shp) for k, shp in (("gx", (3,)), ("gv", (3,)), ("gF", (3, 3)), ("gC", (3, 3)))}
+    gd = {k: torch.from_numpy(v.reshape(n, -1).copy()).cuda() for k, v in g.items()}
+    torch.cuda.synchronize()
+    for when in ("before the frame exists", "after the forward pass"):
+        got = []
+        for dev in (False, True):
+            sim.clear_grads()
+            if when.startswith("after"):
+                sim.run_substeps(0, 6)                      # frame 6 lies under the second binning (interval 4)
+            (sim.add_grad_device if dev else sim.add_grad)(6, **(gd if dev else g))
+            if when.startswith("before"):
+                sim.run_substeps(0, 6)
+            sim.run_substeps_grad(0, 6)
+            got.append([np.asarray(a) for a in sim.get_grad_full(0)])
+        for a, b in zip(*got):
+            _agree(a, b, when)
+    with pytest.raises(Exception):
+        sim.add_grad_device(6, gx=g["gx"].ctypes.data)      # a host pointer is refused, not dereferenced

@@ -158,6 +158,8 @@ KERNEL_BYTES = {
     "sort": (48, 0), "reorder_adjoint": (48, 0),
     # p2g.grad of substep f + g2p.grad of substep f-1 in one launch: p2g.grad's rows, + x of frame f-1 and its x.grad; both gather tiles + the slab
     "p2g_g2p_grad": (24 + 9 + 3 + 24 + 3 + 3, 4 + 3 + 3),
+    # g2p of substep f + p2g of substep f+1 in one launch (round 4): x of frame f and F of frame f+1 in, x v C of frame f+1 and F of frame f+2 out; the gather tile + the slab
+    "g2p_p2g": (3 + 9 + 15 + 9, 3 + 4),
 }
 
 

@@ -80,6 +80,10 @@ template <class R> struct DevSim {
     // grid: one 4-scalar record per cell and field, so a stencil node is ONE 16-byte access
     Vec4<R> *vin, *vmix, *vout;         // {m, p_x, p_y, p_z} / {v_mixed, 0} / {v_out, 0}
     Vec4<R> *ain, *amix, *aout;         // adjoints: {grid_m.grad, grid_v_in.grad} / {grid_v_mixed.grad, 0} / {grid_v_out.grad, 0}
+    // {m, p} that P2G adds with global atomics - the shell of a chunk's wide tile, the stencil of a particle more than a cell past its block - goes to a field
+    // of its own: k_grid_op adds it to the slabs' sum, writes {m, p} to vin and leaves vdrift zero again.  So P2G of substep f + 1 may run while the
+    // checkpoint save of substep f still reads vin (k_g2p_p2g), and vin needs no clear pass.  Invariant: all zero outside [P2G, grid_op].
+    Vec4<R>* vdrift;
     PrimTable<R> prim[MAX_PRIMS];        // tables in R: band filter, collision types 0 / 1
     PrimTable<double> prim64[MAX_PRIMS]; // tables in f64: the forecast contact chain (k_contact_hits / k_contact_grad) runs in double
     // rigid-body state, its adjoint and the wrench accumulators are f64 whatever R is: a pose rounded to float (3e-8 at 0.5)
@@ -139,6 +143,8 @@ template <class R> struct DevSim {
     int fk_ride;                 // > 0: this launch also carries forward_kinematics (k_g2p: its last workgroup) / its adjoint (the grid-adjoint reduction: its last
     size_t fk_stride;            // fk_ride workgroups) of that many velocity-controlled primitives (primitive_base.py:280-283, mpm_simulator.py:329-331, 367-369)
     int* nhits_next;             // the hit counter of the NEXT substep (two counters alternate by frame parity): emptied here while this frame's is still read
+    struct Hit* hits_next;       // ... and the NEXT substep's hit list (k_g2p_p2g: P2G of substep f + 1 appends to it while the save part copies this substep's)
+    int zero_next_hits;          // k_grid_op: empty the next substep's counter (its P2G rides in this substep's G2P launch and appends right away)
     ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
 };
 
@@ -386,8 +392,8 @@ template <class R> __device__ __forceinline__ int active_slot(const DevSim<R>&) 
     SMAC_CHUNK_PROLOGUE_AT(cid)
 
 // store this chunk's f64 LDS tile (NS scalars, tile[s][word]) to its slab as 16-byte records, coalesced
-template <class R, int NS, class W> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const W* tile, R s0 = R(1), R s123 = R(1)) {
-    Vec4<R>* dst = D.slab + (size_t)xcd_chunk(D.nchunks) * TILE_WORDS;
+template <class R, int NS, class W> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const W* tile, R s0 = R(1), R s123 = R(1), int cid = -1) {
+    Vec4<R>* dst = D.slab + (size_t)(cid >= 0 ? cid : xcd_chunk(D.nchunks)) * TILE_WORDS;
     for (int i = threadIdx.x; i < TILE_WORDS; i += BLOCK) {
         const int w = SMAC_WIDE_TILE ? (i / TSX + PO) * PSX + ((i / TSY) % TW + PO) * PSY + i % TW + PO : i;      // the 6^3 core of the wide tile
         Vec4<R> v;
@@ -626,10 +632,7 @@ __device__ __forceinline__ void grid_save_block(const DevSim<R>& D, int nblocks,
         if (empty) return;                                               // no mass: grid_op left v_mixed = v_out = 0 there, {m,p} is zero already
     }
     dst[0] = in; dst[64] = D.vmix[cell]; dst[128] = D.vout[cell];
-    // {m, p} is not read again this substep: leave it zeroed for the next P2G (drifted particles add to it with
-    // global atomics), which saves that substep's clear pass
-    const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-    D.vin[cell] = z;
+    // ({m, p} stays as it is: the next substep's k_grid_op overwrites it; what P2G adds with global atomics goes to D.vdrift)
 }
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
@@ -660,24 +663,16 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
 // PCON: collision_type 1 (penalty contact inside p2g) - a separate instantiation, so that the benchmarked forecast-contact
 // kernel does not carry the f64 penalty chain in its register budget
 // MAT2: the two-entry material table (a separate instantiation: the benchmarked one-material kernel keeps its registers)
-template <class R, bool STORE_F, bool PCON, bool MAT2 = false>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_p2g(DevSim<R> D, int f) {
+// P2G of one chunk (every thread of the workgroup; two barriers).  `tile_raw` is the zeroed scatter tile (zeros visible at the latest by the barrier inside
+// tile_scale), `ps_wg` the workgroup's copy of the primitive states of frame f, `cid` the chunk (its slab).  FROM_REGS: x, v, C of frame f come in
+// registers (`xr`, `vr`, `Cr`: the G2P of the substep before has just produced them, k_g2p_p2g) instead of from the frame's rows; hits go to `hits` / `nhits`.
+template <class R, bool STORE_F, bool PCON, bool MAT2, bool FROM_REGS>
+__device__ __forceinline__ void p2g_body(const DevSim<R>& D, int f, const Chunk& ch, int cid, int t, bool valid, int p, double* tile_raw, R* smax, const R* ps_wg,
+                                         const typename pos_of<R>::type* xr, const R* vr, const R* Cr, struct Hit* hits, int* nhits) {
     typedef typename ScatterTile<R>::word W;
-    __shared__ __attribute__((aligned(16))) double tile_raw[4 * PTILE];
-    __shared__ R smax[4];
-    __shared__ R ps_wg[MAX_PRIMS * 13];
-    SMAC_PHASE(22, true);                // (entry, every wave)
-    if (D.any_contact) {                 // (uniform) primitive states of this frame, converted once per workgroup for the band test
-        if (threadIdx.x < D.P * 13)
-            ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];
-        __syncthreads();
-    }
-    SMAC_CHUNK_PROLOGUE
-    SMAC_PHASE(23, ch.count >= 0);       // (descriptor in, every wave)
     W* const tile = (W*)tile_raw;
     double* const tile64 = tile_raw;
     const bool sparse = sizeof(R) == 4 && ch.count <= SPARSE_MAX;       // workgroup-uniform: f64 words instead of fixed point
-    lds_zero16(tile_raw, 4 * PTILE * (int)(sparse ? sizeof(double) : sizeof(W)));     // (made visible by the barrier inside tile_scale)
     int cmask = 0;
     SMAC_PHASE(16, valid);
     typedef typename pos_of<R>::type PX;
@@ -690,9 +685,16 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
         R Et[9], En[9], stress[9];
         const R* Sf = frame(D.S, f, D.Npad);
         R v[3], C[9], E[9];
-        load_pos(Sf, D.Npad, p, x);
-        load_vec(Sf, CV, 3, D.Npad, p, v);
-        load_vec(Sf, CC, 9, D.Npad, p, C);
+        if (FROM_REGS) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { x[i] = xr[i]; v[i] = vr[i]; }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) C[i] = Cr[i];
+        } else {
+            load_pos(Sf, D.Npad, p, x);
+            load_vec(Sf, CV, 3, D.Npad, p, v);
+            load_vec(Sf, CC, 9, D.Npad, p, C);
+        }
         load_vec(Sf, CF, 9, D.Npad, p, E);
         int cloth_face = -1;
         if (PCON && D.cloth.present) {                             // cloth primitive, penalty contact: the contact face was searched before the substep
@@ -701,13 +703,13 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
             if (cloth_face >= 0) {
                 cmask = 1 | ((D.cloth.penetration[at] == 1 ? 1 : 0) << 1);
                 Hit h = {p, cmask, ch.block, cloth_face};
-                D.hits[hit_slot(D.nhits)] = h;
+                hits[hit_slot(nhits)] = h;
             }
         } else if (D.any_contact && D.collision_type != CONTACT_GRID && !D.cloth.present) {   // contact band test (x is at hand): build the sparse contact lists
             cmask = contact_mask(D, f, x, (const R*)ps_wg);
             if (cmask) {
                 Hit h = {p, cmask, ch.block, 0};
-                D.hits[hit_slot(D.nhits)] = h;
+                hits[hit_slot(nhits)] = h;
             }
         }
         {
@@ -811,8 +813,8 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
                 } else {
                     const unsigned cell = (unsigned)((i == 0 ? nd.cx[0] : (i == 1 ? nd.cx[1] : nd.cx[2])) + (j == 0 ? nd.cy[0] : (j == 1 ? nd.cy[1] : nd.cy[2])) +
                                                      (k == 0 ? nd.cz[0] : (k == 1 ? nd.cz[1] : nd.cz[2])));
-                    gatomic(D.vin, cell, 0, w * D.p_mass);
-                    for (int c = 0; c < 3; ++c) gatomic(D.vin, cell, 1 + c, val[c]);
+                    gatomic(D.vdrift, cell, 0, w * D.p_mass);
+                    for (int c = 0; c < 3; ++c) gatomic(D.vdrift, cell, 1 + c, val[c]);
                 }
             }
         } else if (wave_in) {
@@ -853,9 +855,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
                             for (int c = 0; c < 3; ++c) tile_add(tp + (1 + c) * PTILE, val[c] * to_tile);
                         } else {
                             const unsigned cell = nd.cell(i, j, k);
-                            gatomic(D.vin, cell, 0, w * D.p_mass);
+                            gatomic(D.vdrift, cell, 0, w * D.p_mass);
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) gatomic(D.vin, cell, 1 + c, val[c]);
+                            for (int c = 0; c < 3; ++c) gatomic(D.vdrift, cell, 1 + c, val[c]);
                         }
                     }
                 }
@@ -866,13 +868,31 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_
     SMAC_PHASE(19, valid);                     // scatter issued
     __syncthreads();
     SMAC_PHASE(20, valid);
-    if (sparse) { tile_store<R, 4>(D, tile64, R(1), R(1)); tile_flush_shell<R, 4>(D, tile64, D.vin, ch.block, R(1), R(1)); }
+    if (sparse) { tile_store<R, 4>(D, tile64, R(1), R(1), cid); tile_flush_shell<R, 4>(D, tile64, D.vdrift, ch.block, R(1), R(1)); }
     else {
         const R s_m = sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1);
-        tile_store<R, 4>(D, tile, s_m, from_tile);
-        tile_flush_shell<R, 4>(D, tile, D.vin, ch.block, s_m, from_tile);
+        tile_store<R, 4>(D, tile, s_m, from_tile, cid);
+        tile_flush_shell<R, 4>(D, tile, D.vdrift, ch.block, s_m, from_tile);
     }
     SMAC_PHASE(21, valid);
+}
+
+template <class R, bool STORE_F, bool PCON, bool MAT2 = false>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_P2G : 2)) void k_p2g(DevSim<R> D, int f) {
+    typedef typename ScatterTile<R>::word W;
+    __shared__ __attribute__((aligned(16))) double tile_raw[4 * PTILE];
+    __shared__ R smax[4];
+    __shared__ R ps_wg[MAX_PRIMS * 13];
+    SMAC_PHASE(22, true);                // (entry, every wave)
+    if (D.any_contact) {                 // (uniform) primitive states of this frame, converted once per workgroup for the band test
+        if (threadIdx.x < D.P * 13)
+            ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f) * 13 + threadIdx.x % 13];
+        __syncthreads();
+    }
+    SMAC_CHUNK_PROLOGUE
+    SMAC_PHASE(23, ch.count >= 0);       // (descriptor in, every wave)
+    lds_zero16(tile_raw, 4 * PTILE * (int)((sizeof(R) == 4 && ch.count <= SPARSE_MAX) ? sizeof(double) : sizeof(W)));     // (made visible by the barrier inside tile_scale)
+    p2g_body<R, STORE_F, PCON, MAT2, false>(D, f, ch, cid, t, valid, p, tile_raw, smax, ps_wg, nullptr, (const R*)nullptr, (const R*)nullptr, D.hits, D.nhits);
 }
 
 // boundary_condition :268-281 on a velocity; returns mask bits of the components that were zeroed
@@ -928,16 +948,27 @@ template <class R> __device__ __forceinline__ bool active_cell(const DevSim<R>& 
     return true;
 }
 
+__device__ __forceinline__ void prim_fk_step(double* state, int f, double dt);
 // slab reduction (completes P2G) fused with grid_op :283-297 / grid_op_mixed1 :396-404
 // phase 0: both; 1: slab reduction only (multi-GPU: the halo planes of {m,p} are summed across slabs next);
 // 2: normalisation only
 template <class R, bool GRIDC>
 __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
+    if (D.fk_ride > 0 && blockIdx.x == gridDim.x - 1) {       // forward_kinematics to frame cur_frame + 1 rides here when this substep's G2P launch carries the next
+        if ((int)threadIdx.x < D.fk_ride) prim_fk_step(D.prim_state + threadIdx.x * D.fk_stride, D.cur_frame, D.dt64);      // substep's P2G, whose band test reads those states
+        return;
+    }
+    if (D.zero_next_hits && blockIdx.x == 0 && threadIdx.x == 0) *D.nhits_next = 0;
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    Vec4<R> acc = D.vin[cell];                                                          // drift fallback part
+    Vec4<R> acc = D.vin[cell];
     if (phase != 2) {
+        acc = D.vdrift[cell];                                                           // what P2G added with global atomics ...
+        if (acc.x != R(0) || acc.y != R(0) || acc.z != R(0) || acc.w != R(0)) {
+            const Vec4<R> z0 = {R(0), R(0), R(0), R(0)};
+            D.vdrift[cell] = z0;                                                        // ... consumed: the field is all zero again
+        }
         slab_reduce(D, b, l, acc);
         D.vin[cell] = acc;
     }
@@ -1102,7 +1133,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
 
 // one particle of g2p :299-318: gather from the staged tile `gt` (global fallback for a lane that drifted out of it), write frame f+1
 template <class R>
-__device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch, int p, const typename pos_of<R>::type* x, const Vec4<R>* gt, R* Sn) {
+__device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch, int p, const typename pos_of<R>::type* x, const Vec4<R>* gt, R* Sn,
+                                             typename pos_of<R>::type* xn_o = nullptr, R* nv_o = nullptr, R* nC_o = nullptr) {   // (k_g2p_p2g: x, v, C of frame f + 1 in registers too)
     Stencil<R> st;
     Nodes nd;
     stencil_at_p(D, x, st, nd, ch.block);
@@ -1166,6 +1198,7 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
         Sn[rowoff(CV + c, p, D.Npad)] = nv[c];
         const typename pos_of<R>::type xn = pos_advance(x[c], D.dt64, nv[c]);          // :318
         store_pos(Sn, D.Npad, p, c, xn);
+        if (xn_o) { xn_o[c] = xn; nv_o[c] = nv[c]; }
         // the position just written is scattered by the NEXT substep's P2G: if that substep keeps this binning, the new
         // base must still lie in the blocks around the chunk's own (the only ones that are cleared, reduced and swept)
         int nbase = pos_base(xn, D.n);
@@ -1176,7 +1209,11 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
     }
     if (leaves && D.check_next) *D.drift_flag = 1;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) Sn[rowoff(CC + c, p, D.Npad)] = four_inv_dx * nC[c];
+    for (int c = 0; c < 9; ++c) {
+        const R cc = four_inv_dx * nC[c];
+        Sn[rowoff(CC + c, p, D.Npad)] = cc;
+        if (nC_o) nC_o[c] = cc;
+    }
 }
 
 // forward_kinematics :280-283 of primitive `i` from frame f to f + 1, and its adjoint (13 inputs -> 7 outputs, forward-mode duals: thread `dir` owns input `dir`)
@@ -1236,6 +1273,52 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_
     if (!valid) return;
     g2p_particle(D, ch, p, x, gt, Sn);
     SMAC_PHASE(26, true);
+}
+
+// G2P of substep f and P2G of substep f + 1 in one launch (round 4; the forward counterpart of k_p2g_g2p_grad).  Between two re-sorts a particle keeps its
+// chunk, and x, v, C of frame f + 1 that G2P has just produced are exactly what P2G of the next substep loads first: they stay in registers (15 rows of
+// reads, a kernel boundary and a workgroup prologue less per forward substep; the rows are still written - every frame stays readable).  P2G of
+// substep f + 1 scatters into the slabs and, for what leaves a tile, into D.vdrift - neither is read by G2P or by the checkpoint save of substep f in the
+// first workgroups of this launch; its hits go to the OTHER of two hit lists (D.hits_next / D.nhits_next: the save part copies this substep's).  The host
+// has run forward_kinematics to frame f + 1 and emptied the next counter inside k_grid_op's launch of substep f.  SAVE: as k_g2p<R, true>.
+template <class R, bool SAVE>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2P : 2)) void k_g2p_p2g(DevSim<R> D, int f) {
+    typedef typename ScatterTile<R>::word W;
+    typedef typename pos_of<R>::type PX;
+    __shared__ __attribute__((aligned(16))) double tile_raw[4 * PTILE];
+    __shared__ Vec4<R> gt[PTILE];
+    __shared__ R smax[4];
+    __shared__ R ps_wg[MAX_PRIMS * 13];
+    int bid = (int)blockIdx.x;
+    if (SAVE) {
+        if (bid == 0 && threadIdx.x == 0) { D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand; *D.ncand = 0; }
+        if (bid < D.save_blocks) {
+            grid_save_block(D, D.save_blocks, D.save_ck, D.save_hits, D.save_nhits, D.save_hit_cap);
+            return;
+        }
+        bid -= D.save_blocks;
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        D.last_counts[0] = *D.nhits; D.last_counts[1] = *D.ncand;
+        *D.nhits = 0; *D.ncand = 0;
+    }
+    const int cid = xcd_chunk_at(bid, D.nchunks);
+    if (cid >= D.nchunks) return;
+    if (D.any_contact && threadIdx.x < D.P * 13)      // primitive states of frame f + 1 for the band test (published by the barrier below)
+        ps_wg[threadIdx.x] = (R)D.prim_state[((size_t)(threadIdx.x / 13) * D.max_frames + f + 1) * 13 + threadIdx.x % 13];
+    SMAC_CHUNK_PROLOGUE_AT(cid)
+    lds_zero16(tile_raw, 4 * PTILE * (int)((sizeof(R) == 4 && ch.count <= SPARSE_MAX) ? sizeof(double) : sizeof(W)));
+    const R* Sf = frame(D.S, f, D.Npad);
+    R* Sn = frame(D.S, f + 1, D.Npad);
+    PX x[3];
+    load_pos(Sf, D.Npad, p, x);
+    gather_tile_load_p(D, D.vout, ch.block, gt);
+    __syncthreads();
+    PX xn[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
+    R nv[3] = {R(0), R(0), R(0)}, nC[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) nC[c] = R(0);
+    if (valid) g2p_particle(D, ch, p, x, gt, Sn, xn, nv, nC);
+    p2g_body<R, true, false, false, true>(D, f + 1, ch, cid, t, valid, p, tile_raw, smax, ps_wg, xn, nv, nC, D.hits_next, D.nhits_next);
 }
 
 // ------------------------------------------------------------------------------------------

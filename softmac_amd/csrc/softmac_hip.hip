@@ -40,7 +40,7 @@ static thread_local std::string g_create_error;
         }                                    \
     } while (0)
 
-enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_P2G_G2P_GRAD, K_COUNT };
+enum KernelId { K_CLEAR = 0, K_CKPT, K_P2G, K_GRID_OP, K_CONTACT, K_G2P, K_G2P_GRAD, K_REDUCE, K_CONTACT_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_FK, K_SORT, K_REORDER, K_P2G_G2P_GRAD, K_G2P_P2G, K_COUNT };
 static const char* kDriftMessage =
     "a particle left the halo of its grid block between two re-sorts (it more than doubled its speed inside one re-sort "
     "interval): the frames after that substep are invalid - lower sort_interval or dt";
@@ -48,7 +48,7 @@ static const char* kSlabLeftMessage =
     "slab decomposition: a particle's stencil left the x-planes this rank shares with its neighbours (its deposits there would be lost): "
     "migrate more often (SlabRunner.migrate at every re-sort) or widen the shared band (nplanes = 2 + 2 * drift tolerance)";
 static const char* kKernelNames[K_COUNT] = {"clear_grid", "grid_checkpoint", "p2g", "grid_op", "contact", "g2p", "g2p_grad", "reduce_agvout", "contact_grad",
-                                            "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint", "p2g_g2p_grad"};
+                                            "grid_op_grad", "p2g_grad", "forward_kinematics", "sort", "reorder_adjoint", "p2g_g2p_grad", "g2p_p2g"};
 
 // a few scalars handed to the device inside the kernel's argument block
 template <class T, int N> struct SmallArgs { T v[N]; };
@@ -130,6 +130,7 @@ struct ISim {
     virtual int get_ids(int64_t* ids) = 0;
     virtual int stream_handle(void** s) = 0;
     virtual void hint_backward_next(int f) = 0;
+    virtual void hint_forward_next(int f) = 0;
     virtual int set_param(const char* name, double value) = 0;
     virtual int get_param(const char* name, double* value) = 0;
     virtual int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction,
@@ -207,6 +208,8 @@ template <class R> struct Sim final : ISim {
     Vec4<R>* slab = nullptr;
     size_t slab_chunks = 0;
     Hit* d_hits = nullptr;           // capacity Npad
+    Hit* d_hits2 = nullptr;          // the hit list of odd frames (k_g2p_p2g appends the next substep's hits while this substep's list is filed)
+    Vec4<R>* vdrift = nullptr;       // DevSim::vdrift
     int* d_nhits = nullptr;          // [0] = nhits, [1] = ncand
     int* d_cand = nullptr;
     int* d_pmask = nullptr;
@@ -276,7 +279,7 @@ template <class R> struct Sim final : ISim {
         hipFree(D.cloth.ext_f_grad); hipFree(D.cloth.contact_id); hipFree(D.cloth.penetration); hipFree(D.cloth.contact_before);
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
         hipFree(d_mat_id);
-        hipFree(d_hits); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
+        hipFree(d_hits); hipFree(d_hits2); hipFree(vdrift); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
         if (h_nhits) hipHostFree(h_nhits);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
             if ((void*)prim_tables64[i][0] != (void*)prim_tables[i][0]) { hipFree(prim_tables64[i][0]); hipFree(prim_tables64[i][1]); }
@@ -345,6 +348,12 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&d_nhits, 8 * sizeof(int)));         // [0] hit counter (even frames, backward pass), [1] ncand, [2..3] last counts, [4] hit counter of odd frames
         HIP_TRY(hipMemsetAsync(d_nhits, 0, 8 * sizeof(int), stream));
         HIP_TRY(hipMalloc((void**)&d_hits, (size_t)D.Npad * sizeof(Hit)));
+        HIP_TRY(hipMalloc((void**)&d_hits2, (size_t)D.Npad * sizeof(Hit)));
+        HIP_TRY(hipMalloc((void**)&vdrift, D.G * sizeof(Vec4<R>)));
+        HIP_TRY(hipMemsetAsync(vdrift, 0, D.G * sizeof(Vec4<R>), stream));
+        D.vdrift = vdrift;
+        D.hits_next = d_hits2;
+        D.zero_next_hits = 0;
         HIP_TRY(hipMalloc((void**)&d_pmask, (size_t)D.Npad * sizeof(int)));
         D.nhits = d_nhits;
         D.nhits_next = d_nhits + 4;
@@ -505,7 +514,7 @@ template <class R> struct Sim final : ISim {
 
     int set_frame(int f, const double* x, const double* v, const double* F, const double* C) override {
         int rc = check_frame(f);
-        if (rc) return rc;
+        if (rc || (rc = leave_fused_forward())) return rc;
         if (frame_epoch[f] < 0) frame_epoch[f] = 0;          // first write: identity order
         if (x && v && F && C) frame_epoch[f] = 0;            // a full overwrite needs no old order (and the particle SET may be new: migration)
         ck_epoch[f] = -1;                                    // the saved forward grid of this frame is stale
@@ -546,6 +555,7 @@ template <class R> struct Sim final : ISim {
     int reset(const double* state, int cols) override {                       // mpm_simulator.py:494-519
         REQUIRE(state && (cols == 3 || cols == 24), "reset: cols must be 3 or 24");
         int rc;
+        if ((rc = leave_fused_forward())) return rc;
         frame_epoch[0] = 0;                                                   // user data: identity order, re-binned at the next substep
         ck_epoch[0] = -1;
         // the caller's (N, cols) array goes up once; the split into x / v / C / F rows (host layout x3 v3 F9 C9) happens on the device
@@ -571,7 +581,7 @@ template <class R> struct Sim final : ISim {
     }
     int copy_frame(int src, int dst) override {                               // :468-479
         int rc;
-        if ((rc = check_frame(src)) || (rc = check_frame(dst))) return rc;
+        if ((rc = check_frame(src)) || (rc = check_frame(dst)) || (rc = leave_fused_forward())) return rc;
         if (src == dst) return SMAC_OK;
         HIP_TRY(hipMemcpyAsync(D.S + (size_t)dst * frame_scalars(), D.S + (size_t)src * frame_scalars(),
                                frame_scalars() * sizeof(R), hipMemcpyDeviceToDevice, stream));
@@ -1021,6 +1031,8 @@ template <class R> struct Sim final : ISim {
         repairing = true;
         const int Pn = D.P > 0 ? D.P : 1;
         int rc = SMAC_OK;
+        p2g_done_frame = 0;                                   // (forces the reset below: a particle that out-ran its binning may have added to D.vdrift on blocks
+        if (leave_fused_forward() != SMAC_OK) rc = SMAC_ERR_HIP;   //  no k_grid_op of this epoch sweeps)
         // The wrench accumulators go back to their value at `snap_frame` - the epoch's first frame, or the last env-step boundary inside it at which
         // the host read and cleared ext_f (rigid_simulator.py:92-93, 117): what the host has consumed must not be accumulated again.  Substeps
         // replayed BEFORE that frame send their wrench sums to the scratch slot (as the backward recompute does); from that frame on they count.
@@ -1619,7 +1631,9 @@ template <class R> struct Sim final : ISim {
     // Forward grid passes.  stage 0: everything; stage 1: clear_grid :93-114 on the active blocks, p2g, (forward
     // kinematics), slab reduction; stage 2: grid_op + contact.  Stages 1/2 exist for the slab decomposition, which
     // sums the {m,p} halo planes across neighbouring GPUs between them.
-    int forward_grid(int f, bool store_F, bool is_recompute, int stage = 0) {
+    // skip_p2g: this substep's P2G already ran inside the G2P launch of the substep before (k_g2p_p2g); fuse_next: the NEXT substep's P2G will ride in this
+    // substep's G2P launch - forward_kinematics to frame f + 1 and the emptying of the next hit counter move into k_grid_op's launch
+    int forward_grid(int f, bool store_F, bool is_recompute, int stage = 0, bool skip_p2g = false, bool fuse_next = false) {
         int rc;
         if (D.nchunks == 0 || D.nactive == 0) return SMAC_OK;
         D.any_contact = any_contact() ? 1 : 0;
@@ -1627,12 +1641,13 @@ template <class R> struct Sim final : ISim {
         DevSim<R> Dc = D;                                       // the recompute pass must not double-count ext_f
         if (is_recompute || (repairing && f < replay_count_from)) Dc.ext_f = scratch_ext();
         if ((is_recompute || (repairing && f < replay_count_from)) && D.cloth.present) Dc.cloth.ext_f = d_cloth_ext_scratch;
-        if (stage != 2) {
-            // grid_op rewrites v_mixed / v_out of every active cell; {m,p} must start from zero (drifted particles add to
-            // it atomically) and is left zeroed by the checkpoint save of the previous substep
-            if (is_recompute || !vin_clean) {
+        const bool fk_in_grid_op = fuse_next && !is_recompute && cfg.rigid_velocity_control && D.P > 0;
+        if (stage != 2 && !skip_p2g) {
+            // k_grid_op rewrites {m,p}, v_mixed and v_out of every active cell ({m,p} = slabs + D.vdrift, which it leaves zero again): no clear pass in
+            // front of P2G.  The recompute inside substep_grad clears the adjoint fields with it.
+            if (is_recompute) {
                 prof_begin(K_CLEAR);
-                hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, is_recompute ? 6 : 1);
+                hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 6);
                 prof_end();
             }
             vin_clean = false;
@@ -1650,7 +1665,11 @@ template <class R> struct Sim final : ISim {
                 else hipLaunchKernelGGL((k_p2g<R, false, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
             }
             prof_end();
-            if (!is_recompute && cfg.rigid_velocity_control && D.P > 0 && fk_rides_g2p) {
+        }
+        if (stage != 2) {
+            if (fk_in_grid_op) {
+                REQUIRE(f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");   // (done by the last workgroup of this substep's k_grid_op launch)
+            } else if (!is_recompute && cfg.rigid_velocity_control && D.P > 0 && fk_rides_g2p) {
                 REQUIRE(f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");   // (done by the last workgroup of this substep's k_g2p launch)
             } else if (!is_recompute && cfg.rigid_velocity_control && D.P > 0) {  // :329-331, every primitive in one launch
                 REQUIRE(f + 1 < cfg.max_frames, "forward_kinematics: frame out of range");
@@ -1660,10 +1679,14 @@ template <class R> struct Sim final : ISim {
             }
         }
         prof_begin(K_GRID_OP);
+        Dc.zero_next_hits = fuse_next ? 1 : 0;
+        Dc.fk_ride = 0;
+        if (fk_in_grid_op) { Dc.fk_ride = D.P; Dc.fk_stride = (size_t)cfg.max_frames * 13; }
         if (D.collision_type == CONTACT_GRID && D.any_contact)
-            hipLaunchKernelGGL((k_grid_op<R, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dc, stage);
+            hipLaunchKernelGGL((k_grid_op<R, true>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
         else
-            hipLaunchKernelGGL((k_grid_op<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dc, stage);
+            hipLaunchKernelGGL((k_grid_op<R, false>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
+        Dc.fk_ride = 0;
         prof_end();
         if (stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED) {
             prof_begin(K_CONTACT);
@@ -1721,12 +1744,20 @@ template <class R> struct Sim final : ISim {
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
         normalize_grid_set();
-        // the hit counters of even and odd frames alternate (k_g2p<R, true> empties the next frame's while its save part still reads this one's)
+        // P2G of this substep already ran inside the G2P launch of the substep before (k_g2p_p2g)?  Anything else than that substep coming next abandons it.
+        const bool p2g_done = phase < 0 && p2g_done_frame == f;
+        if (!p2g_done && (rc = leave_fused_forward())) return rc;
+        p2g_done_frame = -1;
+        // the hit counters - and lists - of even and odd frames alternate (k_g2p<R, true> empties the next frame's counter while its save part still reads
+        // this one's; k_g2p_p2g appends the next frame's hits while its save part files this frame's list)
         auto bind_hit_counters = [&]() {
             D.nhits = d_nhits + ((f & 1) ? 4 : 0);
             D.nhits_next = d_nhits + ((f & 1) ? 0 : 4);
+            D.hits = (f & 1) ? d_hits2 : d_hits;
+            D.hits_next = (f & 1) ? d_hits : d_hits2;
         };
         bind_hit_counters();
+        bool fuse_next = false;
         if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
@@ -1744,16 +1775,22 @@ template <class R> struct Sim final : ISim {
             // left counts behind.  Bind for f again and start from two empty counters (the stale binding appended behind nh(f-1) hits and
             // the contact correction of those particles was applied twice).
             bind_hit_counters();
-            if (nhits_zero_frame != f || drift_repairs != repairs_before) {
+            REQUIRE(!(p2g_done && drift_repairs != repairs_before), "internal: a re-sort in front of a substep whose P2G has run");
+            if (!p2g_done && (nhits_zero_frame != f || drift_repairs != repairs_before)) {
                 HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
                 HIP_TRY(hipMemsetAsync(d_nhits + 4, 0, sizeof(int), stream));
             }
             nhits_zero_frame = -1;
             if ((rc = bind_epoch(e))) return rc;
             ck_epoch[f] = -1;
+            // Fused forward step (k_g2p_p2g): the batched loop (smac_substeps) has announced that substep f + 1 follows, it keeps this binning, and nothing
+            // it needs changes in between (no particle action, penalty contact, sheet or second material: those P2G instantiations stay on their own) -
+            // then this substep's G2P launch also runs the next substep's P2G, and the call for f + 1 starts at k_grid_op.  SMAC_FUSED_FWD=0: off.
+            fuse_next = fused_fwd_env && phase < 0 && fwd_hint == f + 1 && f + 2 < cfg.max_frames && !repairing && D.nchunks > 0 && D.nactive > 0 &&
+                        f + 1 - epochs[e].frame < epochs[e].interval && D.n_control == 0 && D.collision_type != CONTACT_PARTICLE && !D.cloth.present && !D.mat_id;
             // whole substep with particles: forward_kinematics rides in k_g2p's launch instead of a launch of its own (SMAC_FK_RIDE=0: own kernel)
-            fk_rides_g2p = fk_ride_env && phase < 0 && cfg.rigid_velocity_control && D.P > 0 && D.nchunks > 0 && D.nactive > 0;
-            if ((rc = forward_grid(f, true, false, phase < 0 ? 0 : 1))) return rc;
+            fk_rides_g2p = !fuse_next && fk_ride_env && phase < 0 && cfg.rigid_velocity_control && D.P > 0 && D.nchunks > 0 && D.nactive > 0;
+            if ((rc = forward_grid(f, true, false, phase < 0 ? 0 : 1, p2g_done, fuse_next))) return rc;
         }
         if (phase == 1 && (rc = forward_grid(f, true, false, 2))) return rc;
         if (phase < 0 || phase == 2) {
@@ -1778,9 +1815,24 @@ template <class R> struct Sim final : ISim {
                 vin_clean = true;
             }
             if (D.nchunks > 0) {
-                prof_begin(K_G2P);
+                prof_begin(fuse_next ? K_G2P_P2G : K_G2P);
                 D.check_next = (f + 1 - epochs[e].frame < epochs[e].interval) ? 1 : 0;     // else substep(f+1) re-bins first
-                if (save_in_g2p) {
+                if (fuse_next) {                                                            // G2P of this substep + P2G of the next in one launch
+                    DevSim<R> Dg = D;
+                    Dg.any_contact = any_contact() ? 1 : 0;
+                    if (save_in_g2p) {
+                        Dg.save_ck = ck_slot(f);
+                        Dg.save_hits = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
+                        Dg.save_nhits = keep_hits ? ck_nhits + f : (int*)nullptr;
+                        Dg.save_nhits_host = keep_hits ? h_nhits + f : nullptr;
+                        Dg.save_hit_cap = ck_hit_cap;
+                        Dg.ck_flags = ck_flags_of(f);
+                        Dg.save_blocks = (ngrid_blocks() + 7) & ~7;
+                        hipLaunchKernelGGL((k_g2p_p2g<R, true>), dim3(Dg.save_blocks + nchunk_blocks()), dim3(BLOCK), 0, stream, Dg, f);
+                    } else
+                        hipLaunchKernelGGL((k_g2p_p2g<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dg, f);
+                    p2g_done_frame = f + 1;
+                } else if (save_in_g2p) {
                     DevSim<R> Dg = D;
                     if (fk_rides_g2p) { Dg.fk_ride = D.P; Dg.fk_stride = (size_t)cfg.max_frames * 13; }
                     Dg.save_ck = ck_slot(f);
@@ -1866,6 +1918,21 @@ template <class R> struct Sim final : ISim {
         }
     }
     int nhits_zero_frame = -1;           // forward frame whose hit counter is known to be empty (k_g2p<R, true> of the frame before emptied it)
+    int fused_fwd_env = getenv("SMAC_FUSED_FWD") ? atoi(getenv("SMAC_FUSED_FWD")) : 1;
+    int fwd_hint = -1;                   // substep the caller runs next (-1: unknown; smac_substeps announces it)
+    int p2g_done_frame = -1;             // substep whose P2G already ran inside the G2P launch of the substep before it
+    void hint_forward_next(int f) override { fwd_hint = f; }
+    // A P2G that ran ahead (k_g2p_p2g) and whose substep is not the next thing to happen: what it left in the slabs is overwritten by the next P2G, what it
+    // added to D.vdrift and to the hit counter is taken back here.  (Only an error between two substeps of smac_substeps gets here.)
+    int leave_fused_forward() {
+        if (p2g_done_frame < 0) return SMAC_OK;
+        p2g_done_frame = -1;
+        nhits_zero_frame = -1;
+        HIP_TRY(hipMemsetAsync(vdrift, 0, D.G * sizeof(Vec4<R>), stream));
+        HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(d_nhits + 4, 0, sizeof(int), stream));
+        return SMAC_OK;
+    }
     int bwd_hint = -1;                   // frame the caller will reverse next (-1: unknown)
     int g2p_done_frame = -1;             // substep whose restore + g2p.grad already ran inside the previous call
     bool g2p_done_paz = false;           // ... and whether its adjoint frame started from zero
@@ -1888,7 +1955,7 @@ template <class R> struct Sim final : ISim {
     int substep_grad_phase(int f, const double* action, const double* ext_f_grad, double* action_grad_out, int phase) {
         int rc;
         ++launch_counter;
-        if ((rc = need_grad())) return rc;
+        if ((rc = need_grad()) || (rc = leave_fused_forward())) return rc;
         D.nhits = d_nhits;                   // (the backward pass uses one counter; the forward pass re-binds and re-empties its pair)
         nhits_zero_frame = -1;
         if (phase <= 0) fk_grad_rode = false;
@@ -2949,7 +3016,9 @@ int smac_substep_grad(smac_handle h, int f, const double* action, const double* 
 int smac_substeps(smac_handle h, int f0, int count) {
     if (!h) return SMAC_ERR_INVALID;
     for (int i = 0; i < count; ++i) {
+        h->impl->hint_forward_next(i + 1 < count ? f0 + i + 1 : -1);   // lets substep f0 + i run the next substep's P2G inside its G2P launch (k_g2p_p2g)
         int rc = h->impl->substep(f0 + i, nullptr);
+        h->impl->hint_forward_next(-1);
         if (rc) return rc;
     }
     return SMAC_OK;

@@ -52,11 +52,11 @@ def test_two_rank_strong_scaling_bench_through_the_launcher():
     """2 ranks on the one GPU of the test box (gloo staging, SMAC_FORCE_DEVICE=0): the strong-scaling slab path end to end.  Two ranks cannot
     share one device under RCCL, so this leg drives the Python SlabRunner (`--slab-runner python`); the in-library RCCL runner that `--gpus N`
     uses by default is exercised on one GPU by tests/test_gpu_slab_lib.py (world-1 self exchange)."""
-    r = _run(["--gpus", "2", "--steps", "12", "--warmup", "2", "--repeats", "1", "--particles", "65536", "--grid", "64", "--no-cpu-baseline",
+    r = _run(["--gpus", "2", "--steps", "12", "--warmup", "2", "--repeats", "2", "--sort-interval", "12", "--particles", "65536", "--grid", "64", "--no-cpu-baseline",
               "--slab-runner", "python"],
              env={"SMAC_DIST_BACKEND": "gloo", "SMAC_FORCE_DEVICE": "0"}, timeout=900)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert sum(d["config"]["particles_per_gpu"]) == 65536
-    assert d["config"]["resorts_in_window"] >= 1
+    assert d["config"]["resorts_in_windows"] >= 1

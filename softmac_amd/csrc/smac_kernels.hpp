@@ -46,6 +46,9 @@ namespace smac {
 #ifndef SMAC_OCC_P2G
 #define SMAC_OCC_P2G 6
 #endif
+#ifndef SMAC_G2P_ROLLED
+#define SMAC_G2P_ROLLED 1        // the G2P gather with its x-planes as a real loop: 9 records live instead of 27, k_g2p 115 -> 88 and k_g2p_p2g 121 -> 96 VGPRs, 5 waves per SIMD (profiles/r04_ad_forward_variants.txt; 0: the unrolled form)
+#endif
 #ifndef SMAC_PHASE_CLOCK
 #define SMAC_PHASE_CLOCK 0       // 1 (tools/phase_clock.sh only): 1 workgroup in 16 of the particle kernels files s_memtime at its phase boundaries
 #endif
@@ -962,12 +965,11 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
-    Vec4<R> acc = D.vin[cell];
+    Vec4<R> acc = *(phase != 2 ? D.vdrift + cell : D.vin + cell);                       // (one load through a selected pointer: what P2G added with global atomics, or {m,p})
     if (phase != 2) {
-        acc = D.vdrift[cell];                                                           // what P2G added with global atomics ...
         if (acc.x != R(0) || acc.y != R(0) || acc.z != R(0) || acc.w != R(0)) {
             const Vec4<R> z0 = {R(0), R(0), R(0), R(0)};
-            D.vdrift[cell] = z0;                                                        // ... consumed: the field is all zero again
+            D.vdrift[cell] = z0;                                                        // consumed: the field is all zero again
         }
         slab_reduce(D, b, l, acc);
         D.vin[cell] = acc;
@@ -1157,6 +1159,36 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
     // a selected pointer - 27 flat_load per particle also for the waves that never leave LDS (found in the ISA, round 2).
     auto gather = [&](auto mixed_tag) {
         constexpr bool MIXED = decltype(mixed_tag)::value;
+#if SMAC_G2P_ROLLED
+        // x-planes as a REAL loop (9 records live instead of 27), the plane's x weight / offsets rotating through registers as in p2g_grad_particle
+        R wxi = st.w[0][0], wx1 = st.w[1][0], wx2 = st.w[2][0];
+        int cxi = nd.cx[0], cx1 = nd.cx[1], cx2 = nd.cx[2];
+        int txi = nd.tx[0], tx1 = nd.tx[1], tx2 = nd.tx[2];
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+            R s0[3] = {R(0), R(0), R(0)}, sy[3] = {R(0), R(0), R(0)}, sz[3] = {R(0), R(0), R(0)};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Vec4<R> g0, g1, g2;
+                if (MIXED && !all_in) {
+                    g0 = gld(D.vout, (unsigned)(cxi + nd.cy[j] + nd.cz[0])); g1 = gld(D.vout, (unsigned)(cxi + nd.cy[j] + nd.cz[1])); g2 = gld(D.vout, (unsigned)(cxi + nd.cy[j] + nd.cz[2]));
+                } else { g0 = gt[txi + nd.ty[j] + nd.tz[0]]; g1 = gt[txi + nd.ty[j] + nd.tz[1]]; g2 = gt[txi + nd.ty[j] + nd.tz[2]]; }
+                const R r0[3] = {st.w[0][2] * g0.x + st.w[1][2] * g1.x + st.w[2][2] * g2.x, st.w[0][2] * g0.y + st.w[1][2] * g1.y + st.w[2][2] * g2.y,
+                                 st.w[0][2] * g0.z + st.w[1][2] * g1.z + st.w[2][2] * g2.z};
+                const R r1[3] = {wz1 * g1.x + wz2 * g2.x, wz1 * g1.y + wz2 * g2.y, wz1 * g1.z + wz2 * g2.z};
+                const R wyj = st.w[j][1];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { s0[c] += wyj * r0[c]; sz[c] += wyj * r1[c]; }
+                if (j == 1) { for (int c = 0; c < 3; ++c) sy[c] += wy1 * r0[c]; }
+                if (j == 2) { for (int c = 0; c < 3; ++c) sy[c] += wy2 * r0[c]; }
+            }
+            const R fi = R(i);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { M0[c] += wxi * s0[c]; My[c] += wxi * sy[c]; Mz[c] += wxi * sz[c]; Mx[c] += fi * wxi * s0[c]; }
+            wxi = wx1; wx1 = wx2; cxi = cx1; cx1 = cx2; txi = tx1; tx1 = tx2;
+        }
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             R s0[3] = {R(0), R(0), R(0)}, sy[3] = {R(0), R(0), R(0)}, sz[3] = {R(0), R(0), R(0)};

@@ -68,9 +68,15 @@ def test_fused_forward_step_equals_the_two_kernels(precision, batches, sort_inte
         out.append((states, ext, hits, grads, pgrad))
     (sa, ea, ha, ga, pa), (sb, eb, hb, gb, pb) = out
     # same arithmetic in the same order per particle; what differs is the order in which a chunk's particles reach the LDS tile (integers in f32 mode: none)
-    tol = 1e-12 if precision == "float64" else 2e-6
+    # (the hit lists - hence the contact corrections' f64 sums - arrive in another order: the float64 leg is the sharp one, the float32 leg carries the
+    #  parity suite's own bound, per field)
+    tol = 1e-12 if precision == "float64" else H.F32_TOL["state"]
+    worst = 0.0
     for g, (a, b) in enumerate(zip(sa, sb)):
-        assert _rel(a, b) <= tol, ("state frame", 3 * g, _rel(a, b))
+        for c0, c1 in ((0, 3), (3, 6), (6, 15), (15, 24)):
+            worst = max(worst, _rel(a[:, c0:c1], b[:, c0:c1]))
+            assert _rel(a[:, c0:c1], b[:, c0:c1]) <= tol, ("state frame", 3 * g, "columns", c0, c1, _rel(a[:, c0:c1], b[:, c0:c1]))
+    H.note(f"fused forward vs plain, {precision}, worst field error over the frames", worst, tol)
     assert ha == hb, (ha, hb)
     if ea is not None:
         assert _rel(ea, eb) <= (1e-10 if precision == "float64" else 1e-5), _rel(ea, eb)

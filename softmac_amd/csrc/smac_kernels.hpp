@@ -147,6 +147,7 @@ template <class R> struct DevSim {
     size_t fk_stride;            // fk_ride workgroups) of that many velocity-controlled primitives (primitive_base.py:280-283, mpm_simulator.py:329-331, 367-369)
     int* nhits_next;             // the hit counter of the NEXT substep (two counters alternate by frame parity): emptied here while this frame's is still read
     struct Hit* hits_next;       // ... and the NEXT substep's hit list (k_g2p_p2g: P2G of substep f + 1 appends to it while the save part copies this substep's)
+    int keep_vmix;               // k_grid_op also stores grid_v_mixed (the slab phases' halo exchange sends v_out - v_mixed); otherwise it is recomputed where it is read
     int zero_next_hits;          // k_grid_op: empty the next substep's counter (its P2G rides in this substep's G2P launch and appends right away)
     ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
 };
@@ -156,6 +157,7 @@ template <class R> struct DevSim {
 // slab in HBM; the grid kernels then sum, per node, the <= 8 slabs that overlap it.  Particles that
 // drifted out of their block since the last sort fall back to global atomics on the dense arrays.
 constexpr int TW = 6, TSY = 6, TSX = 36, TILE_WORDS = 216;
+constexpr int CK_WORDS = 128;    // grid checkpoint: [active slot][{m,p} | v_out][64 cells] (v_mixed is recomputed from {m,p}: grid_v_mixed_at)
 __device__ __forceinline__ int tile_index(int li, int lj, int lk) { return li * TSX + lj * TSY + lk; }
 // WIDE tile of the particle kernels (round 4): the same 6^3 plus ONE node of slack on either side, 8x8x8 nodes with origin 4*block - 1.  A particle that
 // crossed a block face since the last sort (they jitter across the faces: 1-2 % of them by the end of a re-sort interval, i.e. a lane in nearly EVERY
@@ -627,14 +629,14 @@ __device__ __forceinline__ void grid_save_block(const DevSim<R>& D, int nblocks,
     if (a >= D.nactive) return;
     const int l = threadIdx.x & 63;
     const size_t cell = (size_t)D.active[a] * 64 + l;
-    Vec4<R>* dst = ck + (size_t)a * 192 + l;
+    Vec4<R>* dst = ck + (size_t)a * CK_WORDS + l;
     const Vec4<R> in = D.vin[cell];
     if (D.ck_flags) {                                                    // (a wave = a block)
         const bool empty = __ballot(in.x != R(0) || in.y != R(0) || in.z != R(0) || in.w != R(0)) == 0ull;
         if (l == 0) D.ck_flags[a] = empty ? 1 : 0;
         if (empty) return;                                               // no mass: grid_op left v_mixed = v_out = 0 there, {m,p} is zero already
     }
-    dst[0] = in; dst[64] = D.vmix[cell]; dst[128] = D.vout[cell];
+    dst[0] = in; dst[64] = D.vout[cell];
     // ({m, p} stays as it is: the next substep's k_grid_op overwrites it; what P2G adds with global atomics goes to D.vdrift)
 }
 template <class R>
@@ -652,10 +654,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
     if (a >= D.nactive) return;
     const int l = threadIdx.x & 63;
     const size_t cell = (size_t)D.active[a] * 64 + l;
-    const Vec4<R>* src = ck + (size_t)a * 192 + l;
+    const Vec4<R>* src = ck + (size_t)a * CK_WORDS + l;
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-    if (D.ck_flags && D.ck_flags[a]) { D.vin[cell] = z; D.vmix[cell] = z; D.vout[cell] = z; }        // a block that held no mass: nothing was filed
-    else { D.vin[cell] = src[0]; D.vmix[cell] = src[64]; D.vout[cell] = src[128]; }
+    if (D.ck_flags && D.ck_flags[a]) { D.vin[cell] = z; D.vout[cell] = z; }        // a block that held no mass: nothing was filed
+    else { D.vin[cell] = src[0]; D.vout[cell] = src[64]; }
     D.aout[cell] = z;                                // g2p.grad's drifted lanes add to it
     if (zero_all) { D.ain[cell] = z; D.amix[cell] = z; }   // (the fused backward grid pass writes every grid_v_in.grad and never reads grid_v_mixed.grad)
 }
@@ -937,6 +939,21 @@ __device__ __forceinline__ void cell_ijk(int nb, unsigned cell, int& i, int& j, 
     k = 4 * (b % nb) + (l & 3);
 }
 
+// grid_v_mixed at one node from its {m, p} (grid_op_mixed1 :399-403; the same expressions as k_grid_op).  The field itself is only stored for the slab phases:
+// the contact kernels - the only readers - have the node's {m, p} in hand anyway, so the whole-substep path neither writes, files nor restores it (round 4:
+// 16 MB less per substep pair in the grid passes, which run at the bandwidth of their 16-byte accesses).
+template <class R> __device__ __forceinline__ Vec4<R> grid_v_mixed_at(const DevSim<R>& D, const Vec4<R>& in, unsigned cell) {
+    Vec4<R> o = {R(0), R(0), R(0), R(0)};
+    if (!(in.x > D.m_eps)) return o;
+    const R inv = R(1) / in.x;
+    R v[3] = {inv * in.y + D.dt * D.g[0], inv * in.z + D.dt * D.g[1], inv * in.w + D.dt * D.g[2]};
+    int i, j, k;
+    cell_ijk(D.nb, cell, i, j, k);
+    boundary(D, i, j, k, v);
+    o.x = v[0]; o.y = v[1]; o.z = v[2];
+    return o;
+}
+
 // one thread per cell of an active block; returns false past the end
 template <class R> __device__ __forceinline__ bool active_cell(const DevSim<R>& D, int& b, int& l, size_t& cell, int& i, int& j, int& k) {
     const int a = active_slot(D);
@@ -978,7 +995,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
     const R m = acc.x;
     if (!(m > D.m_eps)) {                                                             // :286 / :399: no velocity on this node
-        if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = z;                       // (written, so the fields need no clear)
+        if (D.collision_type == CONTACT_MIXED && D.keep_vmix) D.vmix[cell] = z;        // (written, so the fields need no clear)
         D.vout[cell] = z;
         return;
     }
@@ -997,7 +1014,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     }
     boundary(D, i, j, k, v);
     const Vec4<R> o = {v[0], v[1], v[2], R(0)};
-    if (D.collision_type == CONTACT_MIXED) D.vmix[cell] = o;                            // :403
+    if (D.collision_type == CONTACT_MIXED && D.keep_vmix) D.vmix[cell] = o;             // :403 (see grid_v_mixed_at)
     D.vout[cell] = o;                                                                   // :404 / :297
 }
 
@@ -1055,8 +1072,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         Vec4<R> vm = {R(0), R(0), R(0), R(0)};
         bool has = false;
         if (mask && d < 27) {
-            vm = gld(D.vmix, cell);
-            has = gld(D.vin, cell).x > D.m_eps;
+            const Vec4<R> in_n = gld(D.vin, cell);
+            vm = grid_v_mixed_at(D, in_n, cell);
+            has = in_n.x > D.m_eps;
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2
 #pragma unroll
@@ -1597,10 +1615,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, G
         if (a >= D.nactive) return;
         const int l = threadIdx.x & 63;
         const size_t cell = (size_t)D.active[a] * 64 + l;
-        const Vec4<R>* src = ck + (size_t)a * 192 + l;
+        const Vec4<R>* src = ck + (size_t)a * CK_WORDS + l;
         const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-        if (D.ck_flags_next && D.ck_flags_next[a]) { nx.vin[cell] = z; nx.vmix[cell] = z; nx.vout[cell] = z; }
-        else { nx.vin[cell] = src[0]; nx.vmix[cell] = src[64]; nx.vout[cell] = src[128]; }
+        if (D.ck_flags_next && D.ck_flags_next[a]) { nx.vin[cell] = z; nx.vout[cell] = z; }
+        else { nx.vin[cell] = src[0]; nx.vout[cell] = src[64]; }
         nx.aout[cell] = z;                               // g2p.grad's drifted lanes add to it
     }
 }
@@ -1651,9 +1669,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
         Vec4<R> vm = {R(0), R(0), R(0), R(0)}, G = {R(0), R(0), R(0), R(0)}, vin_n = {R(0), R(0), R(0), R(0)};
         R has = R(0);
         if (mask && d < 27) {
-            vm = gld(D.vmix, cell);
             G = gld(D.aout, cell);
             vin_n = gld(D.vin, cell);
+            vm = grid_v_mixed_at(D, vin_n, cell);
             has = vin_n.x > D.m_eps ? R(1) : R(0);
         }
         R v_tmp[3] = {wn * vm.x, wn * vm.y, wn * vm.z};                                     // mixed2 forward

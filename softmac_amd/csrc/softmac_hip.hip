@@ -354,6 +354,7 @@ template <class R> struct Sim final : ISim {
         D.vdrift = vdrift;
         D.hits_next = d_hits2;
         D.zero_next_hits = 0;
+        D.keep_vmix = 0;
         HIP_TRY(hipMalloc((void**)&d_pmask, (size_t)D.Npad * sizeof(int)));
         D.nhits = d_nhits;
         D.nhits_next = d_nhits + 4;
@@ -1679,6 +1680,7 @@ template <class R> struct Sim final : ISim {
             }
         }
         prof_begin(K_GRID_OP);
+        Dc.keep_vmix = stage != 0 ? 1 : 0;                      // the slab phases send v_out - v_mixed across the slab boundaries after the contact pass
         Dc.zero_next_hits = fuse_next ? 1 : 0;
         Dc.fk_ride = 0;
         if (fk_in_grid_op) { Dc.fk_ride = D.P; Dc.fk_stride = (size_t)cfg.max_frames * 13; }
@@ -1705,7 +1707,7 @@ template <class R> struct Sim final : ISim {
         if (!ck_arena && !ck_tried) {
             ck_tried = true;
             ck_slot_blocks = (size_t)D.nactive + D.nactive / 4 + 64;
-            const size_t bytes = (size_t)cfg.max_frames * ck_slot_blocks * 192 * sizeof(Vec4<R>);
+            const size_t bytes = (size_t)cfg.max_frames * ck_slot_blocks * CK_WORDS * sizeof(Vec4<R>);
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2 ||
                 hipMalloc((void**)&ck_arena, bytes) != hipSuccess) {
@@ -1734,7 +1736,7 @@ template <class R> struct Sim final : ISim {
         }
         return ck_arena != nullptr && (size_t)D.nactive <= ck_slot_blocks;
     }
-    Vec4<R>* ck_slot(int f) { return ck_arena + (size_t)f * ck_slot_blocks * 192; }
+    Vec4<R>* ck_slot(int f) { return ck_arena + (size_t)f * ck_slot_blocks * CK_WORDS; }
 
     // substep :320-337.  phase -1: whole substep; 0 / 1 / 2: the three pieces between which the slab decomposition
     // exchanges halo planes (after 0: {m,p}; after 1: the contact corrections of v_out).

@@ -556,6 +556,7 @@ template <class R> struct Sim final : ISim {
     int reset(const double* state, int cols) override {                       // mpm_simulator.py:494-519
         REQUIRE(state && (cols == 3 || cols == 24), "reset: cols must be 3 or 24");
         int rc;
+        p2g_done_frame = 0;                                                   // (a new episode: D.vdrift all zero whatever an aborted one left on blocks nobody swept)
         if ((rc = leave_fused_forward())) return rc;
         frame_epoch[0] = 0;                                                   // user data: identity order, re-binned at the next substep
         ck_epoch[0] = -1;

@@ -19,7 +19,9 @@ NAMES = {"k_p2g<float, true, false>": "p2g", "k_p2g_grad<float, false, true>": "
          # round 3: the checkpoint save rides in k_g2p's launch, the next restore in the grid-adjoint reduction's
          "k_g2p<float, false>": "g2p", "k_g2p<float, true>": "g2p", "k_reduce_grid_grad_ahead<float>": "reduce_agvout",
          # round 4: the two-entry material table added a template parameter (false = one material, the benchmarked instantiations)
-         "k_p2g<float, true, false, false>": "p2g", "k_p2g_grad<float, false, true, false>": "p2g_grad"}
+         "k_p2g<float, true, false, false>": "p2g", "k_p2g_grad<float, false, true, false>": "p2g_grad",
+         # round 4: G2P of substep f + P2G of substep f+1 in one launch (with the checkpoint save in its first workgroups)
+         "k_g2p_p2g<float, true>": "g2p_p2g", "k_g2p_p2g<float, false>": "g2p_p2g"}
 
 
 def mean_by_kernel(path, counter):

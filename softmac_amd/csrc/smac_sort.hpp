@@ -250,6 +250,14 @@ __global__ void k_compose(int N, const int* orig_to, const int* inv_from, int* m
     if (q < N) map[q] = inv_from[orig_to[q]];
 }
 
+// what the host needs of a re-sort, in ONE write to pinned host memory: the chunk and active-block totals, the fastest particle's speed, the drift
+// flags of the epoch that ends (four hipMemcpyAsync to pageable memory cost 25 us of host round trip each, the GPU idle: profiles/r04_ah_sort_host.txt)
+__global__ void k_sort_info(const int* chunk_total, const int* active_total, const unsigned* vmax, const int* drift, int read_drift, int* host_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    host_out[0] = *chunk_total; host_out[1] = *active_total; host_out[2] = (int)*vmax;
+    for (int i = 0; i < 4; ++i) host_out[3 + i] = read_drift ? drift[i] : 0;      // (the host reads after synchronising with the stream)
+}
+
 // per block: particle count (from the scanned bins), number of chunks, halo flags
 __global__ void k_block_info(int nblocks, int nb, const int* bin_start, int N, int* block_start, int* block_chunks,
                              int* active_flag) {
@@ -274,12 +282,18 @@ __global__ void k_block_info(int nblocks, int nb, const int* bin_start, int N, i
 }
 
 // write the chunk list (chunk_start = exclusive scan of block_chunks) and the compacted active list
+// (also: the epoch's own copies of the four per-block tables - four device-to-device copies of 128 KB each cost the host 8 us apiece right after the
+//  re-sort's synchronisation, with the GPU idle; `chunk_cap`: the chunk list's capacity - the host checks the total AFTER this kernel has run)
 __global__ void k_emit_lists(int nblocks, int N, const int* bin_start, const int* block_start, const int* block_chunks,
                              const int* chunk_start, const int* active_flag, const int* active_start, Chunk* chunks,
-                             int* active) {
+                             int* active, int chunk_cap, int* ep_chunk_start, int* ep_block_chunks, int* ep_block_active, int* ep_block_slot) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nblocks) {
+        ep_chunk_start[b] = chunk_start[b]; ep_block_chunks[b] = block_chunks[b];
+        ep_block_active[b] = active_flag[b]; ep_block_slot[b] = active_start[b];
+    }
     if (b >= nblocks) return;
-    const int nch = block_chunks[b];
+    const int nch = chunk_start[b] + block_chunks[b] <= chunk_cap ? block_chunks[b] : 0;
     if (nch > 0) {
         const int s = block_start[b];
         const int e = (b + 1 < nblocks) ? bin_start[(b + 1) * KMAX] : N;

@@ -207,6 +207,8 @@ template <class R> struct Sim final : ISim {
     R* tmp_frame2 = nullptr;        // second one, allocated when the adjoints of frames f AND f+1 both arrive in another particle order
     Vec4<R>* slab = nullptr;
     size_t slab_chunks = 0;
+    int* h_sort_info = nullptr;      // pinned: what sort_frame reads back of a re-sort (k_sort_info)
+    int* last_dest = nullptr;        // the destination map of the latest re-sort (statistics)
     Hit* d_hits = nullptr;           // capacity Npad
     Hit* d_hits2 = nullptr;          // the hit list of odd frames (k_g2p_p2g appends the next substep's hits while this substep's list is filed)
     Vec4<R>* vdrift = nullptr;       // DevSim::vdrift
@@ -281,6 +283,7 @@ template <class R> struct Sim final : ISim {
         hipFree(d_mat_id);
         hipFree(d_hits); hipFree(d_hits2); hipFree(vdrift); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
         if (h_nhits) hipHostFree(h_nhits);
+        if (h_sort_info) hipHostFree(h_sort_info);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
             if ((void*)prim_tables64[i][0] != (void*)prim_tables[i][0]) { hipFree(prim_tables64[i][0]); hipFree(prim_tables64[i][1]); }
             hipFree(prim_tables[i][0]); hipFree(prim_tables[i][1]);
@@ -403,6 +406,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&d_map, D.Npad * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_block_start, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_block_chunks, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_block_chunks, 0, (nblocks + 1) * sizeof(int), stream));        // (entry [nblocks] stays 0: the scans read one element past the blocks)
         HIP_TRY(hipMalloc((void**)&d_chunk_start, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_active_flag, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_active_start, (nblocks + 1) * sizeof(int)));
@@ -412,6 +416,8 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(d_drift, 0, 4 * sizeof(int), stream));
         HIP_TRY(hipHostMalloc((void**)&h_nhits, (size_t)c.max_frames * sizeof(int), hipHostMallocDefault));
         for (int i = 0; i < c.max_frames; ++i) h_nhits[i] = -1;
+        HIP_TRY(hipHostMalloc((void**)&h_sort_info, 16 * sizeof(int), hipHostMallocDefault));
+        memset(h_sort_info, 0, 16 * sizeof(int));
         D.slab_base_lo = 1; D.slab_base_hi = 0;                        // no slab range check until smac_comm_slab / smac_set_slab_range says so
         D.drift_flag = d_drift;
         epochs.clear();
@@ -1090,8 +1096,9 @@ template <class R> struct Sim final : ISim {
         if ((rc = epoch_buffers(ep))) return rc;
         hipLaunchKernelGGL(k_sort_dest, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_key, (const int*)d_slot, (const int*)d_cell_count,
                            (const int*)d_bin_start, (const unsigned long long*)d_bin_mask, (const int*)d_over_prefix,
-                           (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), d_dest, ep.orig, D.G <= ((size_t)1 << 26) ? ep.cellrank : (int*)nullptr);
-        HIP_TRY(hipMemcpyAsync(ep.from_prev, d_dest, (size_t)D.N * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                           (const int*)(e_old > 0 ? epochs[e_old].orig : nullptr), ep.from_prev, ep.orig, D.G <= ((size_t)1 << 26) ? ep.cellrank : (int*)nullptr);
+        int* const d_dest = ep.from_prev;                          // (the destination map is written where the epoch keeps it: no copy)
+        last_dest = d_dest;
         ep.prev = e_old;
         ep.prev_serial = e_old > 0 ? epochs[e_old].serial : -1;
         ep.serial = ++epoch_serial;
@@ -1110,20 +1117,24 @@ template <class R> struct Sim final : ISim {
         }
         ++resorts_done;
         // block info, chunk list, active list
-        HIP_TRY(hipMemsetAsync(d_active_flag, 0, (nblocks + 1) * sizeof(int), stream));
-        HIP_TRY(hipMemsetAsync(d_block_chunks, 0, (nblocks + 1) * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(d_active_flag, 0, (nblocks + 1) * sizeof(int), stream));      // (d_block_chunks: k_block_info writes every entry, [nblocks] stays 0)
         hipLaunchKernelGGL(k_block_info, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.nb, (const int*)d_bin_start, D.N,
                            d_block_start, d_block_chunks, d_active_flag);
         if ((rc = scan(d_block_chunks, d_chunk_start, nblocks + 1))) return rc;
         if ((rc = scan(d_active_flag, d_active_start, nblocks + 1))) return rc;
-        int totals[2];
-        unsigned vbits = 0;
-        HIP_TRY(hipMemcpyAsync(&totals[0], d_chunk_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(&totals[1], d_active_start + nblocks, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(&vbits, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        int flags2[4] = {0, 0, 0, 0};
-        if (read_drift) HIP_TRY(hipMemcpyAsync(flags2, d_drift, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        // the chunk and active lists and the epoch's per-block tables are written BEFORE the host has the totals (k_emit_lists guards the chunk list's
+        // capacity itself), and the host gets what it needs - totals, the fastest speed, the ending epoch's drift flags - in one write to pinned memory:
+        // after the synchronisation nothing of the re-sort is left to enqueue
+        hipLaunchKernelGGL(k_emit_lists, dim3(nblk(nblocks + 1)), dim3(BLOCK), 0, stream, nblocks, D.N, (const int*)d_bin_start,
+                           (const int*)d_block_start, (const int*)d_block_chunks, (const int*)d_chunk_start,
+                           (const int*)d_active_flag, (const int*)d_active_start, ep.chunks, ep.active, (int)chunk_capacity(),
+                           ep.block_chunk_start, ep.block_chunks, ep.block_active, ep.block_slot);
+        hipLaunchKernelGGL(k_sort_info, dim3(1), dim3(64), 0, stream, (const int*)(d_chunk_start + nblocks), (const int*)(d_active_start + nblocks),
+                           (const unsigned*)d_vmax, (const int*)d_drift, read_drift ? 1 : 0, h_sort_info);
         HIP_TRY(hipStreamSynchronize(stream));
+        const int totals[2] = {((volatile int*)h_sort_info)[0], ((volatile int*)h_sort_info)[1]};
+        const unsigned vbits = (unsigned)((volatile int*)h_sort_info)[2];
+        int flags2[4] = {((volatile int*)h_sort_info)[3], ((volatile int*)h_sort_info)[4], ((volatile int*)h_sort_info)[5], ((volatile int*)h_sort_info)[6]};
         // a drift error of the epoch that ends here is reported AFTER the new epoch is committed: S[f] is already in the
         // new order, so frame_epoch[f] must name it or every later get_state / set_frame of this frame would be scrambled
         const int drifted = flags2[0];
@@ -1145,13 +1156,6 @@ template <class R> struct Sim final : ISim {
             err = "internal: chunk list capacity exceeded";
             return SMAC_ERR_INVALID;
         }
-        hipLaunchKernelGGL(k_emit_lists, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.N, (const int*)d_bin_start,
-                           (const int*)d_block_start, (const int*)d_block_chunks, (const int*)d_chunk_start,
-                           (const int*)d_active_flag, (const int*)d_active_start, ep.chunks, ep.active);
-        HIP_TRY(hipMemcpyAsync(ep.block_chunk_start, d_chunk_start, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(ep.block_chunks, d_block_chunks, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(ep.block_active, d_active_flag, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(ep.block_slot, d_active_start, (nblocks + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
         prof_end();
         ep.frame = f;
         ep.live = true;
@@ -1275,8 +1279,9 @@ template <class R> struct Sim final : ISim {
         if (launches_seen == launch_counter) return SMAC_OK;
         launches_seen = launch_counter;
         int h[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(h, d_drift, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_sort_info + 8, d_drift, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));     // (pinned destination: a DMA, not a staged copy)
         HIP_TRY(hipStreamSynchronize(stream));
+        for (int i = 0; i < 4; ++i) h[i] = ((volatile int*)h_sort_info)[8 + i];
         if (h[0] || h[1] || h[2]) HIP_TRY(hipMemsetAsync(d_drift, 0, 4 * sizeof(int), stream));
         int rc;
         if (h[1] && (rc = hit_overflow())) return rc;
@@ -1349,9 +1354,9 @@ template <class R> struct Sim final : ISim {
         else if (!strcmp(name, "resorts")) *value = (double)resorts_done;                // re-binnings so far (the first one, at reset, included)
         else if (!strcmp(name, "resort_moved") || !strcmp(name, "resort_far")) {         // particles the LAST re-binning moved to another slot / by more than a chunk (256 slots); counted on request
             unsigned long long h = 0;
-            if (resorts_done > 0 && D.N > 0) {
+            if (resorts_done > 0 && D.N > 0 && last_dest) {
                 HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), stream));
-                hipLaunchKernelGGL(k_count_moved, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)d_dest, d_counter, !strcmp(name, "resort_far") ? 256 : 0);
+                hipLaunchKernelGGL(k_count_moved, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, D.N, (const int*)last_dest, d_counter, !strcmp(name, "resort_far") ? 256 : 0);
                 HIP_TRY(hipMemcpyAsync(&h, d_counter, sizeof(h), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
             }

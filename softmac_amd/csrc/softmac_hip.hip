@@ -234,7 +234,6 @@ template <class R> struct Sim final : ISim {
     unsigned char* ck_flags_of(int f) { return (ck_empty && ck_skip_empty) ? ck_empty + (size_t)f * ck_slot_blocks : (unsigned char*)nullptr; }
     size_t ck_slot_blocks = 0;       // capacity of a slot in grid blocks
     bool ck_enabled = true, ck_tried = false;
-    bool vin_clean = false;          // {m,p} of every active block is zero (saves the clear pass before P2G)
     // (The forward grid reaches the checkpoint through copy work riding in k_g2p's launch and comes back through the restore riding in the grid-adjoint
     // reduction's.  Writing / reading the checkpoint in place was measured in round 2 and was slower or equal: profiles/r02_x_checkpoint_in_place.txt.)
     std::vector<int> ck_epoch;       // epoch the slot of frame f was saved in (-1: invalid)
@@ -1187,7 +1186,6 @@ template <class R> struct Sim final : ISim {
             Do.nactive = epochs[grid_epoch].nactive;
             hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 6);
         }
-        if (e != grid_epoch) vin_clean = false;              // (the old epoch's blocks were zeroed just above; the rest always is)
         grid_epoch = e;
         const Epoch& ep = epochs[e];
         D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
@@ -1657,7 +1655,6 @@ template <class R> struct Sim final : ISim {
                 hipLaunchKernelGGL(k_clear_active<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D, grid_block, 6);
                 prof_end();
             }
-            vin_clean = false;
             prof_begin(K_P2G);
             const bool pcon = D.collision_type == CONTACT_PARTICLE && D.any_contact;
             if (D.mat_id) {                                     // two-entry material table: its own instantiation (set_material_ids refuses penalty contact)
@@ -1820,7 +1817,6 @@ template <class R> struct Sim final : ISim {
                 }
                 ck_epoch[f] = e;
                 ck_gen[f] = config_gen;
-                vin_clean = true;
             }
             if (D.nchunks > 0) {
                 prof_begin(fuse_next ? K_G2P_P2G : K_G2P);
@@ -1922,7 +1918,6 @@ template <class R> struct Sim final : ISim {
         hits_in_place_frame = -1;
         if (grid_set != 0) {
             use_grid_set(0);
-            vin_clean = false;
         }
     }
     int nhits_zero_frame = -1;           // forward frame whose hit counter is known to be empty (k_g2p<R, true> of the frame before emptied it)
@@ -2041,7 +2036,6 @@ template <class R> struct Sim final : ISim {
                 D.cur_frame = f;
                 prof_begin(K_CKPT);
                 const bool have_hits = ck_has_hits[f] && D.any_contact && D.collision_type == CONTACT_MIXED;
-                vin_clean = false;
                 DevSim<R> Dk = D;
                 Dk.ck_flags = ck_flags_of(f);
                 hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dk, (const Vec4<R>*)ck_slot(f),
@@ -2135,7 +2129,6 @@ template <class R> struct Sim final : ISim {
                 prof_end();
                 adj_epoch[f - 1] = e;
                 adj_stale[f - 1] = 0;
-                vin_clean = false;
                 g2p_done_frame = f - 1;
                 g2p_done_paz = paz_prev;
             } else if (D.nchunks > 0) {

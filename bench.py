@@ -365,9 +365,12 @@ def window_plan(K, interval):
     and R >= 8 so that the GPU's clocks have settled for most of them (the first two windows after a cold start run 5-8 % slower:
     profiles/r04_z_first_pass.txt).  Every window is timed and counted - nothing is dropped, `value` comes from their sum."""
     block = math.lcm(K, max(interval, 1)) // K
-    if block * K > 640:                                       # (an interval that shares no factor with K: fall back to whole windows, share approximate)
+    if block * K > 480:                                       # (an interval that shares no factor with K: fall back to whole windows, share approximate)
         block = 1
-    return block * -(-8 // block)
+    R = block * -(-8 // block)
+    while R > block and R * K > 480:                          # every frame of the episode is resident (212 MB per frame at 1M particles): a long K gets fewer windows
+        R -= block
+    return max(R, 1)
 
 
 def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist, windows=None):

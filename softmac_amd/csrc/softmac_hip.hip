@@ -1750,7 +1750,7 @@ template <class R> struct Sim final : ISim {
         REQUIRE(frame_epoch[f] >= 0, "substep: frame f holds no state (call reset/set_frame or simulate up to it first)");
         normalize_grid_set();
         // P2G of this substep already ran inside the G2P launch of the substep before (k_g2p_p2g)?  Anything else than that substep coming next abandons it.
-        const bool p2g_done = phase < 0 && p2g_done_frame == f;
+        const bool p2g_done = phase <= 0 && p2g_done_frame == f;       // (phase 0: the slab loop's first piece is where this substep's P2G would run)
         if (!p2g_done && (rc = leave_fused_forward())) return rc;
         p2g_done_frame = -1;
         // the hit counters - and lists - of even and odd frames alternate (k_g2p<R, true> empties the next frame's counter while its save part still reads
@@ -1762,7 +1762,7 @@ template <class R> struct Sim final : ISim {
             D.hits_next = (f & 1) ? d_hits : d_hits2;
         };
         bind_hit_counters();
-        bool fuse_next = false;
+        bool fuse_next = phase > 0 && fuse_pending_frame == f;           // (decided in this substep's first piece)
         if (phase <= 0) {
             if ((rc = check_contact_supported())) return rc;
             if (action && (rc = set_action(action))) return rc;
@@ -1791,8 +1791,10 @@ template <class R> struct Sim final : ISim {
             // Fused forward step (k_g2p_p2g): the batched loop (smac_substeps) has announced that substep f + 1 follows, it keeps this binning, and nothing
             // it needs changes in between (no particle action, penalty contact, sheet or second material: those P2G instantiations stay on their own) -
             // then this substep's G2P launch also runs the next substep's P2G, and the call for f + 1 starts at k_grid_op.  SMAC_FUSED_FWD=0: off.
-            fuse_next = fused_fwd_env && phase < 0 && fwd_hint == f + 1 && f + 2 < cfg.max_frames && !repairing && D.nchunks > 0 && D.nactive > 0 &&
+            // (the slab loop's pieces take it too: G2P of substep f comes after the contact exchange of f, P2G of f + 1 before the {m,p} exchange of f + 1)
+            fuse_next = fused_fwd_env && fwd_hint == f + 1 && f + 2 < cfg.max_frames && !repairing && D.nchunks > 0 && D.nactive > 0 &&
                         f + 1 - epochs[e].frame < epochs[e].interval && D.n_control == 0 && D.collision_type != CONTACT_PARTICLE && !D.cloth.present && !D.mat_id;
+            fuse_pending_frame = fuse_next && phase == 0 ? f : -1;
             // whole substep with particles: forward_kinematics rides in k_g2p's launch instead of a launch of its own (SMAC_FK_RIDE=0: own kernel)
             fk_rides_g2p = !fuse_next && fk_ride_env && phase < 0 && cfg.rigid_velocity_control && D.P > 0 && D.nchunks > 0 && D.nactive > 0;
             if ((rc = forward_grid(f, true, false, phase < 0 ? 0 : 1, p2g_done, fuse_next))) return rc;
@@ -1924,6 +1926,7 @@ template <class R> struct Sim final : ISim {
     int fused_fwd_env = getenv("SMAC_FUSED_FWD") ? atoi(getenv("SMAC_FUSED_FWD")) : 1;
     int fwd_hint = -1;                   // substep the caller runs next (-1: unknown; smac_substeps announces it)
     int p2g_done_frame = -1;             // substep whose P2G already ran inside the G2P launch of the substep before it
+    int fuse_pending_frame = -1;         // slab pieces: the substep whose last piece (G2P) will carry the next substep's P2G
     void hint_forward_next(int f) override { fwd_hint = f; }
     // A P2G that ran ahead (k_g2p_p2g) and whose substep is not the next thing to happen: what it left in the slabs is overwritten by the next P2G, what it
     // added to D.vdrift and to the hit counter is taken back here.  (Only an error between two substeps of smac_substeps gets here.)
@@ -2378,12 +2381,14 @@ template <class R> struct Sim final : ISim {
         const bool contact = sc.contact_l || sc.contact_r;
         int rc;
         for (int f = f0; f < f0 + count; ++f) {
+            fwd_hint = f + 1 < f0 + count ? f + 1 : -1;       // lets substep f's G2P piece carry the next substep's P2G (k_g2p_p2g)
             if ((rc = substep_phase(f, nullptr, 0))) return slab_guard(rc);
             if ((rc = exchange(D.vin, nullptr, false))) return slab_guard(rc);                       // {m, p} partials after P2G
             if ((rc = substep_phase(f, nullptr, 1))) return slab_guard(rc);
             if (contact && any_contact() && (rc = exchange(D.vout, D.vmix, true))) return slab_guard(rc);   // contact corrections v_out - v_mixed
             if ((rc = substep_phase(f, nullptr, 2))) return slab_guard(rc);
         }
+        fwd_hint = -1;
         return SMAC_OK;
     }
     int substeps_slab_grad(int f0, int count, const double* ext_f_grad) override {

@@ -659,7 +659,8 @@ __global__ __launch_bounds__(BLOCK) void k_grid_restore(DevSim<R> D, const Vec4<
     if (D.ck_flags && D.ck_flags[a]) { D.vin[cell] = z; D.vout[cell] = z; }        // a block that held no mass: nothing was filed
     else { D.vin[cell] = src[0]; D.vout[cell] = src[64]; }
     D.aout[cell] = z;                                // g2p.grad's drifted lanes add to it
-    if (zero_all) { D.ain[cell] = z; D.amix[cell] = z; }   // (the fused backward grid pass writes every grid_v_in.grad and never reads grid_v_mixed.grad)
+    if (zero_all == 1) D.ain[cell] = z;                    // (the fused backward grid pass writes every grid_v_in.grad and never reads grid_v_mixed.grad;
+    if (zero_all) D.amix[cell] = z;                        //  2: grid_v_in.grad of the substep before is still to be read - the slab pieces' fused backward launch)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1975,7 +1976,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     Vec4<R> gm_ = zero4;
     if (D.collision_type == CONTACT_MIXED) gm_ = D.amix[cell];
     const R m = in.x;
-    if (!(m > D.m_eps)) return;
+    if (!(m > D.m_eps)) { D.ain[cell] = zero4; return; }     // (written, so that grid_v_in.grad needs no zeroing in front of this kernel: the slab pieces' fused backward launch)
     const R inv = R(1) / m;
     const R vin[3] = {in.y, in.z, in.w};
     R g[3] = {go.x + gm_.x, go.y + gm_.y, go.z + gm_.z};                               // grid_v_out += grid_v_mixed

@@ -1944,8 +1944,10 @@ template <class R> struct Sim final : ISim {
     bool g2p_done_paz = false;           // ... and whether its adjoint frame started from zero
     void hint_backward_next(int f) override { bwd_hint = f; }
     bool can_fuse_prev(int f, int e, int phase, const double* action_grad_out) {
-        if (!fused_pg_env || sizeof(R) != 4 || phase >= 0 || bwd_hint != f - 1 || f < 1 || action_grad_out) return false;   // (f64: 256 VGPRs + 88 KB of LDS, one workgroup per CU)
-        if (!pending_adj_zero || rolling() || !fused_grid_bwd(phase)) return false;                          // frame f carried a seed / frames come and go
+        // (phase 2: the slab loop's last piece - p2g.grad(f) and g2p.grad(f - 1) cross no exchange; its grid adjoint pass stays the three-kernel sequence)
+        if (!fused_pg_env || sizeof(R) != 4 || (phase >= 0 && phase != 2) || bwd_hint != f - 1 || f < 1 || action_grad_out) return false;   // (f64: 256 VGPRs + 88 KB of LDS, one workgroup per CU)
+        if (!pending_adj_zero || rolling()) return false;                                                   // frame f carried a seed / frames come and go
+        if (phase < 0 ? !fused_grid_bwd(phase) : (D.collision_type == CONTACT_GRID && any_contact())) return false;
         if (frame_epoch[f - 1] != e || !(adj_epoch[f - 1] < 0 || adj_epoch[f - 1] == e)) return false;        // a re-sort lies between the two substeps
         if (!(ck_arena && ck_epoch[f - 1] == e && ck_gen[f - 1] == config_gen && D.n_control == 0 && D.nchunks > 0)) return false;
         if (D.collision_type == CONTACT_PARTICLE || D.cloth.present || D.mat_id) return false;
@@ -1972,13 +1974,24 @@ template <class R> struct Sim final : ISim {
         REQUIRE(f >= 0 && f + 1 < cfg.max_frames, "substep_grad: frame f+1 exceeds max_frames");
         REQUIRE(frame_epoch[f] > 0, "substep_grad: frame f was not produced/consumed by a forward substep");
         const int e = frame_epoch[f];
-        if (g2p_done_frame >= 0 && (g2p_done_frame != f || phase >= 0)) {
+        if (g2p_done_frame >= 0 && (g2p_done_frame != f || phase > 0)) {
             g2p_done_frame = -1;
             normalize_grid_set();
             REQUIRE(false, "substep_grad: the batched backward sweep was interrupted (its next substep had been started)");
         }
-        if (!(phase < 0 && g2p_done_frame == f)) normalize_grid_set();
-        if (phase < 0 && g2p_done_frame == f) {           // restore + g2p.grad of this substep ran inside the previous call (k_p2g_g2p_grad)
+        if (!(phase <= 0 && g2p_done_frame == f)) normalize_grid_set();
+        if (phase == 0 && g2p_done_frame == f) {          // the slab loop's first piece: restore + g2p.grad ran inside the previous substep's last piece
+            g2p_done_frame = -1;
+            if ((rc = stage_ext_f_grad(ext_f_grad))) return rc;
+            D.Af = adj_ptr(f);
+            D.An = adj_ptr(f + 1);
+            D.An_map = nullptr;
+            pending_adj_zero = g2p_done_paz;
+            D.cur_frame = f;
+            prof_begin(K_REDUCE);
+            hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+            prof_end();
+        } else if (phase < 0 && g2p_done_frame == f) {    // restore + g2p.grad of this substep ran inside the previous call (k_p2g_g2p_grad)
             g2p_done_frame = -1;
             if ((rc = stage_ext_f_grad(ext_f_grad))) return rc;
             D.Af = adj_ptr(f);
@@ -2119,7 +2132,7 @@ template <class R> struct Sim final : ISim {
                     Dk.ck_flags = ck_flags_of(f - 1);
                     hipLaunchKernelGGL(k_grid_restore<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, Dk, (const Vec4<R>*)ck_slot(f - 1),
                                        have_hits ? (const Hit*)(ck_hits + (size_t)(f - 1) * ck_hit_cap) : (const Hit*)nullptr,
-                                       have_hits ? (const int*)(ck_nhits + (f - 1)) : (const int*)nullptr, 0);
+                                       have_hits ? (const int*)(ck_nhits + (f - 1)) : (const int*)nullptr, phase < 0 ? 0 : 2);
                     prof_end();
                     hits_in_place_frame = -1;
                     hits_from_ck_frame = have_hits ? f - 1 : -1;
@@ -2396,12 +2409,14 @@ template <class R> struct Sim final : ISim {
         const bool contact = sc.contact_l || sc.contact_r;
         int rc;
         for (int f = f0 + count - 1; f >= f0; --f) {
-            if ((rc = substep_grad_phase(f, nullptr, f == f0 + count - 1 ? ext_f_grad : nullptr, nullptr, 0))) return slab_guard(rc);
+            bwd_hint = f > f0 ? f - 1 : -1;                   // lets substep f's last piece carry the G2P adjoint of substep f - 1 (k_p2g_g2p_grad)
+            if ((rc = substep_grad_phase(f, nullptr, f == f0 + count - 1 ? ext_f_grad : nullptr, nullptr, 0))) { bwd_hint = -1; return slab_guard(rc); }
             if ((rc = exchange(D.aout, nullptr, false))) return slab_guard(rc);                      // grid_v_out.grad partials after g2p.grad
             if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 1))) return slab_guard(rc);
             if (contact && any_contact() && (rc = exchange(D.amix, nullptr, true))) return slab_guard(rc);   // grid_v_mixed.grad partials after the contact adjoint
-            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 2))) return slab_guard(rc);
+            if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 2))) { bwd_hint = -1; return slab_guard(rc); }
         }
+        bwd_hint = -1;
         return SMAC_OK;
     }
     // SUM over the ranks of the per-rank partial wrench sums / primitive-state adjoints, in place - once per env step, where the reference

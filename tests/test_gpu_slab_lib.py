@@ -237,3 +237,34 @@ def test_device_side_migration_round_trip(precision, tol):
     g = np.hstack(sim.get_grad(0))
     assert H.note(f"migration grad {precision}", H.rel_err(g, ref_g), tol) < tol, H.rel_err(g, ref_g)
     run.close()
+
+
+def test_the_slab_loop_takes_the_fused_particle_launches():
+    """Round 4: G2P of substep f + P2G of substep f + 1, and p2g.grad of substep f + g2p.grad of substep f - 1, cross no halo exchange - the library's slab
+    loop runs them as the single-GPU loop does (k_g2p_p2g / k_p2g_g2p_grad), its grid passes stay in pieces around the exchanges.  Same result as the
+    Python phase loop (plain kernels), and the fused launches are asserted taken.  float32 (the fused backward kernel is its own), one seed at the end."""
+    from softmac_amd.parallel import LibSlabRunner
+
+    def run(factory):
+        cfg, state, specs, pst = _scene("float32")
+        sim, prims = H.build_engine(cfg, 2e-3, specs, pst)
+        sim.reset(state)
+        r = factory(sim)
+        sim.profile(True)
+        r.run_substeps(0, NSUB)
+        sim.clear_grads()
+        s = _seeds()[NSUB]
+        sim.add_grad(NSUB, gx=s[0], gv=s[1], gC=s[2], gF=s[3])
+        r.run_substeps_grad(0, NSUB, [np.linspace(-1e-2, 1e-2, 6)])
+        counts = sim.profile_report()
+        sim.profile(False)
+        return _collect(sim, prims), counts, r
+
+    ref, c_ref, _ = run(_python_self_loop)
+    got, c_got, r = run(lambda s: LibSlabRunner(s, 0, 1, LEFT0, RIGHT0, NP, has_contact=(True, True), self_loop=True))
+    assert c_ref.get("g2p_p2g", (0, 0))[1] == 0 and c_ref.get("p2g_g2p_grad", (0, 0))[1] == 0, c_ref          # the phase entry points from Python: plain kernels
+    # sort_interval 4 over 6 substeps: substeps 0-3 and 4-5 share a binning -> fused forward launches after substeps 0, 1, 2 and 4; fused backward ones likewise
+    assert c_got.get("g2p_p2g", (0, 0))[1] == 4 and c_got.get("p2g_g2p_grad", (0, 0))[1] == 4, c_got
+    for k in ("st", "gx", "gv", "gF", "gC", "ext", "pg"):
+        assert H.rel_err(got[k], ref[k]) < 2e-5, (k, H.rel_err(got[k], ref[k]))
+    r.close()

@@ -136,8 +136,9 @@ int smac_substep(smac_handle h, int f, const double* action);
 int smac_substep_grad(smac_handle h, int f, const double* action, const double* ext_f_grad, double* action_grad_out);
 /* Batched forms: frames f0 .. f0+count-1 forward; f0+count-1 down to f0 backward.  One call, no
  * host round trip between substeps (replaces the python loops at taichi_env.py:101-102,128-131).
- * The backward form knows which substep follows: it reverses the P2G of substep f and the G2P of substep f-1 in one
- * launch where the two share a binning (results as from count calls of smac_substep_grad). */
+ * Both forms know which substep follows.  Forward: the G2P of substep f and the P2G of substep f+1 run in one launch where
+ * the two share a binning (round 4); backward: the P2G adjoint of substep f and the G2P adjoint of substep f-1 likewise
+ * (results as from count calls of smac_substep / smac_substep_grad). */
 int smac_substeps(smac_handle h, int f0, int count);
 int smac_substeps_grad(smac_handle h, int f0, int count, const double* ext_f_grad);
 /* The same with a particle action held over the window (control_mode "mpm", taichi_env.py:101-102 / :128-133): set_action once, then the
@@ -253,7 +254,8 @@ int smac_halo_unpack_add(smac_handle h, const char* field, int plane0, int nplan
  *                           whether a contact primitive can reach that side's planes (both neighbours must pass the same flag), the range of
  *                           stencil bases (x) this rank's planes cover (a particle outside it raises an error at the next sync instead of losing
  *                           its deposits); self_loop = 1 (world 1 only): left = right = this rank on periodic planes - the whole RCCL path on ONE GPU
- *   smac_substeps_slab[_grad]   count substeps forward / backward with the 2 + 2 exchanges per substep pair, no host round trip in between
+ *   smac_substeps_slab[_grad]   count substeps forward / backward with the 2 + 2 exchanges per substep pair, no host round trip in between; the fused particle
+ *                           launches of smac_substeps[_grad] are taken here too (they cross no exchange), the grid passes stay in pieces around the exchanges
  *   smac_comm_allreduce_ext_f   SUM of ext_f over the ranks in place; total_out (n_primitives, 6) or NULL; clear = the reference's clear_ext_f after the read
  *   smac_comm_allreduce_prim_grad   SUM of the primitive-state adjoints of frames [f_begin, f_end) over the ranks, in place */
 int smac_comm_unique_id(char id128[128]);

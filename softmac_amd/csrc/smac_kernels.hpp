@@ -65,6 +65,9 @@ static_assert(NCOMP == NCOMP_ROWS, "frame layout helpers (smac_math.hpp) assume 
 template <class R> struct alignas(4 * sizeof(R)) Vec4 { R x, y, z, w; };
 struct Hit { int p, mask, block, pad; };
 
+// the shared x-planes of the slab decomposition: entry s of the list = buffer slot (0 = left neighbour, 1 = right neighbour) and first plane
+struct HaloSides { int count; int slot[2]; int plane0[2]; };
+
 template <class R> struct DevSim {
     int N, Npad, n, P, n_control, substeps, collision_type, sticky, max_frames;
     R dt, inv_dx, dx, p_mass, stress_scale;
@@ -147,6 +150,13 @@ template <class R> struct DevSim {
     size_t fk_stride;            // fk_ride workgroups) of that many velocity-controlled primitives (primitive_base.py:280-283, mpm_simulator.py:329-331, 367-369)
     int* nhits_next;             // the hit counter of the NEXT substep (two counters alternate by frame parity): emptied here while this frame's is still read
     struct Hit* hits_next;       // ... and the NEXT substep's hit list (k_g2p_p2g: P2G of substep f + 1 appends to it while the save part copies this substep's)
+    // The library's slab loop, forward {m,p} exchange (round 4): k_grid_op's first piece writes the shared planes' records straight into the send buffer
+    // (k_halo_pack2's work: dense (np, n, n) per side, cells of inactive blocks stay zero from the buffer's reset at the epoch change), its second piece
+    // adds the received planes (k_halo_unpack_add2's work) - two launches less per substep.  halo_hs.count = 0: off.
+    HaloSides halo_hs;
+    int halo_np;
+    Vec4<R>* halo_send;
+    const Vec4<R>* halo_recv;
     int keep_vmix;               // k_grid_op also stores grid_v_mixed (the slab phases' halo exchange sends v_out - v_mixed); otherwise it is recomputed where it is read
     int zero_next_hits;          // k_grid_op: empty the next substep's counter (its P2G rides in this substep's G2P launch and appends right away)
     ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
@@ -991,6 +1001,25 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
         }
         slab_reduce(D, b, l, acc);
         D.vin[cell] = acc;
+        if (phase == 1 && D.halo_hs.count) {                                            // pack: this rank's partial sums on the shared planes
+            const size_t total = (size_t)D.halo_np * D.n * D.n;
+            for (int s = 0; s < D.halo_hs.count; ++s) {
+                const int pi = i - D.halo_hs.plane0[s];
+                if ((unsigned)pi < (unsigned)D.halo_np) D.halo_send[(size_t)D.halo_hs.slot[s] * total + ((size_t)pi * D.n + j) * D.n + k] = acc;
+            }
+        }
+    } else if (D.halo_hs.count) {                                                       // unpack-add: the neighbours' partial sums
+        const size_t total = (size_t)D.halo_np * D.n * D.n;
+        bool got = false;
+        for (int s = 0; s < D.halo_hs.count; ++s) {
+            const int pi = i - D.halo_hs.plane0[s];
+            if ((unsigned)pi < (unsigned)D.halo_np) {
+                const Vec4<R> a = D.halo_recv[(size_t)D.halo_hs.slot[s] * total + ((size_t)pi * D.n + j) * D.n + k];
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                got = true;
+            }
+        }
+        if (got) D.vin[cell] = acc;                                                     // (the checkpoint, the contact kernels and the backward pass read the totals)
     }
     if (phase == 1) return;
     const Vec4<R> z = {R(0), R(0), R(0), R(0)};
@@ -2408,7 +2437,6 @@ __global__ __launch_bounds__(BLOCK) void k_halo_unpack_add(DevSim<R> D, Vec4<R>*
 
 // both neighbours' planes in ONE launch (the in-library exchange, softmac_hip.hip `exchange`): blockIdx.y picks the entry of `hs`;
 // buffer slot 0 = left neighbour, 1 = right neighbour, each np * n * n records
-struct HaloSides { int count; int slot[2]; int plane0[2]; };
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_halo_pack2(DevSim<R> D, const Vec4<R>* field, const Vec4<R>* minus, HaloSides hs, int np, Vec4<R>* out) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x, total = np * D.n * D.n;

@@ -357,6 +357,8 @@ template <class R> struct Sim final : ISim {
         D.hits_next = d_hits2;
         D.zero_next_hits = 0;
         D.keep_vmix = 0;
+        D.halo_hs.count = 0; D.halo_hs.slot[0] = D.halo_hs.slot[1] = 0; D.halo_hs.plane0[0] = D.halo_hs.plane0[1] = 0;
+        D.halo_np = 0; D.halo_send = nullptr; D.halo_recv = nullptr;
         HIP_TRY(hipMalloc((void**)&d_pmask, (size_t)D.Npad * sizeof(int)));
         D.nhits = d_nhits;
         D.nhits_next = d_nhits + 4;
@@ -1186,6 +1188,8 @@ template <class R> struct Sim final : ISim {
             Do.nactive = epochs[grid_epoch].nactive;
             hipLaunchKernelGGL(k_clear_active<R>, dim3((Do.nactive + 3) / 4), dim3(BLOCK), 0, stream, Do, grid_block, 6);
         }
+        // (k_grid_op packs the shared planes of the ACTIVE cells into the send buffer itself: what an earlier epoch's cells left there must read as zero)
+        if (e != grid_epoch && sc.on && halo_buf) HIP_TRY(hipMemsetAsync(halo_buf, 0, 2 * halo_records * sizeof(Vec4<R>), stream));
         grid_epoch = e;
         const Epoch& ep = epochs[e];
         D.chunks = ep.chunks; D.nchunks = ep.nchunks; D.active = ep.active; D.nactive = ep.nactive;
@@ -1684,6 +1688,13 @@ template <class R> struct Sim final : ISim {
         }
         prof_begin(K_GRID_OP);
         Dc.keep_vmix = stage != 0 ? 1 : 0;                      // the slab phases send v_out - v_mixed across the slab boundaries after the contact pass
+        Dc.halo_hs.count = 0;
+        if (stage != 0 && halo_in_grid_op && sc.on && halo_buf) {
+            Dc.halo_hs = halo_sides(false);
+            Dc.halo_np = sc.np;
+            Dc.halo_send = halo_buf;
+            Dc.halo_recv = halo_buf + 2 * halo_records;
+        }
         Dc.zero_next_hits = fuse_next ? 1 : 0;
         Dc.fk_ride = 0;
         if (fk_in_grid_op) { Dc.fk_ride = D.P; Dc.fk_stride = (size_t)cfg.max_frames * 13; }
@@ -1927,6 +1938,8 @@ template <class R> struct Sim final : ISim {
     int fwd_hint = -1;                   // substep the caller runs next (-1: unknown; smac_substeps announces it)
     int p2g_done_frame = -1;             // substep whose P2G already ran inside the G2P launch of the substep before it
     int fuse_pending_frame = -1;         // slab pieces: the substep whose last piece (G2P) will carry the next substep's P2G
+    bool halo_in_grid_op = false;        // set by smac_substeps_slab around the two k_grid_op pieces of a substep (DevSim::halo_hs)
+    int halo_fuse_env = getenv("SMAC_HALO_FUSE") ? atoi(getenv("SMAC_HALO_FUSE")) : 1;
     void hint_forward_next(int f) override { fwd_hint = f; }
     // A P2G that ran ahead (k_g2p_p2g) and whose substep is not the next thing to happen: what it left in the slabs is overwritten by the next P2G, what it
     // added to D.vdrift and to the hit counter is taken back here.  (Only an error between two substeps of smac_substeps gets here.)
@@ -2296,6 +2309,7 @@ template <class R> struct Sim final : ISim {
             hipFree(halo_buf);
             halo_buf = nullptr;
             HIP_TRY(hipMalloc((void**)&halo_buf, 4 * rec * sizeof(Vec4<R>)));
+            HIP_TRY(hipMemsetAsync(halo_buf, 0, 4 * rec * sizeof(Vec4<R>), stream));
             halo_records = rec;
         }
         if (comm_stub == 2) {
@@ -2313,18 +2327,26 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     // SUM the partials of `field` (minus `minus`) on the shared planes with both neighbours
-    int exchange(Vec4<R>* field, const Vec4<R>* minus, bool contact_only) {
+    // the sides an exchange of this kind has (every boundary, or only those a contact primitive can reach)
+    HaloSides halo_sides(bool contact_only, int* peers = nullptr) const {
         HaloSides hs;
         hs.count = 0;
+        hs.slot[0] = hs.slot[1] = 0; hs.plane0[0] = hs.plane0[1] = 0;
+        if (sc.peer_l >= 0 && (sc.contact_l || !contact_only)) { hs.slot[hs.count] = 0; hs.plane0[hs.count] = sc.left0; if (peers) peers[hs.count] = sc.peer_l; ++hs.count; }
+        if (sc.peer_r >= 0 && (sc.contact_r || !contact_only)) { hs.slot[hs.count] = 1; hs.plane0[hs.count] = sc.right0; if (peers) peers[hs.count] = sc.peer_r; ++hs.count; }
+        return hs;
+    }
+    // in_kernels: the producing kernel has packed the planes and the consuming kernel will add what arrives (k_grid_op's two pieces: DevSim::halo_hs)
+    int exchange(Vec4<R>* field, const Vec4<R>* minus, bool contact_only, bool in_kernels = false) {
         int peers[2] = {-1, -1};
-        if (sc.peer_l >= 0 && (sc.contact_l || !contact_only)) { hs.slot[hs.count] = 0; hs.plane0[hs.count] = sc.left0; peers[hs.count++] = sc.peer_l; }
-        if (sc.peer_r >= 0 && (sc.contact_r || !contact_only)) { hs.slot[hs.count] = 1; hs.plane0[hs.count] = sc.right0; peers[hs.count++] = sc.peer_r; }
+        const HaloSides hs = halo_sides(contact_only, peers);
         if (hs.count == 0) return SMAC_OK;
         REQUIRE(grid_epoch > 0, "exchange: no epoch bound");
         const size_t rec = halo_records;
         Vec4<R>* send = halo_buf;
         Vec4<R>* recv = halo_buf + 2 * rec;
-        hipLaunchKernelGGL(k_halo_pack2<R>, dim3(nblk(rec), hs.count), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)field, minus, hs, sc.np, send);   // every side BEFORE any unpack: partials, not totals
+        if (!in_kernels)
+            hipLaunchKernelGGL(k_halo_pack2<R>, dim3(nblk(rec), hs.count), dim3(BLOCK), 0, stream, D, (const Vec4<R>*)field, minus, hs, sc.np, send);   // every side BEFORE any unpack: partials, not totals
         hipStream_t cs = comm_own_stream ? comm_stream : stream;
         if (comm_own_stream) {
             HIP_TRY(hipEventRecord(ev_kernels, stream));
@@ -2361,7 +2383,8 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipEventRecord(ev_comm, comm_stream));
             HIP_TRY(hipStreamWaitEvent(stream, ev_comm, 0));
         }
-        hipLaunchKernelGGL(k_halo_unpack_add2<R>, dim3(nblk(rec), hs.count), dim3(BLOCK), 0, stream, D, field, hs, sc.np, (const Vec4<R>*)recv);
+        if (!in_kernels)
+            hipLaunchKernelGGL(k_halo_unpack_add2<R>, dim3(nblk(rec), hs.count), dim3(BLOCK), 0, stream, D, field, hs, sc.np, (const Vec4<R>*)recv);
         ++exchanges_done;
         return check_launch();
     }
@@ -2395,9 +2418,12 @@ template <class R> struct Sim final : ISim {
         int rc;
         for (int f = f0; f < f0 + count; ++f) {
             fwd_hint = f + 1 < f0 + count ? f + 1 : -1;       // lets substep f's G2P piece carry the next substep's P2G (k_g2p_p2g)
-            if ((rc = substep_phase(f, nullptr, 0))) return slab_guard(rc);
-            if ((rc = exchange(D.vin, nullptr, false))) return slab_guard(rc);                       // {m, p} partials after P2G
-            if ((rc = substep_phase(f, nullptr, 1))) return slab_guard(rc);
+            halo_in_grid_op = halo_fuse_env != 0;             // k_grid_op's two pieces pack / add the shared planes of {m,p} themselves (SMAC_HALO_FUSE=0: own launches)
+            if ((rc = substep_phase(f, nullptr, 0))) { halo_in_grid_op = false; return slab_guard(rc); }
+            if ((rc = exchange(D.vin, nullptr, false, halo_in_grid_op))) { halo_in_grid_op = false; return slab_guard(rc); }   // {m, p} partials after P2G
+            rc = substep_phase(f, nullptr, 1);
+            halo_in_grid_op = false;
+            if (rc) return slab_guard(rc);
             if (contact && any_contact() && (rc = exchange(D.vout, D.vmix, true))) return slab_guard(rc);   // contact corrections v_out - v_mixed
             if ((rc = substep_phase(f, nullptr, 2))) return slab_guard(rc);
         }

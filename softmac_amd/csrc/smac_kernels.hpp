@@ -983,7 +983,8 @@ __device__ __forceinline__ void prim_fk_step(double* state, int f, double dt);
 // slab reduction (completes P2G) fused with grid_op :283-297 / grid_op_mixed1 :396-404
 // phase 0: both; 1: slab reduction only (multi-GPU: the halo planes of {m,p} are summed across slabs next);
 // 2: normalisation only
-template <class R, bool GRIDC>
+// HALO: the slab loop's two pieces pack / add the shared planes themselves (DevSim::halo_hs) - an instantiation of its own, the single-GPU kernel carries none of it
+template <class R, bool GRIDC, bool HALO = false>
 __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
     if (D.fk_ride > 0 && blockIdx.x == gridDim.x - 1) {       // forward_kinematics to frame cur_frame + 1 rides here when this substep's G2P launch carries the next
         if ((int)threadIdx.x < D.fk_ride) prim_fk_step(D.prim_state + threadIdx.x * D.fk_stride, D.cur_frame, D.dt64);      // substep's P2G, whose band test reads those states
@@ -1001,14 +1002,14 @@ __global__ __launch_bounds__(BLOCK) void k_grid_op(DevSim<R> D, int phase) {
         }
         slab_reduce(D, b, l, acc);
         D.vin[cell] = acc;
-        if (phase == 1 && D.halo_hs.count) {                                            // pack: this rank's partial sums on the shared planes
+        if (HALO && phase == 1 && D.halo_hs.count) {                                    // pack: this rank's partial sums on the shared planes
             const size_t total = (size_t)D.halo_np * D.n * D.n;
             for (int s = 0; s < D.halo_hs.count; ++s) {
                 const int pi = i - D.halo_hs.plane0[s];
                 if ((unsigned)pi < (unsigned)D.halo_np) D.halo_send[(size_t)D.halo_hs.slot[s] * total + ((size_t)pi * D.n + j) * D.n + k] = acc;
             }
         }
-    } else if (D.halo_hs.count) {                                                       // unpack-add: the neighbours' partial sums
+    } else if (HALO && D.halo_hs.count) {                                               // unpack-add: the neighbours' partial sums
         const size_t total = (size_t)D.halo_np * D.n * D.n;
         bool got = false;
         for (int s = 0; s < D.halo_hs.count; ++s) {

@@ -1698,8 +1698,11 @@ template <class R> struct Sim final : ISim {
         Dc.zero_next_hits = fuse_next ? 1 : 0;
         Dc.fk_ride = 0;
         if (fk_in_grid_op) { Dc.fk_ride = D.P; Dc.fk_stride = (size_t)cfg.max_frames * 13; }
-        if (D.collision_type == CONTACT_GRID && D.any_contact)
-            hipLaunchKernelGGL((k_grid_op<R, true>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
+        if (D.collision_type == CONTACT_GRID && D.any_contact) {
+            if (Dc.halo_hs.count) hipLaunchKernelGGL((k_grid_op<R, true, true>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
+            else hipLaunchKernelGGL((k_grid_op<R, true>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
+        } else if (Dc.halo_hs.count)
+            hipLaunchKernelGGL((k_grid_op<R, false, true>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
         else
             hipLaunchKernelGGL((k_grid_op<R, false>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
         Dc.fk_ride = 0;

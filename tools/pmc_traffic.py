@@ -21,7 +21,9 @@ NAMES = {"k_p2g<float, true, false>": "p2g", "k_p2g_grad<float, false, true>": "
          # round 4: the two-entry material table added a template parameter (false = one material, the benchmarked instantiations)
          "k_p2g<float, true, false, false>": "p2g", "k_p2g_grad<float, false, true, false>": "p2g_grad",
          # round 4: G2P of substep f + P2G of substep f+1 in one launch (with the checkpoint save in its first workgroups)
-         "k_g2p_p2g<float, true>": "g2p_p2g", "k_g2p_p2g<float, false>": "g2p_p2g"}
+         "k_g2p_p2g<float, true>": "g2p_p2g", "k_g2p_p2g<float, false>": "g2p_p2g",
+         # (k_grid_op got a third template parameter: the slab loop's instantiation packs / adds the shared planes itself)
+         "k_grid_op<float, false, false>": "grid_op"}
 
 
 def mean_by_kernel(path, counter):

@@ -2,6 +2,7 @@
 CPU (`--launch-check`: spawn, gloo rendezvous, report - no simulator, the product has no CPU path); on the GPU box the
 2-rank slab bench goes through the same launcher with both ranks on the one card."""
 import json
+import math
 import os
 import pathlib
 import subprocess
@@ -60,3 +61,16 @@ def test_two_rank_strong_scaling_bench_through_the_launcher():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert sum(d["config"]["particles_per_gpu"]) == 65536
     assert d["config"]["resorts_in_windows"] >= 1
+
+
+def test_window_plan_gives_the_resorts_their_steady_state_share():
+    """bench.py times R windows of exactly K substep pairs that advance through one episode; R K is a multiple of the re-sort interval wherever that fits
+    in 480 resident frames, so that windows without and with a re-sort appear in their steady-state proportion."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    for K, I in ((20, 40), (32, 40), (40, 40), (20, 20), (64, 40), (7, 40), (100, 40)):
+        R = bench.window_plan(K, I)
+        assert R >= 1 and (R * K) % I == 0, (K, I, R)
+        assert R * K <= 480 or R == math.lcm(K, I) // K, (K, I, R)
+    assert bench.window_plan(20, 40) == 8 and bench.window_plan(32, 40) == 10          # the driver's flags, the default flags
+    assert bench.window_plan(1000, 40) == 1                                           # one window is the least there is

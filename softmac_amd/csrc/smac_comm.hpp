@@ -96,6 +96,7 @@ struct IpcLink {
     static constexpr size_t REDUCE_CAP = 1 << 16;                 // doubles per rank and round of the host-side all-reduce
     struct Barrier { std::atomic<int> count, sense; };
     struct Shm {
+        std::atomic<int> aborted;                                  // set by any rank that gives up (a failure, a timeout, smac_comm_abort): every barrier wait ends at once
         Barrier all;
         Barrier pair[MAX_WORLD];                                   // pair[r]: between rank r and rank r + 1
         hipIpcMemHandle_t handle[MAX_WORLD];
@@ -140,7 +141,14 @@ struct IpcLink {
         rank = r; world = w;
         return true;
     }
+    // once every rank holds a mapping the NAME can go: the kernel then frees the segment with the last unmap - also after a crash, a timeout or os._exit
+    // (only rank 0's detach() removed it, every failure path left 4 MB in /dev/shm).  Every rank calls it; ENOENT is the expected answer for all but one.
+    void unlink_name() { if (!name.empty()) (void)shm_unlink(name.c_str()); }
+    // give up on behalf of everybody: a rank waiting at any barrier of this link returns with an error within one poll (50 us)
+    void abort_link() { if (shm) shm->aborted.store(1, std::memory_order_release); }
+    bool aborted() const { return shm && shm->aborted.load(std::memory_order_acquire) != 0; }
     bool sync(Barrier& b, int parties, int& local_sense) {
+        if (aborted()) { err = "IPC link: aborted (a rank of this link failed or called smac_comm_abort)"; return false; }
         local_sense ^= 1;
         if (b.count.fetch_add(1, std::memory_order_acq_rel) == parties - 1) {
             b.count.store(0, std::memory_order_relaxed);
@@ -148,7 +156,12 @@ struct IpcLink {
             return true;
         }
         for (long waited = 0; b.sense.load(std::memory_order_acquire) != local_sense; waited += 50) {
-            if (waited > 60L * 1000 * 1000) { err = "IPC link: a neighbour did not reach the barrier within 60 s (it failed or exchanges a different sequence)"; return false; }
+            if (aborted()) { err = "IPC link: aborted while waiting at a barrier (a rank of this link failed or called smac_comm_abort)"; return false; }
+            if (waited > 60L * 1000 * 1000) {
+                abort_link();                                      // (this rank's arrival stays counted in the barrier: the link is unusable from here on, and says so to everybody)
+                err = "IPC link: a neighbour did not reach the barrier within 60 s (it failed or exchanges a different sequence)";
+                return false;
+            }
             usleep(50);
         }
         return true;
@@ -194,7 +207,7 @@ struct IpcLink {
     }
     void detach() {
         close_boxes();
-        if (shm) { munmap(shm, sizeof(Shm)); shm = nullptr; if (rank == 0 && !name.empty()) shm_unlink(name.c_str()); }
+        if (shm) { munmap(shm, sizeof(Shm)); shm = nullptr; unlink_name(); }
     }
 };
 

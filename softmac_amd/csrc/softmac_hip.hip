@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -768,9 +769,14 @@ template <class R> struct Sim final : ISim {
         return SMAC_OK;
     }
     unsigned char* d_mat_id = nullptr;
+    int mat2_set = 0;                   // bits: mu2, lam2, yield_ratio2 have been set (smac_set_param)
     int set_material_ids(const int32_t* ids) override {                       // per-particle selector of the two-entry material table (nullptr: one material again)
         if (!ids) { D.mat_id = nullptr; ++config_gen; return SMAC_OK; }
         REQUIRE(D.collision_type != CONTACT_PARTICLE || !any_contact(), "set_material_ids: not with penalty contact (collision_type 1)");
+        // entry 1 must have been described: an entry left at its zero initialisation has no stiffness and - plastic, von Mises - yields at zero stress
+        // (ADVICE r4).  The reference fills yield_stress uniformly from the config (mpm_simulator.py:86-90): a missing yield_ratio2 means the SAME yield stress.
+        REQUIRE((mat2_set & 3) == 3, "set_material_ids: set entry 1 first (smac_set_param \"mu2\" and \"lam2\")");
+        if (!(mat2_set & 4)) D.yield_c2 = D.mu2 > R(0) ? D.mat.yield_c * D.mat.mu / D.mu2 : D.mat.yield_c;
         std::vector<unsigned char> tmp(D.Npad, 0);
         for (int p = 0; p < cfg.n_particles; ++p) {
             REQUIRE(ids[p] == 0 || ids[p] == 1, "set_material_ids: entries must be 0 or 1");
@@ -1330,6 +1336,7 @@ template <class R> struct Sim final : ISim {
         } else if (!strcmp(name, "mu2") || !strcmp(name, "lam2") || !strcmp(name, "yield_ratio2")) {   // entry 1 of the two-entry material table (smac_set_material_ids)
             REQUIRE(value >= 0.0, "set_param(mu2 | lam2 | yield_ratio2): negative");
             (name[0] == 'm' ? D.mu2 : (name[0] == 'l' ? D.lam2 : D.yield_c2)) = (R)value;
+            mat2_set |= name[0] == 'm' ? 1 : (name[0] == 'l' ? 2 : 4);
         } else if (!strcmp(name, "mass_eps")) {
             REQUIRE(value >= 0.0, "set_param(mass_eps): negative");
             D.m_eps = (R)value;
@@ -2260,6 +2267,10 @@ template <class R> struct Sim final : ISim {
     // the 2 x 0.5 MB exchange itself, and until interior chunks are launched beside it there is nothing for the second stream to overlap with.
     int comm_own_stream = getenv("SMAC_COMM_STREAM") ? atoi(getenv("SMAC_COMM_STREAM")) : 0;
     long long exchanges_done = 0;
+    // smac_comm_abort may come from ANOTHER host thread (parallel.FailureWatch: a neighbour failed while this rank's thread sits in a stream
+    // synchronisation behind a receive nobody will answer).  The communicator is therefore only touched under this mutex: the enqueueing calls
+    // (short, they never wait for the device) and the abort exclude each other; a stream synchronisation is never made while holding it.
+    std::mutex comm_mu;
 #define NCCL_TRY(expr)                                                                                      \
     do {                                                                                                    \
         ncclResult_t _r = (expr);                                                                           \
@@ -2276,6 +2287,7 @@ template <class R> struct Sim final : ISim {
             HIP_TRY(hipSetDevice(cfg.device));
             if (!ipc.attach(id128, rank, world)) { err = ipc.err; return SMAC_ERR_INVALID; }
             if (!ipc.sync_all()) { err = ipc.err; return SMAC_ERR_INVALID; }
+            ipc.unlink_name();                                // every rank holds its mapping: the name goes now, the segment with the last unmap (crashes included)
             c_rank = rank; c_world = world;
             return SMAC_OK;
         }
@@ -2368,6 +2380,8 @@ template <class R> struct Sim final : ISim {
         } else if (!comm_stub) {
             Rccl& L = Rccl::get();
             const size_t count = rec * 4;
+            std::lock_guard<std::mutex> lock(comm_mu);
+            REQUIRE(comm, "exchange: the communicator was aborted (smac_comm_abort)");
             NCCL_TRY(L.GroupStart());
             for (int s = 0; s < hs.count; ++s) NCCL_TRY(L.Send(send + (size_t)hs.slot[s] * rec, count, nccl_type<R>::v, peers[s], comm, cs));
             // self loop: sends and receives between one pair match in order - the first message (sent "to the left") is what a left-hand
@@ -2397,21 +2411,34 @@ template <class R> struct Sim final : ISim {
     // expected to end the process with a non-zero status so that the launcher tears the peers down (bench.py; parallel.agreed_failure for hosts that
     // have a control plane of their own).  World 1 (the self-loop test mode) has no peer to release and keeps its communicator.
     int slab_guard(int rc) {
-        if (rc != SMAC_OK && comm && c_world > 1) {
-            Rccl& L = Rccl::get();
-            if (L.CommAbort) L.CommAbort(comm);
-            comm = nullptr;
+        if (rc != SMAC_OK && c_world > 1 && (comm || (comm_stub == 2 && ipc.shm))) {
+            {
+                std::lock_guard<std::mutex> lock(comm_mu);
+                if (comm) {
+                    Rccl& L = Rccl::get();
+                    if (L.CommAbort) L.CommAbort(comm);
+                    comm = nullptr;
+                }
+            }
+            ipc.abort_link();                                 // (IPC test transport: every rank waiting at a barrier of the link returns at once)
             sc.on = false;
-            err += " [rank " + std::to_string(c_rank) + ": the RCCL communicator was aborted; end this process so that the launcher stops the other ranks]";
+            err += " [rank " + std::to_string(c_rank) + ": the communicator was aborted; end this process, or publish the failure (parallel.FailureWatch), so that the other ranks stop]";
         }
         return rc;
     }
-    int comm_abort() override {                               // the host's reaction to ANOTHER rank's failure: no stream sync (a receive may never complete)
-        if (comm) {
-            Rccl& L = Rccl::get();
-            if (L.CommAbort) L.CommAbort(comm);
-            comm = nullptr;
+    // The host's reaction to ANOTHER rank's failure: no stream sync (a receive may never complete).  Callable from a second host thread while the
+    // handle's own thread waits in a synchronisation: ncclCommAbort makes the communicator's device kernels give up, the wait returns, and the next
+    // exchange finds no communicator.  Over the IPC test transport the link's abort flag ends any barrier wait.
+    int comm_abort() override {
+        {
+            std::lock_guard<std::mutex> lock(comm_mu);
+            if (comm) {
+                Rccl& L = Rccl::get();
+                if (L.CommAbort) L.CommAbort(comm);
+                comm = nullptr;
+            }
         }
+        ipc.abort_link();
         sc.on = false;
         return SMAC_OK;
     }
@@ -2419,6 +2446,7 @@ template <class R> struct Sim final : ISim {
         REQUIRE(sc.on, "substeps_slab: no slab geometry (smac_comm_slab)");
         const bool contact = sc.contact_l || sc.contact_r;
         int rc;
+        struct Reset { Sim* s; ~Reset() { s->fwd_hint = -1; s->halo_in_grid_op = false; } } reset_on_exit{this};   // every return: a later single substep must not take the fused path on a stale hint
         for (int f = f0; f < f0 + count; ++f) {
             fwd_hint = f + 1 < f0 + count ? f + 1 : -1;       // lets substep f's G2P piece carry the next substep's P2G (k_g2p_p2g)
             halo_in_grid_op = halo_fuse_env != 0;             // k_grid_op's two pieces pack / add the shared planes of {m,p} themselves (SMAC_HALO_FUSE=0: own launches)
@@ -2437,6 +2465,7 @@ template <class R> struct Sim final : ISim {
         REQUIRE(sc.on, "substeps_slab_grad: no slab geometry (smac_comm_slab)");
         const bool contact = sc.contact_l || sc.contact_r;
         int rc;
+        struct Reset { Sim* s; ~Reset() { s->bwd_hint = -1; } } reset_on_exit{this};
         for (int f = f0 + count - 1; f >= f0; --f) {
             bwd_hint = f > f0 ? f - 1 : -1;                   // lets substep f's last piece carry the G2P adjoint of substep f - 1 (k_p2g_g2p_grad)
             if ((rc = substep_grad_phase(f, nullptr, f == f0 + count - 1 ? ext_f_grad : nullptr, nullptr, 0))) { bwd_hint = -1; return slab_guard(rc); }
@@ -2470,8 +2499,9 @@ template <class R> struct Sim final : ISim {
             return SMAC_OK;
         }
         if (comm_stub || c_world == 1 || n == 0) return SMAC_OK;
-        REQUIRE(comm, "no communicator (smac_comm_init)");
         Rccl& L = Rccl::get();
+        std::lock_guard<std::mutex> lock(comm_mu);
+        REQUIRE(comm, "no communicator (smac_comm_init; or it was aborted)");
         NCCL_TRY(L.AllReduce(buf, buf, n, ncclFloat64, ncclSum, comm, stream));      // on the kernels' stream: ordered with them, nothing to hand over
         return SMAC_OK;
     }
@@ -2566,8 +2596,9 @@ template <class R> struct Sim final : ISim {
                 if (peers[s] >= 0 && bytes_out[s]) HIP_TRY(hipMemcpyAsync(recv[1 - s], send[s], bytes_out[s], hipMemcpyDeviceToDevice, stream));
             return SMAC_OK;
         }
-        REQUIRE(comm, "no communicator (smac_comm_init)");
         Rccl& L = Rccl::get();
+        std::lock_guard<std::mutex> lock(comm_mu);
+        REQUIRE(comm, "no communicator (smac_comm_init; or it was aborted)");
         NCCL_TRY(L.GroupStart());
         for (int s = 0; s < 2; ++s)
             if (peers[s] >= 0 && bytes_out[s]) NCCL_TRY(L.Send(send[s], bytes_out[s], ncclUint8, peers[s], comm, stream));

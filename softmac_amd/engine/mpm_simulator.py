@@ -321,7 +321,9 @@ class MPMSimulator:
         scale2 = getattr(self, "scale", 1.0) ** 2                                            # (soft_cloth mirror: unit-domain moduli are E / s^2)
         self._h.call("smac_set_param", b"mu2", C.c_double(mu2 / scale2))
         self._h.call("smac_set_param", b"lam2", C.c_double(lam2 / scale2))
-        if yield_stress2 is not None and mu2 > 0:
+        if yield_stress2 is None:
+            yield_stress2 = self._yield_stress                  # the reference fills yield_stress uniformly from the config (:86-90)
+        if mu2 > 0:
             self._h.call("smac_set_param", b"yield_ratio2", C.c_double(float(yield_stress2) / (2.0 * mu2)))
         self._h.call("smac_set_material_ids", ids.ctypes.data_as(_ffi.c_int32_p))
 

@@ -130,5 +130,9 @@ class TaichiEnv:
     def compute_loss(self, f=None, **kwargs):
         assert self.loss is not None
         if f is None:
-            f = 0 if self._is_copy else self.simulator.cur
+            if self._is_copy:
+                self.loss.clear()                                # :156-158: copy mode starts the loss from zero
+                f = 0
+            else:
+                f = self.simulator.cur
         return self.loss.compute_loss(f, **kwargs)

@@ -281,12 +281,130 @@ def all_ranks_ok(error, group=None):
     return [f"rank {r}: {e}" for r, e in enumerate(allf) if e]
 
 
-def agreed_failure(error, runner=None, group=None):
-    """End of a window of collective work (bench.py calls it once per timed window, outside the substep loop): every rank reports None or its
-    failure; if ANY rank failed, every rank aborts its communicator (`runner.abort()`: ncclCommAbort - the failing rank's library already did,
-    smac_comm_abort elsewhere releases receives that would never be answered) and raises the same RuntimeError naming the ranks that failed.
-    The caller lets it propagate: a non-zero exit is what makes the launcher stop everybody (an error on one rank must not leave its
-    neighbours waiting in an exchange)."""
+class FailureWatch:
+    """Out-of-band failure channel between the ranks of ONE node (the metric's 8 GPUs are one node), without a collective.
+
+    Why: a rank that fails inside the slab loop aborts ITS communicator (softmac_hip.hip slab_guard), but ncclCommAbort there does not release
+    the receives its neighbours have enqueued: they sit in their next stream synchronisation and never reach a collective in which they could
+    be told (`agreed_failure` alone deadlocks until gloo's timeout).  So the failing rank PUBLISHES - one small file in a directory
+    every rank derives from the launcher's rendezvous (MASTER_ADDR / MASTER_PORT), written atomically - and every rank runs a daemon thread that
+    polls the directory; when another rank's file appears the thread calls `runner.abort()` (smac_comm_abort, safe from a second thread: the
+    library takes its communicator mutex) so that the main thread's pending wait returns, and remembers the message.  `arm(seconds, what)` adds a
+    deadline for one bounded step (bench.py: the first warm-up window, the first place an N-rank run can hang): when it passes, the thread
+    publishes, aborts and ends the process with status 3 - a fresh, non-zero exit instead of a hang; nothing is re-executed.
+
+    Supported reactions, in order of preference: (1) the main thread's call raises (its exchange finds no communicator), the caller passes the
+    error to `agreed_failure(error, runner, watch=watch)` and every rank raises the same RuntimeError; (2) under a launcher, exit non-zero."""
+
+    def __init__(self, rank, world, runner=None, directory=None, key=None, poll=0.05):
+        import os
+        import tempfile
+        import threading
+        self.rank, self.world, self.runner, self.poll = int(rank), int(world), runner, float(poll)
+        if key is None:
+            key = f"{os.environ.get('MASTER_ADDR', 'local')}-{os.environ.get('MASTER_PORT', '0')}-{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}"
+        base = directory or os.environ.get("SMAC_FAIL_DIR") or tempfile.gettempdir()
+        self.dir = os.path.join(base, "smac-fail-" + "".join(c if c.isalnum() or c in "-_." else "_" for c in str(key)))
+        os.makedirs(self.dir, exist_ok=True)
+        self._mine = os.path.join(self.dir, f"rank{self.rank}.txt")
+        try:
+            os.unlink(self._mine)                            # a stale file of an earlier run with the same rendezvous
+        except OSError:
+            pass
+        self.failure = None                                  # "rank r: message" of the first OTHER rank seen to have failed
+        self._deadline = None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._loop, name="smac-failure-watch", daemon=True)
+        self._thread.start()
+
+    def publish(self, message):
+        """this rank failed: tell the others (atomic rename, so a reader never sees half a message)"""
+        import os
+        tmp = self._mine + ".tmp"
+        with open(tmp, "w") as fh:
+            fh.write(str(message)[:2000])
+        os.replace(tmp, self._mine)
+
+    def arm(self, seconds, what="a bounded step"):
+        import time
+        self._deadline = (time.monotonic() + float(seconds), str(what))
+
+    def disarm(self):
+        self._deadline = None
+
+    def _others(self):
+        import os
+        out = []
+        try:
+            names = os.listdir(self.dir)
+        except OSError:
+            return out
+        for n in sorted(names):
+            if n.startswith("rank") and n.endswith(".txt") and n != os.path.basename(self._mine):
+                try:
+                    out.append(f"rank {int(n[4:-4])}: " + open(os.path.join(self.dir, n)).read())
+                except (OSError, ValueError):
+                    pass
+        return out
+
+    def _abort_runner(self):
+        if self.runner is not None and hasattr(self.runner, "abort"):
+            try:
+                self.runner.abort()
+            except Exception:                                # noqa: BLE001 - the failure being reported is the one that matters
+                pass
+
+    def _loop(self):
+        import os
+        import sys
+        import time
+        while not self._stop.wait(self.poll):
+            others = self._others()
+            if others:
+                self.failure = "; ".join(others)
+                self._abort_runner()                         # releases this rank's pending receive / barrier wait
+                return
+            dl = self._deadline
+            if dl is not None and time.monotonic() > dl[0]:
+                msg = f"{dl[1]} did not finish within its time limit on rank {self.rank}"
+                self.publish(msg)
+                self._abort_runner()
+                print("softmac_amd.parallel.FailureWatch: " + msg + " - exiting with status 3", file=sys.stderr, flush=True)
+                os._exit(3)
+
+    def check(self):
+        if self.failure:
+            raise RuntimeError("collective run failed: " + self.failure)
+
+    def close(self):
+        import os
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+        try:
+            os.unlink(self._mine)
+        except OSError:
+            pass
+        try:
+            os.rmdir(self.dir)                               # (the last rank to leave succeeds)
+        except OSError:
+            pass
+
+
+def agreed_failure(error, runner=None, group=None, watch=None):
+    """End of a window of collective work for hosts that keep their ranks alive: every rank reports None or its failure; if ANY rank failed,
+    every rank aborts its communicator (`runner.abort()`) and raises the same RuntimeError naming the ranks that failed.
+
+    This is a COLLECTIVE (all_gather over the control group), so every rank must be able to reach it.  A healthy rank whose neighbour failed in
+    the middle of the slab loop cannot by itself: its next stream synchronisation waits on a receive nobody will answer (ncclCommAbort on the
+    failing rank does not release it).  Pass a `FailureWatch`: the failing rank publishes out of band BEFORE entering the all_gather, the healthy
+    ranks' watch threads abort their communicators, their pending calls return with an error, and they arrive here with it.  Without a watch the
+    only supported reaction to a failure inside the loop is a non-zero exit under a launcher, which then stops the other ranks - that is what
+    bench.py does (it does not call this function)."""
+    if watch is not None:
+        if error:
+            watch.publish(error)
+        elif watch.failure:
+            error = f"stopped because another rank failed ({watch.failure})"
     failed = all_ranks_ok(error, group=group)
     if failed:
         if runner is not None and hasattr(runner, "abort"):

@@ -31,6 +31,8 @@ def main():
         return grip_strong(a)
     if a.scene == "cloth":
         return cloth(a)
+    if a.scene == "lib_failure":
+        return lib_failure(a)
     sc = S.build(a.precision)
     idx = S.owned(sc, a.rank, a.world)
     state = sc["state"][idx]
@@ -97,6 +99,44 @@ def main():
                    ext=np.array([m.ext_f.to_numpy() for m in prims]) if sc["specs"] else np.zeros((0, 6)),
                    pgrad=np.array([[m.get_all_states_grad(f) for m in prims] for f in range(nsteps)]))
     np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=idx, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def lib_failure(a):
+    """rank 1 fails before its first exchange and publishes through parallel.FailureWatch; rank 0 is INSIDE smac_substeps_slab, waiting at the
+    IPC link's pair barrier for a neighbour that never comes (the test transport's form of a pending receive).  Its watch thread sees the file and calls
+    smac_comm_abort from the second host thread; the barrier wait returns with an error and both ranks raise through agreed_failure within seconds - the
+    link's own timeout is 60 s."""
+    import json
+    import time
+    from softmac_amd.parallel import FailureWatch, LibSlabRunner, agreed_failure, rendezvous_unique_id
+    assert os.environ.get("SMAC_COMM_STUB") == "2"
+    sc = S.build(a.precision)
+    idx = S.owned(sc, a.rank, a.world)
+    cfg = sc["cfg"]
+    cfg.n_particles = len(idx)
+    sim, prims = H.build_engine(cfg, sc["env_dt"], sc["specs"], sc["pstates"])
+    sim.reset(sc["state"][idx])
+    run = LibSlabRunner(sim, a.rank, a.world, sc["split"], sc["split"], 2, has_contact=(True, True), unique_id=rendezvous_unique_id(a.rank))
+    watch = FailureWatch(a.rank, a.world, runner=run, directory=a.out)
+    dist.barrier()
+    t0, err = time.monotonic(), None
+    try:
+        if a.rank == 1:
+            raise RuntimeError("injected failure on rank 1 before its first exchange")
+        run.run_substeps(0, sc["nsteps"])
+        sim.sync()
+    except Exception as e:                                         # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    raised = None
+    try:
+        agreed_failure(err, run, watch=watch)
+    except RuntimeError as e:
+        raised = str(e)
+    json.dump({"raised": raised, "own_error": err, "seconds": time.monotonic() - t0}, open(pathlib.Path(a.out) / f"rank{a.rank}.json", "w"))
+    watch.close()
+    np.savez(pathlib.Path(a.out) / f"rank{a.rank}.npz", idx=idx)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -166,3 +166,41 @@ def test_reference_fixtures_are_what_the_survey_says():
     # the reference's voxeliser rule (mesh.py:170-233) reproduced analytically for the palm box
     from softmac_amd import scenes
     assert np.abs(scenes.box_sdf()["sdf"] - palm["sdf"]).max() < 1e-12
+
+
+def test_fixture_F_columns_pin_the_constitutive_constants():
+    """the only constants of mpm_simulator.py:226-233 the reference's DATA can pin.  Both init-state files were written by
+    the reference's own `p2g` (`F[f + 1] = new_F`, :250), so their F columns carry its projection:
+      * grip (plastic, :226-229): every singular value of F lies inside the clip [1 - 2e-3, 1 + 3e-3] - a different clip constant, or clipping
+        applied to anything else than sigma, would show here (observed 0.99837 .. 1.00226: both ends are approached, neither is passed);
+      * pour (liquid, :233): F = J^(1/3) I exactly - zero off-diagonal entries, equal diagonal.
+    And ONE oracle substep from each fixture keeps both properties: the restatement's projection lands where the reference's did."""
+    g = np.load(H.GOLDEN / "grip_scene.npz")["state"]
+    p = np.load(H.GOLDEN / "pour_scene.npz")["state"]
+    LO, HI = 1.0 - 2e-3, 1.0 + 3e-3
+
+    def sv(F):
+        return np.linalg.svd(np.asarray(F).reshape(-1, 3, 3), compute_uv=False)
+
+    def anisotropy(F):
+        F = np.asarray(F).reshape(-1, 3, 3)
+        return np.abs(F - F[:, 0, 0][:, None, None] * np.eye(3)).max()
+
+    s = sv(g[:, 6:15])
+    assert LO - 1e-12 <= s.min() and s.max() <= HI + 1e-12, (s.min(), s.max())
+    assert s.min() < LO + 5e-4 and s.max() > HI - 1e-3            # the data comes close to both bounds: the bounds are pinned, not merely satisfied
+    assert anisotropy(p[:, 6:15]) == 0.0
+    d = p[:, 6]
+    assert 0.8 < d.min() and d.max() < 1.1 and d.std() > 1e-3     # J^(1/3) varies from particle to particle: not a constant fill
+
+    cfg = H.sim_cfg(len(g), n_grid=64, dt=2e-4, E=3e3, nu=0.2, ptype=0, material_model=0, ground_friction=20., collision_type=2, max_steps=3)
+    x, v, C, F = H.OracleRollout(H.oracle_params(cfg, 1e-3), g).forward(1).frames[-1]
+    s1 = sv(F.numpy())
+    assert LO - 1e-12 <= s1.min() and s1.max() <= HI + 1e-12, (s1.min(), s1.max())
+    cfg = H.sim_cfg(len(p), n_grid=64, dt=1e-3, E=22.0, nu=0.2, ptype=2, material_model=0, ground_friction=0.0, collision_type=2, max_steps=3)
+    x, v, C, F = H.OracleRollout(H.oracle_params(cfg, 1e-3), p).forward(1).frames[-1]
+    assert anisotropy(F.numpy()) == 0.0
+    # ... and J^(1/3) of the new F is the cube root of det(F_tmp) of the OLD isotropic F: det((I + dt C) c I) = c^3 det(I + dt C)
+    Cm = p[:, 15:24].reshape(-1, 3, 3)
+    J = d ** 3 * np.linalg.det(np.eye(3) + 1e-3 * Cm)
+    assert np.abs(F.numpy().reshape(-1, 3, 3)[:, 0, 0] - np.cbrt(J)).max() < 1e-12

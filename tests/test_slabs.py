@@ -163,6 +163,18 @@ def test_device_side_migration_between_two_ranks_gpu(tmp_path, precision, ts, tg
 
 
 @pytest.mark.gpu
+def test_pending_exchange_is_released_when_the_neighbour_fails_gpu(tmp_path):
+    """the healthy rank really has a pending exchange - it is inside smac_substeps_slab at the link's barrier - when its neighbour fails.
+    parallel.FailureWatch publishes out of band, the healthy rank's watch thread calls smac_comm_abort from a second host thread, both ranks raise."""
+    import json
+    _run_ranks("lib", "float64", tmp_path, 2, "lib_failure", env={"SMAC_COMM_STUB": "2"})
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert "injected failure on rank 1" in res[0]["raised"] and "injected failure on rank 1" in res[1]["raised"]
+    assert res[0]["own_error"] and "abort" in res[0]["own_error"]          # rank 0's pending call came back with the link's abort error ...
+    assert res[0]["seconds"] < 20.0 and res[1]["seconds"] < 20.0           # ... long before the link's 60 s timeout
+
+
+@pytest.mark.gpu
 def test_in_library_loop_and_migration_among_three_ranks_gpu(tmp_path):
     """World 3 over the IPC link: rank 1 is a MIDDLE slab - two different peers, both slots of every pack / unpack-add in use, arrivals from both sides
     in one migration - which neither the world-1 self exchange (both neighbours = this rank) nor the two-rank runs (one neighbour each) execute."""
@@ -280,7 +292,7 @@ def test_rendezvous_failure_reaches_every_rank(tmp_path, mode):
         assert res[0]["err"] is None and res[0]["failed"] == ["rank 1: SmacError: smac_comm_init failed"]
 
 
-@pytest.mark.parametrize("mode", ["fine", "rank1_fails"])
+@pytest.mark.parametrize("mode", ["fine", "rank1_fails", "rank1_fails_peer_pending"])
 def test_run_time_failure_on_one_rank_surfaces_on_all(tmp_path, mode):
     """an error inside the collective loop returns on ONE rank (drift, the slab-range guard, a HIP error) while its neighbour waits in the
     matching receive.  The failing rank's library aborts its communicator (softmac_hip.hip slab_guard); a host with a control plane then calls
@@ -295,5 +307,12 @@ def test_run_time_failure_on_one_rank_surfaces_on_all(tmp_path, mode):
     if mode == "fine":
         assert all(r["raised"] is None and not r["aborted"] for r in res)
     else:
-        assert res[0]["raised"] == res[1]["raised"] and "rank 1:" in res[0]["raised"] and "left the halo" in res[0]["raised"]
+        # rank1_fails_peer_pending: rank 0 sits in an exchange rank 1 never answers and cannot reach the all_gather by itself; rank 1 publishes
+        # through parallel.FailureWatch, rank 0's watch thread aborts its runner, the pending call returns and both ranks raise - within seconds, not after
+        # gloo's timeout
+        assert "rank 1:" in res[0]["raised"] and "left the halo" in res[0]["raised"] and "rank 1:" in res[1]["raised"]
+        if mode == "rank1_fails":
+            assert res[0]["raised"] == res[1]["raised"]
+        else:
+            assert "rank 0:" in res[0]["raised"] and "aborted" in res[0]["raised"] and res[0]["seconds"] < 20.0
         assert all(r["aborted"] for r in res)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """bench.py - MPM substeps/s (forward + backward) on the S-grip workload (BASELINE config C3:
 1,048,576 particles, 128^3 grid, plasticine + gripper SDF forecast contact), synthetic seeded data.
+`--workload s-pour` (C4: 4,194,304 liquid particles, 256^3, the reference's bowl) and `--workload s-mixed` (C5: 16,777,216
+particles, 256^3, two material blocks + rigid palm + sheet) are SURVEY 8(d)'s other two scenes under the same window scheme.
 
 One "step" = one substep() + one substep_grad() (its forward recompute included), run as K forward
 substeps followed by K backward substeps with inputs resident in HBM.  Contract: SURVEY/driver
@@ -43,6 +45,16 @@ def gripper_tables(dev=0):
     return _TABLES[dev]
 
 
+def bowl_table(dev=0):
+    """S-pour's bowl: the reference's bowl mesh (arrays in tests/golden/pour_scene.npz, made from assets by tools/make_fixtures.py) through the library's
+    voxeliser with the reference's sampling rule (mesh.py:170-233) - its cache blob is one of those missing from the reference checkout"""
+    if ("bowl", dev) not in _TABLES:
+        from softmac_amd.engine.primitive import voxelize
+        d = np.load(os.path.join(ROOT, "tests", "golden", "pour_scene.npz"))
+        _TABLES[("bowl", dev)] = voxelize.mesh_to_sdf(d["bowl_vertices"], d["bowl_faces"], device=dev)
+    return _TABLES[("bowl", dev)]
+
+
 def build_sim(args, rank, world, precision=None, frames=None):
     from softmac_amd import scenes
     from softmac_amd.config import CfgNode
@@ -64,6 +76,8 @@ def build_sim(args, rank, world, precision=None, frames=None):
         slab = (lh[0], lh[1], 2)
     elif args.workload == "s-grip":
         cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, frames, precision, dev, seed=1 + rank, tables=tables)
+    elif args.workload == "s-pour":
+        cfg, env_dt, state, specs, s13 = scenes.s_pour(args.particles, args.grid, frames, precision, dev, seed=2 + rank, bowl_table=bowl_table(dev))
     else:
         cfg, env_dt, state, specs, s13 = scenes.s_elastic(args.particles, args.grid, frames, precision, dev, seed=rank)
     cfg.recompute_backward = args.recompute_backward
@@ -201,15 +215,25 @@ def cpu_baseline(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
     from oracle import mpm_cpu
-    cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, "float64", 0, seed=1, tables=gripper_tables(0))
+    if args.workload == "s-pour":
+        cfg, env_dt, state, specs, s13 = scenes.s_pour(args.particles, args.grid, 8, "float64", 0, seed=2, bowl_table=bowl_table(0))
+        what = "liquid column over the reference's bowl, 1 primitive"
+    elif args.workload == "s-elastic":
+        cfg, env_dt, state, specs, s13 = scenes.s_elastic(args.particles, args.grid, 8, "float64", 0, seed=0)
+        what = "elastic block, no primitives"
+    else:
+        cfg, env_dt, state, specs, s13 = scenes.s_grip(args.particles, args.grid, 8, "float64", 0, seed=1, tables=gripper_tables(0))
+        what = "3 primitives"
     port = mpm_cpu.CpuPort(H.oracle_params(cfg, env_dt), specs)
     N = args.particles
     threads = port.threads()
     nsub = args.cpu_steps
     dt = _cpu_window(port, cfg, state, s13, nsub, N)
     out = {"value": nsub / dt, "unit": "substeps/s (fwd+bwd)", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
-           "sample": f"{nsub} forward + {nsub} backward substeps of the full workload ({N} particles, {args.grid}^3, 3 primitives), "
+           "sample": f"{nsub} forward + {nsub} backward substeps of the full workload ({N} particles, {args.grid}^3, {what}), "
                      f"f64 C++/OpenMP restatement of the reference's kernel decomposition (not Taichi), {dt:.1f} s on {threads} threads"}
+    if args.workload != "s-grip":
+        return out
     try:
         c2, env2, st2, sp2, s2 = scenes.s_elastic(1 << 18, 64, 8, "float64", 0, seed=0)
         port2 = mpm_cpu.CpuPort(H.oracle_params(c2, env2), sp2)
@@ -300,34 +324,81 @@ def env_loop_record(args, seed_gx):
                     "primitives as `value`"}
 
 
+def workload_text(args, N, cfg):
+    head = f"{args.workload}: {N} particles, {args.grid}^3 grid, dt {cfg.dt:g}, "
+    if args.workload == "s-grip":
+        return head + ("plastic fixed-corotated, 3 gripper SDF primitives (2 in forecast contact; palm = the reference's cached SDF table, fingers = "
+                       "finger.obj through smac_mesh_to_sdf), fwd+bwd")
+    if args.workload == "s-pour":
+        return head + ("liquid (ptype 2, E 22: demo_pour_config.py:9,20,28) falling into the reference's bowl (bowl.obj through smac_mesh_to_sdf, friction 1.0) "
+                       "in forecast contact, fwd+bwd - SURVEY 8(d) S-pour = BASELINE C4's scene on ONE GPU")
+    return head + "elastic fixed-corotated, no primitives, fwd+bwd"
+
+
+def metric_name(args):
+    """BASELINE.json's metric for the configuration it is quoted on (s-grip at its default size); any other workload says what it is"""
+    if args.workload == "s-grip" and args.particles == 1 << 20 and args.grid == 128:
+        return baseline_metric()
+    return f"MPM substeps/s (fwd+bwd), {args.workload} at {args.particles} particles / {args.grid}^3 (not the headline configuration)"
+
+
+def transport_note(run, sim, dist, world):
+    """What carried the shared planes in THIS run, read back from the objects that did it - never a constant."""
+    from softmac_amd.parallel import LibSlabRunner
+    if isinstance(run, LibSlabRunner):
+        kind, ranks = int(sim.get_param("comm_transport")), int(sim.get_param("comm_world"))
+        name = {1: "RCCL (ncclSend / ncclRecv inside libsoftmac_hip, its own communicator)",
+                2: "IPC link between processes sharing GPUs (SMAC_COMM_STUB=2: a test transport, host-synchronous - NOT a scaling number)",
+                3: "device-copy stub (SMAC_COMM_STUB=1: no bytes leave the GPU - NOT a scaling number)"}.get(kind, "none: the communicator is gone")
+        return f"{name}; {ranks} ranks in the library's communicator (launched: {world}); control plane torch.distributed/{dist.get_backend()}"
+    be = dist.get_backend()
+    how = "RCCL through torch.distributed" if be == "nccl" else f"torch.distributed/{be}: halo planes staged through the HOST - NOT a scaling number"
+    return f"{how}; {dist.get_world_size()} ranks in the process group"
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); spawned here when not already under torchrun")
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=None, help="substep pairs per window (default 32; s-mixed: 5 - a frame of 16M particles is 3.2 GB)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--repeats", type=int, default=0, help="number of K-step windows (0: window_plan - as many as give the re-sorts their steady-state share, at least 8)")
-    ap.add_argument("--workload", default="s-grip", choices=["s-grip", "s-elastic"])
+    ap.add_argument("--workload", default="s-grip", choices=["s-grip", "s-elastic", "s-pour", "s-mixed"],
+                    help="SURVEY 8(d)'s scenes: s-grip = BASELINE C3 (the metric's configuration), s-elastic = C2, s-pour = C4 (4M / 256^3 on one GPU), s-mixed = C5 (16M / 256^3)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the metric's one 1M-particle scene cut into N slabs; weak = N bars of 1M particles each")
-    ap.add_argument("--particles", type=int, default=1 << 20)
-    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--particles", type=int, default=None, help="default: the workload's size (s-grip 1,048,576; s-elastic 262,144; s-pour 4,194,304; s-mixed 16,777,216)")
+    ap.add_argument("--grid", type=int, default=None, help="default: the workload's grid (128 / 64 / 256 / 256)")
     ap.add_argument("--precision", default="float32", choices=["float32", "float64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the float64 sub-record (the mode that equals the reference's dtype)")
     ap.add_argument("--no-cloth", action="store_true", help="skip the soft <-> cloth sub-record (tools/bench_cloth.py in a child process)")
     ap.add_argument("--no-env-loop", action="store_true", help="skip the env_loop sub-record (the reference's TaichiEnv.step / backward loop on the same workload)")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=None, help="substep pairs of the CPU baseline's sample (default 8; s-pour 2)")
     ap.add_argument("--recompute-backward", action="store_true", help="substep_grad recomputes the forward grid (reference style)")
     ap.add_argument("--sort-interval", type=int, default=0, help="0: the library's default")
-    ap.add_argument("--slab-runner", default=os.environ.get("SMAC_SLAB_RUNNER", "python"), choices=["lib", "python"],
-                    help="N > 1: python (default) = parallel.SlabRunner on torch.distributed (RCCL through torch); lib = smac_substeps_slab (RCCL inside "
-                         "the library) - selectable, not the default, until it has run between two different ranks (it has only run as a world-1 self exchange)")
+    ap.add_argument("--slab-runner", default=os.environ.get("SMAC_SLAB_RUNNER", "lib"), choices=["lib", "python"],
+                    help="N > 1: lib (default since round 5) = smac_substeps_slab, the loop inside the library with its own RCCL communicator and the fused particle "
+                         "launches - its distinct-peer code has run between 2 and 3 ranks over the IPC test transport; if the communicator does not come up on "
+                         "every rank the run falls back, on every rank together, to python = parallel.SlabRunner on torch.distributed (plain kernels, slower)")
+    ap.add_argument("--first-window-limit", type=float, default=float(os.environ.get("SMAC_FIRST_WINDOW_LIMIT", 240.0)),
+                    help="N > 1: seconds the warm-up window (the first place an N-rank run can hang: first exchange, first migration) may take before the rank "
+                         "publishes a failure, aborts its communicator and exits with status 3 - a fresh non-zero exit, nothing is re-executed")
     ap.add_argument("--migrate-every", type=int, default=0,
                     help="N > 1, strong scaling, --slab-runner lib: hand particles over between the slabs (smac_migrate, device side) every k substeps INSIDE the "
                          "timed window; the handles get 25 %% spare capacity and one extra frame per migration")
     ap.add_argument("--launch-check", action="store_true",
                     help="spawn the ranks, rendezvous (gloo), report - no simulator, no GPU call (CPU test of the launcher)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    size = {"s-grip": (1 << 20, 128), "s-elastic": (1 << 18, 64), "s-pour": (1 << 22, 256), "s-mixed": (1 << 24, 256)}[args.workload]
+    if args.particles is None:
+        args.particles = size[0]
+    if args.grid is None:
+        args.grid = size[1]
+    if args.steps is None:
+        args.steps = 5 if args.workload == "s-mixed" else 32
+    if args.cpu_steps is None:
+        args.cpu_steps = 2 if args.workload == "s-pour" else 8
+    return args
 
 
 def launch_children(args, argv):
@@ -435,7 +506,14 @@ def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist, windows=None)
         return f_end
 
     sim.clear_grads()
+    watch = getattr(args, "failure_watch", None)
+    if watch is not None:
+        watch.arm(args.first_window_limit, f"the warm-up window ({W} substep pairs: the first exchanges of the {getattr(args, 'gpus', None)}-rank run)")
     pair(0, W)
+    sim.sync()
+    if watch is not None:
+        watch.disarm()
+        watch.check()
     walls, devs = [], []
     f0 = W
     starts = []
@@ -465,6 +543,161 @@ def timed_windows(args, sim, run, reducer, seed_gx, barrier, dist, windows=None)
     return walls, devs, forward, backward
 
 
+def run_mixed(args):
+    """S-mixed (BASELINE config C5): 16,777,216 particles / 256^3, two material blocks, the reference's cached gripper palm pressed into the
+    cylinder from above, the sticky sheet under it - ONE handle with both kinds of primitive.  The loop is the reference's soft_cloth env loop
+    (soft_cloth/engine/taichi_env.py:86-106: substep, contact-face search, penetration tracing per substep) forward, then substep_grad in reverse; windows
+    of exactly K substep pairs advancing through one episode, every window counted, the loss seed added from HBM inside the window - the scheme of
+    `timed_windows`.  A frame of this scene is 3.2 GB (state + adjoint), hence the short default K = 5."""
+    import torch
+    torch.cuda.init()
+    from softmac_amd import scenes
+    from softmac_amd.config import CfgNode
+    from softmac_amd.engine.primitive import Mesh, Primitives
+    from softmac_amd.soft_cloth.engine.mpm_simulator import MPMSimulator
+    from softmac_amd.soft_cloth.engine.primitive import Primitive_Cloth
+    K, W = args.steps, args.warmup
+    R = args.repeats if args.repeats > 0 else 8
+    frames = W + R * K + 2
+    N = args.particles
+    palm = np.load(os.path.join(ROOT, "tests", "golden", "palm_sdf.npz"))
+    palm = dict(sdf=palm["sdf"], normal=palm["normal"], lower=palm["lower"], upper=palm["upper"], dx=float(palm["dx"]), res=palm["res"])
+    rings = max(12, 48 * args.grid // 256)
+    cfg, env_dt, state, V, F, sheet_cfg, rigid, s13, mat_id, mat2 = scenes.s_mixed(N, args.grid, max_steps=frames, precision=args.precision, rings=rings, palm=palm)
+    cfg.sort_interval = args.sort_interval
+    sheet = Primitive_Cloth(CfgNode(sheet_cfg), max_timesteps=cfg.max_steps, mpm_scale=1.0, vertices=V, faces=F)
+    rc = CfgNode()
+    rc.friction, rc.enable_external_force, rc.urdf_path = rigid["friction"], True, ""
+    mesh = Mesh(sdf=rigid, cfg=rc, max_timesteps=cfg.max_steps)
+    sim = MPMSimulator(cfg, sheet, env_dt, 1.0, rigid_primitives=Primitives(primitives=[mesh]))
+    sheet.initialize()
+    mesh.softness[None] = 666.0
+    mesh.friction[None] = rigid["friction"]
+    sim.primitives_contact = [True]
+    Vv = np.zeros_like(V)
+    sheet.set_all_states(0, V, Vv, f_end=cfg.max_steps)
+    for f in range(cfg.max_steps):
+        st = s13.copy()
+        st[:3] += f * cfg.dt * s13[7:10]
+        mesh.set_all_states(f, st)
+    sim.set_materials(mat_id, mat2["E"], mat2["nu"], mat2["yield_stress"])
+    sim.reset(state)
+    rng = np.random.default_rng(7)
+    seed_dev = torch.from_numpy(rng.standard_normal((N, 3))).to(f"cuda:{sim.device}")
+    del state
+    sim.get_contact_pair(0)
+
+    def forward(f0, n):
+        for s_ in range(f0, f0 + n):
+            sim.substep(s_)
+            sim.get_contact_pair(s_ + 1)
+            sim.trace_penetration_after_mpm(s_ + 1)
+
+    def backward(f0, n):
+        for s_ in range(f0 + n - 1, f0 - 1, -1):
+            sim.substep_grad(s_)
+
+    def pair(f0, n):
+        forward(f0, n)
+        sim.add_grad_device(f0 + n, gx=seed_dev)
+        backward(f0, n)
+
+    sim.clear_grads()
+    pair(0, W)
+    walls, devs, starts = [], [], []
+    f0 = W
+    for _ in range(R):
+        sim.clear_grads()
+        sim.sync()
+        t0 = time.perf_counter()
+        sim.timer_start()
+        pair(f0, K)
+        dev_ms = sim.timer_stop()
+        sim.sync()
+        walls.append(time.perf_counter() - t0)
+        devs.append(dev_ms)
+        starts.append(f0)
+        f0 += K
+    wall, dev_ms = sum(walls) / len(walls), sum(devs) / len(devs)
+    sim.profile(True)
+    for f0 in starts[-2:]:                                  # per-kernel HIP-event profile over the last two windows once more (out of the timed region)
+        sim.clear_grads()
+        pair(f0, K)
+    prof = sim.profile_report()
+    sim.profile(False)
+    prof_substeps = 2 * K
+    G_t = sim.count_active_cells(W)
+    n_hits = sim.contact_counts()[0]
+    ids, pen = sim.get_contact(W)
+    kern = {k: v for k, v in prof.items() if v[1] > 0}
+    dom = max((k for k in kern if k not in ("sort", "reorder_adjoint")), key=lambda k: kern[k][0])
+    avg_ms = kern[dom][0] / kern[dom][1]
+    sbytes = 4 if args.precision == "float32" else 8
+    pp, pc = KERNEL_BYTES.get(dom, (0, 0))
+    alg = (pp * N + pc * G_t) * sbytes
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    ab = algorithmic_bytes(N, G_t, sbytes)
+    sub_gbs = (ab["fwd"] + ab["bwd"]) * (K / (dev_ms * 1e-3)) / 1e9
+    out = {"metric": metric_name(args), "value": K / wall, "unit": "substeps/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * wall / K,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",
+           "config": {"workload": (f"s-mixed: {N} particles, {args.grid}^3 grid, dt {cfg.dt:g}, von-Mises plasticine in TWO material blocks (E {cfg.E:g} / {mat2['E']:g}, yield stress "
+                                   f"{cfg.yield_stress:g} / {mat2['yield_stress']:g}), one rigid SDF primitive (the reference's cached gripper palm) AND a sticky triangle-mesh sheet of "
+                                   f"{len(F)} faces in forecast contact; per substep the contact-face search and the penetration tracing of the reference's soft_cloth loop; fwd+bwd - "
+                                   "SURVEY 8(d) S-mixed = BASELINE C5 on ONE GPU"),
+                      "n_grid": args.grid, "touched_cells": G_t, "contact_particles": n_hits, "particles_holding_a_face": int((ids >= 0).sum()), "penetrated": int((pen == 1).sum()),
+                      "resort_interval": args.sort_interval, "resorts_in_windows": int(kern.get("sort", (0, 0))[1]),
+                      "windows": (f"{R} windows of exactly {K} substep pairs each, advancing through one episode (frames {W} .. {W + R * K}); the loss seed is added from HBM "
+                                  "inside each window; value = K / mean window time, no window dropped"),
+                      "parallelism": "1 gpu"},
+           "repeats": R, "aggregate": "mean", "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls], "spread": (max(walls) - min(walls)) / wall,
+           "device_ms_per_step": dev_ms / K, "drift_repairs": int(sim.get_param("drift_repairs")),
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                        "traffic_note": "no PMC pass was taken for this workload", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
+           "roofline_substep": {"algorithmic_bytes_fwd_bwd": ab["fwd"] + ab["bwd"], "achieved": sub_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sub_gbs / PEAK_HBM_GBS},
+           "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in kern.items()},
+           "kernels_ms_per_step": {k: round(v[0] / prof_substeps, 4) for k, v in kern.items()}}
+    sim._h.close()
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_mixed(args, palm)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_mixed(args, palm):
+    """CPU baseline of S-mixed: the composed torch-f64 oracle (oracle/mixed_oracle.py: NOT Taichi, NOT the reference - the reference has no simulator with
+    both primitive kinds) on a BOUNDED SAMPLE: the same scene generator at 1/64 of the particles on a grid of a quarter the resolution per axis (same 8
+    particles per cell, same shapes), one substep forward + its adjoint; `value` is that rate scaled by (sample particles / full particles) - linear in
+    N, which is what the dense per-particle torch ops cost - and says so."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H                                     # noqa: F401  (puts the repo root on sys.path for `oracle`)
+    import dataclasses
+    from oracle import cloth_oracle as CO, mixed_oracle as MO, softmac_oracle as O
+    from softmac_amd import scenes
+    n_s, g_s = min(max(args.particles // 64, 1 << 14), 1 << 17), max(args.grid // 4, 32)      # (131,072 particles: ~20-50 s of torch work)
+    cfg, env_dt, state, V, F, sheet_cfg, rigid, s13, mat_id, mat2 = scenes.s_mixed(n_s, g_s, max_steps=4, precision="float64", rings=12, palm=palm)
+    P = CO.ClothSimParams(n_grid=g_s, dt=cfg.dt, E=cfg.E, nu=cfg.nu, ptype=0, material_model=0, gravity=tuple(cfg.gravity), yield_stress=cfg.yield_stress,
+                          collision_type=2, substeps=int(round(env_dt / cfg.dt)), scale=1.0)
+    P2 = dataclasses.replace(P, E=mat2["E"], nu=mat2["nu"], yield_stress=mat2["yield_stress"])
+    x, v, C, Fm = O.state24_split(state)
+    faces = torch.as_tensor(F.astype(np.int64))
+    sheet = CO.ClothPrim(position=torch.as_tensor(V), velocity=torch.zeros(V.shape, dtype=O.DT), faces=faces, friction=sheet_cfg["friction"], softness=sheet_cfg["softness"],
+                         cloth_force_scale=sheet_cfg["cloth_force_scale"], sticky=sheet_cfg["sticky"])
+    prim = O.make_prim(s13[:3], s13[3:7], s13[7:10], s13[10:13], rigid["sdf"], rigid["normal"], rigid["lower"], rigid["upper"], rigid["dx"], rigid["friction"], rigid["softness"], True)
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    ids = np.asarray(CO.get_contact_pair(x, sheet.position, faces, np.zeros(n_s, dtype=np.int64), 1.0))
+    pen = np.zeros(n_s, dtype=np.int64)
+    nx, nv, nC, nF, er, ec = MO.substep(x, v, C, Fm, P, [prim], sheet, ids, pen, 0, P2, mat_id)
+    g = MO.substep_grad(x, v, C, Fm, P, [prim], sheet, ids, pen, 0, torch.ones_like(nx), torch.zeros_like(nv), torch.zeros_like(nC), torch.zeros_like(nF), P2=P2, mat_id=mat_id)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(g["gx"]).all()
+    return {"value": (1.0 / dt) * n_s / args.particles, "unit": "substeps/s (fwd+bwd)", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "sample": (f"1 forward + 1 backward substep (contact-face search included) of the SAME scene generator at {n_s} particles / {g_s}^3 (1/{args.particles // n_s} of the "
+                       f"particles, 8 per cell as at full size), composed torch-f64 oracle (oracle/mixed_oracle.py; not Taichi), {dt:.1f} s on {threads} torch threads; "
+                       f"value = that rate x {n_s}/{args.particles} (linear in N)"),
+            "sample_substeps_per_s": 1.0 / dt}
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -479,6 +712,10 @@ def main():
         return launch_check(args, world, rank)
     if args.sort_interval <= 0:
         args.sort_interval = LIB_SORT_INTERVAL              # the library's default (smac_config.sort_interval = 0): what a caller of the engine gets
+    if args.workload == "s-mixed":
+        if world > 1:
+            sys.exit("bench.py: --workload s-mixed runs on one GPU (the slab runners do not carry the sheet's contact search)")
+        return run_mixed(args)
     dist = None
     import torch
     torch.cuda.init()           # torch's HIP runtime comes up BEFORE libsoftmac_hip loads the system's (the other order leaves torch without a device)
@@ -496,9 +733,14 @@ def main():
     rng = np.random.default_rng(7 + rank)
     seed_gx = rng.standard_normal((N_local, 3))
     reducer = None
+    watch = None
     if world > 1:
-        from softmac_amd.parallel import LibSlabRunner, PrimitiveReducer
+        from softmac_amd.parallel import FailureWatch, LibSlabRunner, PrimitiveReducer
         reducer = run if isinstance(run, LibSlabRunner) else PrimitiveReducer(sim)
+        # out-of-band failure channel: a rank that fails inside the loop publishes; its neighbours' watch threads abort their communicators so
+        # that their pending receives return, and every rank exits non-zero instead of waiting for the launcher's timeout
+        watch = FailureWatch(rank, world, runner=run if hasattr(run, "abort") else None)
+        args.failure_watch = watch
 
     def barrier():
         sim.sync()
@@ -517,6 +759,8 @@ def main():
         # NOW with a non-zero status and the launcher (torch.distributed.run) stops the others.  os._exit: no destructor may wait on the dead exchange.
         print(f"bench.py: rank {rank} failed inside the collective run: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         try:
+            if watch is not None and not watch.failure:     # (a rank that was stopped BY the watch does not publish: the first failure is the one to read)
+                watch.publish(f"{type(e).__name__}: {e}")
             if hasattr(run, "abort"):
                 run.abort()
         except Exception:                                   # noqa: BLE001
@@ -605,15 +849,12 @@ def main():
             par = (f"weak scaling: {world} x-slabs of one bar, {N} particles each; value counts every slab's substep; per substep "
                    f"neighbour-only RCCL send/recv of 2 shared grid planes")
         out = {
-            "metric": baseline_metric(),
+            "metric": metric_name(args),
             "value": value, "unit": "substeps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * wall / K, "higher_is_better": True,
             "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "float32" else "f64", "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: {N} particles, {args.grid}^3 grid, plastic fixed-corotated, "
-                                    f"3 gripper SDF primitives (2 in forecast contact; palm = the reference's cached SDF table, fingers = "
-                                    f"finger.obj through smac_mesh_to_sdf), fwd+bwd") if args.workload == "s-grip" else
-                                   f"{args.workload}: {N} particles, {args.grid}^3 grid, elastic fixed-corotated, no primitives, fwd+bwd",
+            "config": {"workload": workload_text(args, N, cfg),
                        "particles_per_gpu": [c[0] for c in allc] if world > 1 else N, "n_grid": args.grid,
                        "touched_cells": Gsum if world > 1 else G_t, "contact_particles": sum(c[2] for c in allc),
                        "backward": "forward grid recomputed in substep_grad (reference style)" if args.recompute_backward
@@ -623,11 +864,10 @@ def main():
                                    "the loss seed is added from HBM inside each window; value = K / mean window time, no window dropped"),
                        "parallelism": par},
             "slab_runner": None if world == 1 else (getattr(run, "fallback_note", None) or (("in-library slab loop over the IPC test transport" if os.environ.get("SMAC_COMM_STUB") == "2" else "in-library RCCL loop") if args.slab_runner == "lib" else "Python SlabRunner")),
-            "transport": None if world == 1 else ("IPC link between processes sharing GPUs (SMAC_COMM_STUB=2: a test transport, host-synchronous - NOT a scaling number)"
-                                                    if os.environ.get("SMAC_COMM_STUB") == "2" else "RCCL"),
+            "transport": None if world == 1 else transport_note(run, sim, dist, world),
             "migrations_in_window": int(getattr(timed_windows, "migrations", 0)), "particles_migrated": int(getattr(timed_windows, "moved", 0)),
-            "multi_gpu_note": None if world == 1 else ("no N > 1 run on N GPUs existed when this code was committed: the in-library slab loop has run between two ranks "
-                                                         "over the IPC test transport on one GPU (tests/test_slabs.py) and as a world-1 RCCL self exchange"),
+            "multi_gpu_note": None if world == 1 else ("no N > 1 run on N GPUs existed when this code was committed: the in-library slab loop has run between two and three "
+                                                         "ranks over the IPC test transport on one GPU (tests/test_slabs.py) and as a world-1 RCCL self exchange"),
             "repeats": len(walls), "aggregate": "mean", "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
             "spread": (max(walls) - min(walls)) / wall,
             "device_ms_per_step": dev_ms / K,
@@ -645,7 +885,7 @@ def main():
                 out[name] = {"value": K / t, "unit": "substeps/s", "ms_per_step": 1e3 * t / K, "algorithmic_bytes": ab[key],
                              "achieved": gbs, "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS,
                              "note": f"{K} {'forward' if key == 'fwd' else 'backward'} substeps of the same window, one sync before and after"}
-    if world == 1 and args.precision == "float32" and not args.no_f64:
+    if world == 1 and args.precision == "float32" and not args.no_f64 and args.workload in ("s-grip", "s-elastic"):
         # the mode that computes in the reference's own dtype (mpm_simulator.py:19) and meets 1e-9: one window, same workload
         del run
         sim._h.close()
@@ -680,6 +920,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
+    if watch is not None:
+        watch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

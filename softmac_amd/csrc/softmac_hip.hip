@@ -1355,6 +1355,8 @@ template <class R> struct Sim final : ISim {
         if (!strcmp(name, "drift_repairs")) *value = (double)drift_repairs;             // epochs recomputed because a particle out-ran its binning
         else if (!strcmp(name, "cloth_hash_entries")) *value = hash_total_host ? (double)*hash_total_host : 0.0;   // (face, block) pairs of the last broad-phase build
         else if (!strcmp(name, "exchanges")) *value = (double)exchanges_done;          // halo exchanges run by smac_substeps_slab[_grad] so far
+        else if (!strcmp(name, "comm_world")) *value = (comm || (comm_stub == 2 && ipc.shm)) ? (double)c_world : 0.0;   // ranks of this handle's LIVE communicator (0: none / aborted)
+        else if (!strcmp(name, "comm_transport")) *value = comm ? 1.0 : ((comm_stub == 2 && ipc.shm) ? 2.0 : (comm_stub == 1 && sc.on ? 3.0 : 0.0));   // 1 RCCL, 2 IPC test link, 3 device-copy stub, 0 none
         else if (!strcmp(name, "contact_skips")) *value = (double)contact_skips;        // backward substeps that needed no contact adjoint launch (empty filed hit list)
         else if (!strcmp(name, "hit_overflows")) *value = (double)hit_overflows;      // times a contact hit list did not fit its checkpoint slot (backward then repeats the band test)
         else if (!strcmp(name, "plasticity")) *value = (double)D.mat.plast;
@@ -1371,7 +1373,7 @@ template <class R> struct Sim final : ISim {
             }
             *value = (double)h;
         }
-        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | exchanges | resorts | resort_moved | resort_far | cloth_hash_entries | plasticity | yield_ratio | mass_eps)");
+        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | exchanges | comm_world | comm_transport | resorts | resort_moved | resort_far | cloth_hash_entries | plasticity | yield_ratio | mass_eps)");
         return SMAC_OK;
     }
     int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,

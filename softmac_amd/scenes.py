@@ -86,15 +86,24 @@ def table_spec(t):
                 upper=np.asarray(t["upper"], dtype=np.float64), dx=float(t["dx"]), res=np.asarray(t["res"]))
 
 
-def s_grip(n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
+def grip_dt(n_grid):
+    """SURVEY 8(d): dt = 1e-4 at dx = 1/128 keeps the plastic block's elastic wave (c = sqrt((lam + 2 mu) / rho) = 57.7 m/s) at c dt / dx = 0.74;
+    the same Courant number at any other resolution (2e-4 at 64^3 - the reference's own demo_grip_config.py:25 - and 5e-5 at 256^3).  Round 4 kept
+    1e-4 at 256^3 (c dt / dx = 1.48) and the scene diverged from frame 22 on."""
+    return 1e-4 * 128.0 / n_grid
+
+
+def s_grip(n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=None,
            substeps=10, x_offset=0.0, tables=None):
-    """Returns (cfg namespace, env_dt, state24, primitive specs, primitive state13 at frame 0).
+    """Returns (cfg namespace, env_dt, state24, primitive specs, primitive state13 at frame 0).  dt=None: `grip_dt(n_grid)`.
 
     tables = (palm, finger): the gripper's SDF tables as SURVEY 8(d) asks for them - the palm from the reference's own cache
     (assets/gripper/6895...c4d5), the finger voxelised from assets/gripper/finger.obj by the library's mesh -> SDF kernel (row f3); bench.py
     passes them (`gripper_tables`).  None: tables built analytically with the reference voxeliser's sampling rule (the tests' default: no
     fixture files, no GPU call before the simulator exists; the palm table equals the cache to 2e-16, the finger is a true cylinder instead
     of finger.obj's 32-sided prism)."""
+    if dt is None:
+        dt = grip_dt(n_grid)
     center = (0.5 + x_offset, 0.3, 0.5)
     state, lo, side = block_cloud(n_particles, n_grid, center, ppc=8, seed=seed, v_std=0.05, C_std=0.5, F_std=5e-3)
     cfg = sim_namespace(n_particles=n_particles, n_grid=n_grid, dt=dt, max_steps=max_steps, precision=precision,
@@ -119,13 +128,15 @@ def s_elastic(n_particles=1 << 18, n_grid=64, max_steps=128, precision="float32"
     return cfg, 2e-3, state, [], []
 
 
-def s_grip_slab(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
+def s_grip_slab(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=None,
                 substeps=10, lo=32, hi=96):
     """Weak-scaling variant of S-grip for several GPUs: one continuous bar of plasticine along x, cut into
     `world` slabs.  Rank r simulates in local coordinates on its own n_grid^3 grid and owns the particles whose
     stencil base lies in x-planes [lo, hi); its planes [hi, hi+2) are the same physical planes as the right
     neighbour's [lo, lo+2).  Same particle count, density and primitives per GPU as the single-GPU workload
     (the two fingers close on the bar's z faces)."""
+    if dt is None:
+        dt = grip_dt(n_grid)
     rng = np.random.default_rng(seed + 1000 * rank)
     wx = hi - lo
     side = (n_particles / 8 / wx) ** 0.5                     # y,z extent in cells at 8 particles per cell
@@ -187,7 +198,7 @@ def gripper_tables(fixture_dir, device=0):
     return dict(sdf=palm["sdf"], normal=palm["normal"], lower=palm["lower"], upper=palm["upper"], dx=float(palm["dx"]), res=palm["res"]), finger
 
 
-def s_grip_strong(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=1e-4,
+def s_grip_strong(rank, world, n_particles=1 << 20, n_grid=128, max_steps=128, precision="float32", device=0, seed=1, dt=None,
                   substeps=10, drift_tol=1, tables=None):
     """Strong-scaling form of S-grip (the metric's "1M particles / 128^3 on 1/2/4/8 GPUs"): the SAME scene as `s_grip`
     - one block, one global grid, the shared gripper primitives - cut into `world` x-slabs balanced by particle count.

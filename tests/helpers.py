@@ -130,8 +130,20 @@ def clamp_zone(orc, P, nsteps, margin=3e-6, neighbours=False):
         mask |= here
         if neighbours and here.any():
             base = (x.numpy() * P.inv_dx - 0.5).astype(np.int64)
-            for b in base[here]:
-                near |= (np.abs(base - b).max(axis=1) <= 2)
+            if N <= 20000:
+                for b in base[here]:
+                    near |= (np.abs(base - b).max(axis=1) <= 2)
+            else:                                   # the same set through a dense node grid (the loop above is O(zone x N): minutes at 1M particles)
+                n = int(P.n_grid)
+                g = np.zeros((n + 4, n + 4, n + 4), dtype=bool)
+                b = np.clip(base, 0, n - 1) + 2
+                g[b[here, 0], b[here, 1], b[here, 2]] = True
+                d = np.zeros_like(g)
+                for ox in range(-2, 3):              # max-norm dilation by 2 cells: stencil bases at most 2 apart share a node
+                    for oy in range(-2, 3):
+                        for oz in range(-2, 3):
+                            d[2:-2, 2:-2, 2:-2] |= g[2 + ox:n + 2 + ox, 2 + oy:n + 2 + oy, 2 + oz:n + 2 + oz]
+                near |= d[b[:, 0], b[:, 1], b[:, 2]]
     near &= ~mask
     return (mask, near) if neighbours else mask
 

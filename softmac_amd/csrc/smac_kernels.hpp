@@ -49,6 +49,9 @@ namespace smac {
 #ifndef SMAC_G2P_ROLLED
 #define SMAC_G2P_ROLLED 1        // the G2P gather with its x-planes as a real loop: 9 records live instead of 27, k_g2p 115 -> 88 and k_g2p_p2g 121 -> 96 VGPRs, 5 waves per SIMD (profiles/r04_ad_forward_variants.txt; 0: the unrolled form)
 #endif
+#ifndef SMAC_CONTACT_HYBRID
+#define SMAC_CONTACT_HYBRID 1    // float32 mode: forecast contact in two widths - the signed distance in f64, the rest in f32 (collide_mixed_hybrid; 0: all f64, rounds 1-4)
+#endif
 #ifndef SMAC_PHASE_CLOCK
 #define SMAC_PHASE_CLOCK 0       // 1 (tools/phase_clock.sh only): 1 workgroup in 16 of the particle kernels files s_memtime at its phase boundaries
 #endif
@@ -159,6 +162,13 @@ template <class R> struct DevSim {
     const Vec4<R>* halo_recv;
     int keep_vmix;               // k_grid_op also stores grid_v_mixed (the slab phases' halo exchange sends v_out - v_mixed); otherwise it is recomputed where it is read
     int zero_next_hits;          // k_grid_op: empty the next substep's counter (its P2G rides in this substep's G2P launch and appends right away)
+    // Tail reduction (round 5): the slab reduction + grid_op (forward) / + grid_op's node adjoint (backward) are done INSIDE the particle
+    // kernel that scatters, by the workgroup whose arrival completes a block's count - k_grid_op and the reduction half of k_reduce_grid_grad_ahead go.
+    int tail_on;                 // this launch's scatter ends with the arrival protocol (tail_arrive)
+    int tail_rule;               // handle-wide: binning valid only while every stencil stays inside the 27-block neighbourhood of the particle's chunk (g2p_particle)
+    int tail_extra;              // arrivals per block on top of tail_expect (1: the checkpoint-save wave of the block in the same launch reads what the reducer overwrites)
+    int* tail_cnt;               // [blocks] arrival counters, zero between launches (the last arriver resets its block's)
+    const int* tail_expect;      // [blocks] chunks of the 27 blocks around it (smac_sort.hpp k_tail_expect)
     ClothDev cloth;              // soft <-> cloth contact (present = 0: none)
 };
 
@@ -406,15 +416,52 @@ template <class R> __device__ __forceinline__ int active_slot(const DevSim<R>&) 
     if (cid >= D.nchunks) return;                             \
     SMAC_CHUNK_PROLOGUE_AT(cid)
 
+// ------------------------------------------------------------------------------------------
+// Agent-scope ("sc1") accesses: bytes one workgroup hands to ANOTHER workgroup of the same launch (tail reduction below).  A CU's vector L1 is never refreshed
+// by other CUs' stores and the eight XCD L2s are not coherent for plain accesses (MI355X_MICROARCH.md, inter-workgroup visibility); the hand-off used here is
+// that guide's counter form with write-through stores: EVERY store of the handed-off bytes is an sc1 store, every storing wave drains (s_waitcnt vmcnt(0)), a
+// workgroup barrier, ONE wave adds to the counters (agent-scope atomics), the workgroup whose add came last - told by the value the add returned - reads
+// the bytes with sc1 loads only.  Float atomics (the drift field) execute at the memory side and are agent-scope by themselves.
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sc1_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00027000);       // raw buffer: byte offsets, 32-bit data format
+}
+constexpr int AUX_SC1 = 16;
+__device__ __forceinline__ Vec4<float> ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned rec, const Vec4<float>*) {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rec * 16u), 0, AUX_SC1);
+    Vec4<float> v = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+    return v;
+}
+__device__ __forceinline__ Vec4<double> ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned rec, const Vec4<double>*) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rec * 32u), 0, AUX_SC1), b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rec * 32u + 16u), 0, AUX_SC1);
+    Vec4<double> v = {__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z), __hiloint2double((int)b.y, (int)b.x), __hiloint2double((int)b.w, (int)b.z)};
+    return v;
+}
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t rs, unsigned rec, const Vec4<float>& v) {
+    const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)(rec * 16u), 0, AUX_SC1);
+}
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t rs, unsigned rec, const Vec4<double>& v) {
+    const u32x4 a = {(unsigned)__double2loint(v.x), (unsigned)__double2hiint(v.x), (unsigned)__double2loint(v.y), (unsigned)__double2hiint(v.y)};
+    const u32x4 b = {(unsigned)__double2loint(v.z), (unsigned)__double2hiint(v.z), (unsigned)__double2loint(v.w), (unsigned)__double2hiint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(a, rs, (int)(rec * 32u), 0, AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(b, rs, (int)(rec * 32u + 16u), 0, AUX_SC1);
+}
+
 // store this chunk's f64 LDS tile (NS scalars, tile[s][word]) to its slab as 16-byte records, coalesced
-template <class R, int NS, class W> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const W* tile, R s0 = R(1), R s123 = R(1), int cid = -1) {
-    Vec4<R>* dst = D.slab + (size_t)(cid >= 0 ? cid : xcd_chunk(D.nchunks)) * TILE_WORDS;
+// (sc1: write-through stores - the slab is read by another workgroup of this launch, see tail_arrive)
+template <class R, int NS, class W> __device__ __forceinline__ void tile_store(const DevSim<R>& D, const W* tile, R s0 = R(1), R s123 = R(1), int cid = -1, bool sc1 = false) {
+    const unsigned first = (unsigned)(cid >= 0 ? cid : xcd_chunk(D.nchunks)) * TILE_WORDS;
+    Vec4<R>* dst = D.slab + first;
+    const __amdgpu_buffer_rsrc_t rs = sc1_rsrc(D.slab);
     for (int i = threadIdx.x; i < TILE_WORDS; i += BLOCK) {
         const int w = SMAC_WIDE_TILE ? (i / TSX + PO) * PSX + ((i / TSY) % TW + PO) * PSY + i % TW + PO : i;      // the 6^3 core of the wide tile
         Vec4<R> v;
         v.x = (R)tile[w] * s0; v.y = (R)tile[PTILE + w] * s123; v.z = (R)tile[2 * PTILE + w] * s123;
         v.w = NS > 3 ? (R)tile[3 * PTILE + w] * s123 : R(0);
-        dst[i] = v;
+        if (sc1) st_sc1(rs, first + (unsigned)i, v);
+        else dst[i] = v;
     }
 }
 // zero `bytes` (a multiple of 16) of LDS with 16-byte stores
@@ -451,7 +498,7 @@ template <class R, int NS, class W> __device__ __forceinline__ void tile_flush_s
 
 // Sum, for one cell of block `b`, every slab record that overlaps it (own block and the blocks at -1
 // along each dimension in which the cell's local coordinate is <= 1).
-template <class R>
+template <class R, bool SC1 = false>
 __device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, Vec4<R>& acc) {
     // Called by a whole wave for the 64 cells of block b.  The <= 8 source blocks (b and its -1 neighbours) are the same
     // for every lane: lanes 0..7 fetch their chunk ranges in ONE round trip and broadcast them; then up to 4 slab
@@ -479,19 +526,22 @@ __device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, Ve
         const bool mine = dx <= ex && dy <= ey && dz <= ez;
         const int w = tile_index(lx + 4 * dx, ly + 4 * dy, lz + 4 * dz);
         const Vec4<R>* sl = D.slab + (size_t)start * TILE_WORDS + w;
+        const unsigned rec0 = (unsigned)start * TILE_WORDS + (unsigned)w;
+        const __amdgpu_buffer_rsrc_t rs = sc1_rsrc(D.slab);
+        auto rd = [&](int c) { return SC1 ? ld_sc1(rs, rec0 + (unsigned)c * TILE_WORDS, sl) : sl[(size_t)c * TILE_WORDS]; };
         const Vec4<R> z = {R(0), R(0), R(0), R(0)};
         Vec4<R> v0 = z, v1 = z, v2 = z, v3 = z;
         if (mine) {
-            v0 = sl[0];
-            if (nch > 1) v1 = sl[TILE_WORDS];
-            if (nch > 2) v2 = sl[2 * TILE_WORDS];
-            if (nch > 3) v3 = sl[3 * TILE_WORDS];
+            v0 = rd(0);
+            if (nch > 1) v1 = rd(1);
+            if (nch > 2) v2 = rd(2);
+            if (nch > 3) v3 = rd(3);
         }
         acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
         acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
         if (mine)
             for (int c = 4; c < nch; ++c) {
-                const Vec4<R> v = sl[(size_t)c * TILE_WORDS];
+                const Vec4<R> v = rd(c);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
     }
@@ -613,6 +663,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
     if (D.collision_type == CONTACT_PARTICLE && valid) D.pmask[p] = cmask;
 }
 
+// tail reduction (defined behind boundary(): the forward reducer applies grid_op's boundary rule)
+template <class R> __device__ __forceinline__ void tail_block_fwd(const DevSim<R>& D, int b);
+template <class R, class FN> __device__ __forceinline__ void tail_arrive(const DevSim<R>& D, int block, int* lds_word, FN reduce);
+
 // Grid checkpoint: the three value fields of the active blocks, packed [active slot][field][64 cells].
 // Saved after the forward substep's contact pass, restored (with the adjoint fields zeroed) at the start
 // of substep_grad instead of recomputing compute_F_tmp/svd/p2g/grid_op (mpm_simulator.py:352-359).
@@ -638,16 +692,27 @@ __device__ __forceinline__ void grid_save_block(const DevSim<R>& D, int nblocks,
     const int a = active_slot(D);
     if (a >= D.nactive) return;
     const int l = threadIdx.x & 63;
-    const size_t cell = (size_t)D.active[a] * 64 + l;
+    const int b = D.active[a];
+    const size_t cell = (size_t)b * 64 + l;
     Vec4<R>* dst = ck + (size_t)a * CK_WORDS + l;
     const Vec4<R> in = D.vin[cell];
+    bool empty = false;
     if (D.ck_flags) {                                                    // (a wave = a block)
-        const bool empty = __ballot(in.x != R(0) || in.y != R(0) || in.z != R(0) || in.w != R(0)) == 0ull;
+        empty = __ballot(in.x != R(0) || in.y != R(0) || in.z != R(0) || in.w != R(0)) == 0ull;
         if (l == 0) D.ck_flags[a] = empty ? 1 : 0;
-        if (empty) return;                                               // no mass: grid_op left v_mixed = v_out = 0 there, {m,p} is zero already
     }
-    dst[0] = in; dst[64] = D.vout[cell];
-    // ({m, p} stays as it is: the next substep's k_grid_op overwrites it; what P2G adds with global atomics goes to D.vdrift)
+    if (!empty) { dst[0] = in; dst[64] = D.vout[cell]; }                 // (no mass: grid_op left v_mixed = v_out = 0 there, {m,p} is zero already: nothing is filed)
+    // ({m, p} stays as it is: the next substep's grid_op overwrites it; what P2G adds with global atomics goes to D.vdrift)
+    // Tail reduction: the P2G of the NEXT substep rides in this launch (k_g2p_p2g) and its last arriver overwrites {m,p} and v_out of the block.  This wave is
+    // one of the block's readers: it arrives like a chunk (DevSim::tail_extra) once its loads have returned - and, should every chunk have arrived before it,
+    // it is the one that reduces.
+    if (D.tail_on && D.tail_extra && D.tail_expect[b] > 0) {             // (wave-uniform)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int old = 0;
+        if (l == 0) old = __hip_atomic_fetch_add(D.tail_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old + 1 == D.tail_expect[b] + D.tail_extra) tail_block_fwd(D, b);
+    }
 }
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_grid_save(DevSim<R> D, Vec4<R>* ck, Hit* hit_ck, int* nhit_ck, int hit_cap) {
@@ -884,13 +949,17 @@ __device__ __forceinline__ void p2g_body(const DevSim<R>& D, int f, const Chunk&
     SMAC_PHASE(19, valid);                     // scatter issued
     __syncthreads();
     SMAC_PHASE(20, valid);
-    if (sparse) { tile_store<R, 4>(D, tile64, R(1), R(1), cid); tile_flush_shell<R, 4>(D, tile64, D.vdrift, ch.block, R(1), R(1)); }
+    const bool tail = D.tail_on != 0;                                   // (launch-uniform)
+    if (sparse) { tile_store<R, 4>(D, tile64, R(1), R(1), cid, tail); tile_flush_shell<R, 4>(D, tile64, D.vdrift, ch.block, R(1), R(1)); }
     else {
         const R s_m = sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1);
-        tile_store<R, 4>(D, tile, s_m, from_tile, cid);
+        tile_store<R, 4>(D, tile, s_m, from_tile, cid, tail);
         tile_flush_shell<R, 4>(D, tile, D.vdrift, ch.block, s_m, from_tile);
     }
     SMAC_PHASE(21, valid);
+    // tail reduction: this chunk has delivered to the 27 blocks around its own; for each of them whose count it completes, it sums the block's slab records and
+    // the drift field, applies grid_op (mpm_simulator.py:283-297, 396-404) and writes {m,p} and v_out - k_grid_op's work, without the launch
+    if (tail) tail_arrive(D, ch.block, (int*)smax, [&](int B) { tail_block_fwd(D, B); });
 }
 
 template <class R, bool STORE_F, bool PCON, bool MAT2 = false>
@@ -963,6 +1032,70 @@ template <class R> __device__ __forceinline__ Vec4<R> grid_v_mixed_at(const DevS
     boundary(D, i, j, k, v);
     o.x = v[0]; o.y = v[1]; o.z = v[2];
     return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tail reduction (round 5).  What completed a scatter so far was a launch of its own: k_grid_op summed, per node, the <= 8 slabs that overlap it (42 MB moved
+// for 6 MB of result) and applied grid_op; the backward pass had the same in k_reduce_grid_grad_ahead.  Now the scatter's own launch finishes the job:
+//   * every chunk, after its slab (sc1 stores) and its drift-field atomics have LEFT (s_waitcnt vmcnt(0) in every wave, then the workgroup barrier), adds 1 to
+//     the arrival counter of each of the 27 blocks around its own - one wave instruction, 27 lanes, agent-scope atomics that return the old value;
+//   * a block's count is complete when it reaches the number of chunks in those 27 blocks (tail_expect, made at the re-sort) [+ 1: the checkpoint-save wave
+//     that still reads the block's previous contents in the same launch];  the workgroup whose add completed it knows from the returned value and reduces the
+//     block - one wave per block, slab records and the drift field read with sc1 loads - and resets the counter;
+//   * no workgroup ever WAITS: no residency assumption, no ordering assumption, nothing to deadlock.
+// The readers of what the reducer overwrites are exactly the contributors: a chunk gathers its tile from the blocks it scatters to, and it arrives after both.
+// ------------------------------------------------------------------------------------------
+template <class R, class FN> __device__ __forceinline__ void tail_arrive(const DevSim<R>& D, int block, int* lds_word, FN reduce) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every storing wave: its sc1 stores and atomics are out
+    __syncthreads();
+    const int nb = D.nb;
+    const int bz = block % nb, by = (block / nb) % nb, bx = block / (nb * nb);
+    if (threadIdx.x < 64) {                                               // ONE wave signals for the workgroup
+        const int t = threadIdx.x;
+        bool last = false;
+        if (t < 27) {
+            const int X = bx + t / 9 - 1, Y = by + (t / 3) % 3 - 1, Z = bz + t % 3 - 1;
+            if ((unsigned)X < (unsigned)nb && (unsigned)Y < (unsigned)nb && (unsigned)Z < (unsigned)nb) {
+                const int B = (X * nb + Y) * nb + Z;
+                const int old = __hip_atomic_fetch_add(D.tail_cnt + B, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = old + 1 == D.tail_expect[B] + D.tail_extra;
+            }
+        }
+        const unsigned long long bal = __ballot(last);
+        if (t == 0) *lds_word = (int)(unsigned)bal;
+    }
+    __syncthreads();                                                      // the other waves load only behind the barrier the signalling wave joins after its adds returned
+    unsigned mask = (unsigned)*lds_word;
+    const int wave = (int)(threadIdx.x >> 6);
+    int k = 0;
+    while (mask) {                                                        // (workgroup-uniform) the completed blocks, dealt to the four waves
+        const int q = __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        if ((k++ & 3) == wave) reduce(((bx + q / 9 - 1) * nb + (by + (q / 3) % 3 - 1)) * nb + (bz + q % 3 - 1));
+    }
+}
+
+// one wave, lane = cell of block b: {m,p} = slab records + drift field (completes P2G), grid_op :283-297 / grid_op_mixed1 :396-404 with the boundary rule
+// (k_grid_op's phase 0 without grid-node contact), counter back to zero
+template <class R> __device__ __forceinline__ void tail_block_fwd(const DevSim<R>& D, int b) {
+    const int l = (int)(threadIdx.x & 63);
+    const unsigned cell = (unsigned)b * 64u + (unsigned)l;
+    const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+    Vec4<R> acc = ld_sc1(sc1_rsrc(D.vdrift), cell, D.vdrift);
+    if (acc.x != R(0) || acc.y != R(0) || acc.z != R(0) || acc.w != R(0)) D.vdrift[cell] = z;      // consumed: the field is all zero again
+    slab_reduce<R, true>(D, b, l, acc);
+    D.vin[cell] = acc;
+    const int nb = D.nb;
+    const int i = 4 * (b / (nb * nb)) + (l >> 4), j = 4 * ((b / nb) % nb) + ((l >> 2) & 3), k = 4 * (b % nb) + (l & 3);
+    Vec4<R> o = z;
+    if (acc.x > D.m_eps) {
+        const R inv = R(1) / acc.x;
+        R v[3] = {inv * acc.y + D.dt * D.g[0], inv * acc.z + D.dt * D.g[1], inv * acc.w + D.dt * D.g[2]};
+        boundary(D, i, j, k, v);
+        o.x = v[0]; o.y = v[1]; o.z = v[2];
+    }
+    D.vout[cell] = o;
+    if (l == 0) __hip_atomic_store(D.tail_cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one thread per cell of an active block; returns false past the end
@@ -1076,11 +1209,18 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
     typedef typename pos_of<R>::type PX;
     __shared__ tile_t ctile[3 * TILE_WORDS];
     __shared__ double ext_acc[MAX_PRIMS * 6];
+    // (tail reduction: no k_grid_op launch - forward_kinematics to frame f + 1 and the emptying of the next substep's hit counter ride here instead)
+    if (D.fk_ride > 0 && blockIdx.x == gridDim.x - 1) {
+        if ((int)threadIdx.x < D.fk_ride) prim_fk_step(D.prim_state + threadIdx.x * D.fk_stride, f, D.dt64);
+        return;
+    }
+    if (D.zero_next_hits && blockIdx.x == 0 && threadIdx.x == 0) *D.nhits_next = 0;
     if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
     const int nh = *D.nhits;
     const int grp = threadIdx.x >> 5, d = threadIdx.x & 31;
     const double life = 1.0 / (double)(D.substeps - (f - D.frame_shift) % D.substeps);     // :425
-    for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
+    const int nwg = (int)gridDim.x - (D.fk_ride > 0 ? 1 : 0);            // (the last workgroup of a launch that carries forward_kinematics walks no hits)
+    for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += nwg * (BLOCK / 32)) {
         for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) ctile[i] = 0.0;
         const int wg_block = D.hits[base].block;
         __syncthreads();
@@ -1112,9 +1252,12 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
             for (int c = 0; c < 3; ++c) v_tmp[c] += __shfl_xor(v_tmp[c], o, 64);
-        // mixed3 in double whatever R is: the push-out divides a signed distance by dt
+        // mixed3: the push-out divides a signed distance by dt - f64 mode runs the whole chain in double; float32 mode keeps the DISTANCE in double and
+        // everything else in float (collide_mixed_hybrid, smac_math.hpp: SMAC_CONTACT_HYBRID=0 builds the all-f64 chain of rounds 1-4 for A/B)
+        constexpr bool HYB = SMAC_CONTACT_HYBRID && sizeof(R) == 4;
         const double x64[3] = {pos_get(x[0]), pos_get(x[1]), pos_get(x[2])};
         double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
+        float v32[3] = {(float)v_tmp[0], (float)v_tmp[1], (float)v_tmp[2]};
         // CLOTH instantiation: Hit::mask = sheet bits (0: has a contact face, 1: penetrated) | SDF-primitive band bits << 8.  A scene with SDF primitives
         // AND the sheet (round 4; BASELINE config C5 "mixed soft-rigid-cloth") walks the primitives in index order, then the sheet - the reference has no
         // simulator with both (softmac :421-429 loops the primitives, soft_cloth :419-428 has the one sheet): the composition is this build's.
@@ -1125,7 +1268,13 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
             const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
             double s13[13], ext[6] = {0, 0, 0, 0, 0, 0};
             for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-            collide_mixed(D.prim64[i], s13, x64, v_tgt, (double)D.p_mass, D.dt64, life, ext);
+            if (HYB) {
+                float e32[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                collide_mixed_hybrid<double, float>(D.prim64[i], *(const PrimTable<float>*)&D.prim[i], s13, x64, v32, (float)D.p_mass, D.dt64, life, e32);
+                for (int c = 0; c < 6; ++c) ext[c] = (double)e32[c];
+                for (int c = 0; c < 3; ++c) v_tgt[c] = (double)v32[c];
+            } else
+                collide_mixed(D.prim64[i], s13, x64, v_tgt, (double)D.p_mass, D.dt64, life, ext);
             if (d < 6) {                                                                    // lane c adds component c
                 const double e = d == 0 ? ext[0] : (d == 1 ? ext[1] : (d == 2 ? ext[2] : (d == 3 ? ext[3] : (d == 4 ? ext[4] : ext[5]))));
                 if (e != 0.0) __hip_atomic_fetch_add(ext_acc + i * 6 + d, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1287,6 +1436,9 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
         nbase = nbase < 0 ? 0 : (nbase > D.n - 3 ? D.n - 3 : nbase);
         const int cbk = c == 0 ? ch.block / (D.nb * D.nb) : (c == 1 ? (ch.block / D.nb) % D.nb : ch.block % D.nb);
         leaves |= (nbase >> 2) < cbk - 1 || (nbase >> 2) > cbk + 1;
+        // tail reduction: a block's arrival count covers the chunks of the 27 blocks around it, so the WHOLE stencil (base .. base + 2) of the next P2G must stay
+        // inside the blocks cbk - 1 .. cbk + 1 (without it a base in block cbk + 1 may reach cbk + 2, which k_grid_op swept and no count covers)
+        leaves |= D.tail_rule && ((nbase + 2) >> 2) > cbk + 1;
     }
     if (leaves && D.check_next) *D.drift_flag = 1;
 #pragma unroll
@@ -1713,8 +1865,19 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
             for (int c = 0; c < 3; ++c) { v_tmp[c] += __shfl_xor(v_tmp[c], o, 64); gd[c] += __shfl_xor(gd[c], o, 64); }
         // forward chain (every lane), then its adjoint primitive by primitive in reverse - in double whatever R is (the
         // push-out and its derivative carry a factor 1/dt)
+        constexpr bool HYB = SMAC_CONTACT_HYBRID && sizeof(R) == 4;          // (see k_contact_hits: float32 mode keeps only the distance in double)
+        // the forward chain of ONE primitive on a velocity held in double (exact for the float values the hybrid chain works on)
+        auto chain_fwd = [&](int i, const double* s13v, double* vel) {
+            if (HYB) {
+                float v32[3] = {(float)vel[0], (float)vel[1], (float)vel[2]}, e32[6];
+                collide_mixed_hybrid<double, float>(D.prim64[i], *(const PrimTable<float>*)&D.prim[i], s13v, x64, v32, (float)D.p_mass, D.dt64, life, e32);
+                vel[0] = (double)v32[0]; vel[1] = (double)v32[1]; vel[2] = (double)v32[2];
+            } else {
+                double dummy6[6];
+                collide_mixed(D.prim64[i], s13v, x64, vel, pm64, D.dt64, life, dummy6);
+            }
+        };
         double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
-        double dummy[6];
         // One primitive in range (the usual case): the value part of the dual pass below IS the forward result,
         // so the separate forward evaluation - a second chain of dependent SDF lookups - is skipped.
         // (CLOTH instantiation: sheet bits | primitive band bits << 8, see k_contact_hits; the forward chain is primitives in index order, then the sheet,
@@ -1729,7 +1892,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                     const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
                     double s13[13];
                     for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                    collide_mixed(D.prim64[i], s13, x64, v_tgt, pm64, D.dt64, life, dummy);
+                    chain_fwd(i, s13, v_tgt);
                 }
         }
         double g[3] = {-(double)gd[0], -(double)gd[1], -(double)gd[2]};             // adjoint of v_tgt
@@ -1787,17 +1950,27 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
                         const double* pq = D.prim_state + ((size_t)q * D.max_frames + f) * 13;
                         double sq[13];
                         for (int c = 0; c < 13; ++c) sq[c] = pq[c];
-                        collide_mixed(D.prim64[q], sq, x64, vin, pm64, D.dt64, life, dummy);
+                        chain_fwd(q, sq, vin);
                     }
                 if (d < 19) {
-                    Dual<double> pos[3], v[3], stt[13], ext[6];
+                    Dual<double> pos[3], stt[13];
                     for (int c = 0; c < 3; ++c) pos[c] = Dual<double>(x64[c], d == c ? 1.0 : 0.0);
-                    for (int c = 0; c < 3; ++c) v[c] = Dual<double>(vin[c], d == 3 + c ? 1.0 : 0.0);
                     for (int c = 0; c < 13; ++c) stt[c] = Dual<double>(ps[c], d == 6 + c ? 1.0 : 0.0);
-                    collide_mixed(D.prim64[i], stt, pos, v, pm64, D.dt64, life, ext);
-                    for (int c = 0; c < 3; ++c) out += g[c] * v[c].d;
-                    for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * ext[c].d;
-                    for (int c = 0; c < 3; ++c) vfwd[c] = v[c].v;
+                    if (HYB) {
+                        Dual<float> v[3], ext[6];
+                        for (int c = 0; c < 3; ++c) v[c] = Dual<float>((float)vin[c], d == 3 + c ? 1.f : 0.f);
+                        collide_mixed_hybrid<Dual<double>, Dual<float>>(D.prim64[i], *(const PrimTable<float>*)&D.prim[i], stt, pos, v, (float)D.p_mass, D.dt64, life, ext);
+                        for (int c = 0; c < 3; ++c) out += g[c] * (double)v[c].d;
+                        for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * (double)ext[c].d;
+                        for (int c = 0; c < 3; ++c) vfwd[c] = (double)v[c].v;
+                    } else {
+                        Dual<double> v[3], ext[6];
+                        for (int c = 0; c < 3; ++c) v[c] = Dual<double>(vin[c], d == 3 + c ? 1.0 : 0.0);
+                        collide_mixed(D.prim64[i], stt, pos, v, pm64, D.dt64, life, ext);
+                        for (int c = 0; c < 3; ++c) out += g[c] * v[c].d;
+                        for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * ext[c].d;
+                        for (int c = 0; c < 3; ++c) vfwd[c] = v[c].v;
+                    }
                 }
             }
             {   // forward velocity after this primitive, from the group's first lane

@@ -321,6 +321,116 @@ SMAC_HD bool collide_mixed(const PrimTable<R>& T, const S* st13, const S* p_pos,
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// collide_mixed in TWO arithmetic widths (round 5; float32 storage mode only).
+//
+// The all-f64 chain above is ~2,000 dependent f64 instructions for each of the few thousand particles inside a contact band, its dual-number
+// form ~4,500: 40 us of latency per substep pair on an otherwise idle chip (profiles/r04_ag_contact_probe.txt).  What NEEDS f64 is what the
+// push-out divides by dt: the signed distance.  v -= (sdf(x') / dt) n life turns an absolute error e of the distance into e / dt of velocity, so
+// the north-star's 1e-5 of a 0.3 m/s field at dt = 1e-4 allows e = 3e-10 m - a float position (3e-8 at 0.5) or a float cell fraction (6e-8 of a
+// 2.5 ... 7.5 mm table cell = 1.5e-10 ... 4.5e-10) does not give that.  So S64 (double, or Dual<double> in the adjoint) carries exactly:
+//   the particle position relative to the primitive, its rotation into the body frame (inv_trans, primitive_utils.py:42-46), the cell
+//   fraction (mesh.py:55-57) and the 8-tap interpolation of the f64 distance table (:58-65); the forecast position x' = x + v dt (:166);
+//   the product sdf(x') life / dt (:169).
+// Everything else - the 24 normal taps and their normalisation (mesh.py:99-110), collider_v (:63-70), the relative velocity, Coulomb friction,
+// the softness blend exp(-666 d) (:149-163), the wrench (:173-179) - is S32 (float / Dual<float>): relative errors of 1e-7 on quantities of the
+// size of the velocity itself, with native rcp / rsq / exp instead of f64 Newton sequences.  ~160 f64 + ~400 f32 operations.
+// Same branches, same order of operations, same derivative conventions as collide_mixed.
+// ------------------------------------------------------------------------------------------
+SMAC_HD float narrow_(double a) { return (float)a; }
+SMAC_HD Dual<float> narrow_(Dual<double> a) { return Dual<float>((float)a.v, (float)a.d); }
+SMAC_HD double widen_(float a) { return (double)a; }
+SMAC_HD Dual<double> widen_(Dual<float> a) { return Dual<double>((double)a.v, (double)a.d); }
+
+// distance (S64) and world-frame normal (S32) at `pos`.  `iq`: the NORMALISED inverse quaternion of the pose (computed once per primitive: inv_trans
+// normalises it on every call, to the same value), `rot32`: the pose quaternion as it stands (primitive_base.py:61 rotates the normal back with it).
+template <class S64, class S32>
+SMAC_HD S64 prim_sdf_normal_hybrid(const PrimTable<double>& T64, const PrimTable<float>& T32, const S64* position, const S64* iq, const S32* rot32,
+                                   const S64* pos, S32* n_out) {
+    S64 d[3] = {pos[0] - position[0], pos[1] - position[1], pos[2] - position[2]};
+    S64 local[3];
+    qrot(iq, d, local);
+    int b[3]; S64 fx[3];
+    S32 n[3] = {S32(0.f), S32(1.f), S32(0.f)};
+    S64 out = S64(1e10);
+    if (sdf_cell(T64, local, b, fx)) {
+        n[1] = S32(0.f);
+        out = S64(0.0);
+        const int sy = T64.res[2], sx = T64.res[1] * T64.res[2];
+        double ts[8]; float tn[24];
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    const int c = (b[0] + i) * sx + (b[1] + j) * sy + (b[2] + k), q = 4 * i + 2 * j + k;
+                    ts[q] = T64.sdf[c];
+                    tn[3 * q] = T32.normal[3 * c]; tn[3 * q + 1] = T32.normal[3 * c + 1]; tn[3 * q + 2] = T32.normal[3 * c + 2];
+                }
+        const S32 f32[3] = {narrow_(fx[0]), narrow_(fx[1]), narrow_(fx[2])};
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    const int q = 4 * i + 2 * j + k;
+                    S64 w = (i ? fx[0] : 1.0 - fx[0]) * (j ? fx[1] : 1.0 - fx[1]) * (k ? fx[2] : 1.0 - fx[2]);
+                    out = out + w * ts[q];
+                    S32 w32 = (i ? f32[0] : 1.f - f32[0]) * (j ? f32[1] : 1.f - f32[1]) * (k ? f32[2] : 1.f - f32[2]);
+                    n[0] = n[0] + w32 * tn[3 * q]; n[1] = n[1] + w32 * tn[3 * q + 1]; n[2] = n[2] + w32 * tn[3 * q + 2];
+                }
+        S32 l = sqrt_(dot3(n, n));                     // .normalized(), mesh.py:110
+        n[0] = n[0] / l; n[1] = n[1] / l; n[2] = n[2] / l;
+    }
+    qrot(rot32, n, n_out);
+    return out;
+}
+
+template <class S64, class S32>
+SMAC_HD bool collide_mixed_hybrid(const PrimTable<double>& T64, const PrimTable<float>& T32, const S64* st13, const S64* p_pos, S32* v_io,
+                                  float p_mass, double dt, double life, S32* ext6) {
+    // normalised inverse quaternion, once for both lookups
+    S64 iq[4] = {st13[3], -st13[4], -st13[5], -st13[6]};
+    {
+        S64 nq = sqrt_(iq[0] * iq[0] + iq[1] * iq[1] + iq[2] * iq[2] + iq[3] * iq[3]);
+        iq[0] = iq[0] / nq; iq[1] = iq[1] / nq; iq[2] = iq[2] / nq; iq[3] = iq[3] / nq;
+    }
+    S32 st32[13];
+    for (int i = 0; i < 13; ++i) st32[i] = narrow_(st13[i]);
+    S32 D[3], r[3], cv[3], in[3];
+    S64 dist = prim_sdf_normal_hybrid(T64, T32, st13, iq, st32 + 3, p_pos, D);      // :141, :145
+    if (!(val(dist) <= 5e-3)) return false;                                        // :142-143
+    S32 p_v_in[3] = {v_io[0], v_io[1], v_io[2]};
+    S32 p_v[3] = {v_io[0], v_io[1], v_io[2]};
+    for (int i = 0; i < 3; ++i) r[i] = narrow_(p_pos[i] - st13[i]);                  // :146
+    collider_v(st32, r, cv);                                                       // :147
+    for (int i = 0; i < 3; ++i) in[i] = p_v[i] - cv[i];                            // :149
+    S32 nc = dot3(in, D);                                                          // :150
+    if (val(nc) < 0.f) {                                                           // :152
+        S32 t[3] = {in[0] - nc * D[0], in[1] - nc * D[1], in[2] - nc * D[2]};      // :153
+        S32 tt = dot3(t, t);
+        S32 tn = sqrt_(tt + 1e-8f);                                                // length(), primitive_utils.py:5
+        S32 scale = maxc(tn + nc * T32.friction, 0.f) / tn;                        // :155
+        float flag = (std::sqrt(val(tt)) > 1e-30f) ? 1.f : 0.f;                    // :156
+        for (int i = 0; i < 3; ++i) t[i] = (t[i] * scale) * flag + t[i] * (1.f - flag);   // :157
+        if (val(dist) > 0.0) {                                                     // :161-163
+            S32 infl = minc(exp_(-narrow_(dist) * T32.softness), 1.f);
+            for (int i = 0; i < 3; ++i) p_v[i] = cv[i] + in[i] * (1.f - infl) + t[i] * infl;
+        } else {
+            for (int i = 0; i < 3; ++i) p_v[i] = cv[i] + t[i];                     // :159
+        }
+    }
+    S64 xn[3] = {widen_(p_v[0]) * dt + p_pos[0], widen_(p_v[1]) * dt + p_pos[1], widen_(p_v[2]) * dt + p_pos[2]};   // :166
+    S32 n2[3];
+    S64 sdf2 = prim_sdf_normal_hybrid(T64, T32, st13, iq, st32 + 3, xn, n2);        // :167, :169
+    if (val(sdf2) < 0.0) {                                                         // :168-170
+        S32 k = narrow_(sdf2 * (life / dt));                                       // (the f64 distance times a constant: narrowing the PRODUCT costs 6e-8 of it)
+        for (int i = 0; i < 3; ++i) p_v[i] = p_v[i] - k * n2[i];
+    }
+    S32 bf[3], bt[3];
+    const float m_dt = p_mass * (float)(1.0 / dt);
+    for (int i = 0; i < 3; ++i) bf[i] = (p_v_in[i] - p_v[i]) * m_dt;               // :173
+    cross3(r, bf, bt);                                                             // :174
+    for (int i = 0; i < 3; ++i) { ext6[i] = bf[i]; ext6[3 + i] = bt[i]; v_io[i] = p_v[i]; }
+    return true;
+}
+
 // Adjoint of collide_mixed by 19 forward-mode passes (inputs: p_pos3, p_v3, state13).
 // g_v[3]: adjoint of the output velocity, g_ext[6]: adjoint seeds of ext_f.
 // Accumulates into g_pos[3], g_state[13]; OVERWRITES g_vin[3].

@@ -313,4 +313,21 @@ __global__ void k_emit_lists(int nblocks, int N, const int* bin_start, const int
     if (active_flag[b]) active[active_start[b]] = b;
 }
 
+// Tail reduction (round 5, smac_kernels.hpp tail_arrive): a block B receives scatter from the chunks of the blocks B + [-1, 1]^3 (a chunk's wide LDS tile
+// reaches one node past its block on either side); expect[B] = that many chunks.  The chunk whose arrival completes the count sums B's slab records.
+__global__ void k_tail_expect(int nblocks, int nb, const int* block_chunks, int* expect) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int bz = b % nb, by = (b / nb) % nb, bx = b / (nb * nb);
+    int n = 0;
+    for (int i = -1; i <= 1; ++i)
+        for (int j = -1; j <= 1; ++j)
+            for (int k = -1; k <= 1; ++k) {
+                const int X = bx + i, Y = by + j, Z = bz + k;
+                if (X < 0 || Y < 0 || Z < 0 || X >= nb || Y >= nb || Z >= nb) continue;
+                n += block_chunks[(X * nb + Y) * nb + Z];
+            }
+    expect[b] = n;
+}
+
 }  // namespace smac

@@ -181,6 +181,7 @@ template <class R> struct Sim final : ISim {
         int* block_chunks = nullptr;
         int* block_active = nullptr;
         int* block_slot = nullptr;    // dense per block: slot in the active list (exclusive scan of the active flags)
+        int* tail_expect = nullptr;   // dense per block: chunks of the 27 blocks around it (tail reduction's arrival count)
         int frame = 0;              // frame at which the sort happened
         int interval = 1;           // substeps this binning is used for (<= sort_interval, shortened for fast particles)
         bool live = false;
@@ -213,6 +214,9 @@ template <class R> struct Sim final : ISim {
     Hit* d_hits = nullptr;           // capacity Npad
     Hit* d_hits2 = nullptr;          // the hit list of odd frames (k_g2p_p2g appends the next substep's hits while this substep's list is filed)
     Vec4<R>* vdrift = nullptr;       // DevSim::vdrift
+    int* d_tail_cnt = nullptr;       // DevSim::tail_cnt
+    int tail_env = getenv("SMAC_TAIL_REDUCE") ? atoi(getenv("SMAC_TAIL_REDUCE")) : 1;
+    int p2g_tail_frame = -1;         // substep whose P2G ended with the tail reduction: {m,p} and v_out are complete, no k_grid_op launch
     int* d_nhits = nullptr;          // [0] = nhits, [1] = ncand
     int* d_cand = nullptr;
     int* d_pmask = nullptr;
@@ -281,7 +285,7 @@ template <class R> struct Sim final : ISim {
         hipFree(D.cloth.ext_f_grad); hipFree(D.cloth.contact_id); hipFree(D.cloth.penetration); hipFree(D.cloth.contact_before);
         hipFree(d_target); hipFree(d_loss); hipFree(d_best); hipFree(d_md_out);
         hipFree(d_mat_id);
-        hipFree(d_hits); hipFree(d_hits2); hipFree(vdrift); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
+        hipFree(d_hits); hipFree(d_hits2); hipFree(vdrift); hipFree(d_tail_cnt); hipFree(d_nhits); hipFree(d_cand); hipFree(d_pmask); hipFree(ck_arena); hipFree(ck_hits); hipFree(ck_nhits); hipFree(ck_empty);
         if (h_nhits) hipHostFree(h_nhits);
         if (h_sort_info) hipHostFree(h_sort_info);
         for (int i = 0; i < SMAC_MAX_PRIMS; ++i) {
@@ -355,6 +359,12 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&vdrift, D.G * sizeof(Vec4<R>)));
         HIP_TRY(hipMemsetAsync(vdrift, 0, D.G * sizeof(Vec4<R>), stream));
         D.vdrift = vdrift;
+        // tail reduction (DevSim::tail_on): one arrival counter per grid block, zero between launches.  SMAC_TAIL_REDUCE=0: k_grid_op / the reduction launch as in round 4.
+        HIP_TRY(hipMalloc((void**)&d_tail_cnt, ((size_t)D.nb * D.nb * D.nb + 1) * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_tail_cnt, 0, ((size_t)D.nb * D.nb * D.nb + 1) * sizeof(int), stream));
+        D.tail_cnt = d_tail_cnt;
+        D.tail_on = 0; D.tail_extra = 0; D.tail_expect = nullptr;
+        D.tail_rule = tail_env ? 1 : 0;
         D.hits_next = d_hits2;
         D.zero_next_hits = 0;
         D.keep_vmix = 0;
@@ -949,7 +959,8 @@ template <class R> struct Sim final : ISim {
     // ---- epochs / sorting ------------------------------------------------------------------
     static void free_epoch(Epoch& e) {
         hipFree(e.orig); hipFree(e.cellrank); hipFree(e.from_prev); hipFree(e.inv); hipFree(e.chunks); hipFree(e.active); hipFree(e.block_chunk_start); hipFree(e.block_chunks); hipFree(e.block_active);
-        hipFree(e.block_slot);
+        hipFree(e.block_slot); hipFree(e.tail_expect);
+        e.tail_expect = nullptr;
         e.orig = e.cellrank = e.from_prev = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
         e.chunks = nullptr;
         e.live = false;
@@ -960,8 +971,9 @@ template <class R> struct Sim final : ISim {
         b.orig = e.orig; b.cellrank = e.cellrank; b.from_prev = e.from_prev; b.inv = e.inv; b.chunks = e.chunks; b.active = e.active;
         b.block_chunk_start = e.block_chunk_start; b.block_chunks = e.block_chunks; b.block_active = e.block_active;
         b.block_slot = e.block_slot;
+        b.tail_expect = e.tail_expect;
         epoch_pool.push_back(std::move(b));
-        e.orig = e.cellrank = e.from_prev = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = nullptr;
+        e.orig = e.cellrank = e.from_prev = e.inv = e.active = e.block_chunk_start = e.block_chunks = e.block_active = e.block_slot = e.tail_expect = nullptr;
         e.chunks = nullptr;
         e.inv_valid = false;
         e.live = false;
@@ -974,6 +986,7 @@ template <class R> struct Sim final : ISim {
             ep.orig = b.orig; ep.cellrank = b.cellrank; ep.from_prev = b.from_prev; ep.inv = b.inv; ep.chunks = b.chunks; ep.active = b.active;
             ep.block_chunk_start = b.block_chunk_start; ep.block_chunks = b.block_chunks; ep.block_active = b.block_active;
             ep.block_slot = b.block_slot;
+            ep.tail_expect = b.tail_expect;
             ep.inv_valid = false;
             return SMAC_OK;
         }
@@ -986,6 +999,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&ep.block_chunks, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.block_active, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&ep.block_slot, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&ep.tail_expect, (nblocks + 1) * sizeof(int)));
         return SMAC_OK;
     }
     void gc_epochs() {                                   // drop epochs no frame refers to any more
@@ -1136,6 +1150,7 @@ template <class R> struct Sim final : ISim {
                            (const int*)d_block_start, (const int*)d_block_chunks, (const int*)d_chunk_start,
                            (const int*)d_active_flag, (const int*)d_active_start, ep.chunks, ep.active, (int)chunk_capacity(),
                            ep.block_chunk_start, ep.block_chunks, ep.block_active, ep.block_slot);
+        hipLaunchKernelGGL(k_tail_expect, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.nb, (const int*)d_block_chunks, ep.tail_expect);
         hipLaunchKernelGGL(k_sort_info, dim3(1), dim3(64), 0, stream, (const int*)(d_chunk_start + nblocks), (const int*)(d_active_start + nblocks),
                            (const unsigned*)d_vmax, (const int*)d_drift, read_drift ? 1 : 0, h_sort_info);
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1202,6 +1217,7 @@ template <class R> struct Sim final : ISim {
         D.orig_id = ep.orig; D.block_chunk_start = ep.block_chunk_start; D.block_chunks = ep.block_chunks;
         D.block_active = ep.block_active;
         D.block_slot = ep.block_slot;
+        D.tail_expect = ep.tail_expect;
         D.slab = slab;
         D.cand = d_cand;
         return check_launch();
@@ -1660,7 +1676,15 @@ template <class R> struct Sim final : ISim {
         if (is_recompute || (repairing && f < replay_count_from)) Dc.ext_f = scratch_ext();
         if ((is_recompute || (repairing && f < replay_count_from)) && D.cloth.present) Dc.cloth.ext_f = d_cloth_ext_scratch;
         const bool fk_in_grid_op = fuse_next && !is_recompute && cfg.rigid_velocity_control && D.P > 0;
+        // Tail reduction: the P2G launch itself completes {m,p} and applies grid_op (whole substeps, no grid-node contact: k_grid_op's phase 0 is what the
+        // last arriver does).  A P2G that rode in the previous substep's G2P launch says so through p2g_tail_frame.
+        const bool can_tail = tail_env && stage == 0 && !(D.collision_type == CONTACT_GRID && D.any_contact);
+        bool tail_done = skip_p2g && p2g_tail_frame == f;
+        REQUIRE(!tail_done || can_tail, "internal: a tail-reduced P2G in front of a substep that needs k_grid_op's other forms");
+        p2g_tail_frame = -1;
+        Dc.tail_on = 0; Dc.tail_extra = 0;
         if (stage != 2 && !skip_p2g) {
+            if (can_tail) { Dc.tail_on = 1; tail_done = true; }      // (no other reader of {m,p} / v_out runs in a plain P2G launch: tail_extra 0)
             // k_grid_op rewrites {m,p}, v_mixed and v_out of every active cell ({m,p} = slabs + D.vdrift, which it leaves zero again): no clear pass in
             // front of P2G.  The recompute inside substep_grad clears the adjoint fields with it.
             if (is_recompute) {
@@ -1695,6 +1719,20 @@ template <class R> struct Sim final : ISim {
                 prof_end();
             }
         }
+        Dc.tail_on = 0;
+        bool fk_in_contact = false;
+        if (tail_done) {
+            // no k_grid_op: what rode in its launch moves to the contact kernel's (forward_kinematics to frame f + 1, the emptying of the next hit counter) -
+            // or, without a contact launch, to a launch of its own
+            const bool contact_launch = stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED && !D.cloth.present;
+            if (fk_in_grid_op && contact_launch) fk_in_contact = true;
+            else if (fk_in_grid_op) {
+                prof_begin(K_FK);
+                hipLaunchKernelGGL(k_prim_fk<double>, dim3(1), dim3(64), 0, stream, D.prim_state, f, D.dt64, D.P, (size_t)cfg.max_frames * 13);
+                prof_end();
+            }
+            if (fuse_next && !contact_launch && D.any_contact) HIP_TRY(hipMemsetAsync(D.nhits_next, 0, sizeof(int), stream));
+        } else {
         prof_begin(K_GRID_OP);
         Dc.keep_vmix = stage != 0 ? 1 : 0;                      // the slab phases send v_out - v_mixed across the slab boundaries after the contact pass
         Dc.halo_hs.count = 0;
@@ -1716,13 +1754,21 @@ template <class R> struct Sim final : ISim {
             hipLaunchKernelGGL((k_grid_op<R, false>), dim3(ngrid_blocks() + (fk_in_grid_op ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, stage);
         Dc.fk_ride = 0;
         prof_end();
+        }
         if (stage != 1 && D.any_contact && D.collision_type == CONTACT_MIXED) {
             prof_begin(K_CONTACT);
+            Dc.zero_next_hits = 0;
             if (D.cloth.present) {
                 hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
                 hipLaunchKernelGGL((k_contact_hits<R, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
-            } else
-                hipLaunchKernelGGL((k_contact_hits<R, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+            } else {
+                if (tail_done) {
+                    Dc.zero_next_hits = fuse_next ? 1 : 0;
+                    if (fk_in_contact) { Dc.fk_ride = D.P; Dc.fk_stride = (size_t)cfg.max_frames * 13; }
+                }
+                hipLaunchKernelGGL((k_contact_hits<R, false>), dim3(contact_grad_grid() + (fk_in_contact ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, f);
+                Dc.fk_ride = 0; Dc.zero_next_hits = 0;
+            }
             prof_end();
         }
         return check_launch();
@@ -1849,6 +1895,11 @@ template <class R> struct Sim final : ISim {
                 if (fuse_next) {                                                            // G2P of this substep + P2G of the next in one launch
                     DevSim<R> Dg = D;
                     Dg.any_contact = any_contact() ? 1 : 0;
+                    // tail reduction of the riding P2G (whole substeps only: the slab pieces exchange {m,p} between P2G and grid_op).  The save part of this
+                    // launch still reads this substep's {m,p} / v_out: its waves arrive too (tail_extra)
+                    Dg.tail_on = (tail_env && phase < 0 && !(D.collision_type == CONTACT_GRID && Dg.any_contact)) ? 1 : 0;
+                    Dg.tail_extra = (Dg.tail_on && save_in_g2p) ? 1 : 0;
+                    p2g_tail_frame = Dg.tail_on ? f + 1 : -1;
                     if (save_in_g2p) {
                         Dg.save_ck = ck_slot(f);
                         Dg.save_hits = keep_hits ? ck_hits + (size_t)f * ck_hit_cap : (Hit*)nullptr;
@@ -1958,8 +2009,10 @@ template <class R> struct Sim final : ISim {
     int leave_fused_forward() {
         if (p2g_done_frame < 0) return SMAC_OK;
         p2g_done_frame = -1;
+        p2g_tail_frame = -1;
         nhits_zero_frame = -1;
         HIP_TRY(hipMemsetAsync(vdrift, 0, D.G * sizeof(Vec4<R>), stream));
+        HIP_TRY(hipMemsetAsync(d_tail_cnt, 0, ((size_t)D.nb * D.nb * D.nb + 1) * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_nhits + 4, 0, sizeof(int), stream));
         return SMAC_OK;

@@ -66,6 +66,50 @@ static void collide_run(int n, const double* sdf, const double* normal, const in
     delete[] tn;
 }
 
+// the two-width chain of float32 mode (collide_mixed_hybrid): f64 distance, f32 everything else; positions and primitive state in f64, velocities in f32
+static void collide_hybrid_run(int n, const double* sdf, const double* normal, const int* res, const double* lower,
+                               const double* upper, double sdf_dx, double friction, double softness, const double* st13,
+                               const double* pos, const double* vel, double p_mass, double dt, double life,
+                               const double* g_v, const double* g_ext, double* out_v, double* out_ext, int* active,
+                               double* g_pos, double* g_vin, double* g_state) {
+    long cells = (long)res[0] * res[1] * res[2];
+    std::vector<float> ts32(cells), tn32(cells * 3);
+    for (long i = 0; i < cells; ++i) ts32[i] = (float)sdf[i];
+    for (long i = 0; i < cells * 3; ++i) tn32[i] = (float)normal[i];
+    PrimTable<double> T64;
+    PrimTable<float> T32;
+    T64.sdf = sdf; T64.normal = normal; T32.sdf = ts32.data(); T32.normal = tn32.data();
+    for (int i = 0; i < 3; ++i) { T64.res[i] = T32.res[i] = res[i]; T64.lower[i] = lower[i]; T64.upper[i] = upper[i]; T32.lower[i] = (float)lower[i]; T32.upper[i] = (float)upper[i]; }
+    T64.inv_dx = 1.0 / sdf_dx; T64.friction = friction; T64.softness = softness; T64.contact = 1;
+    T32.inv_dx = (float)(1.0 / sdf_dx); T32.friction = (float)friction; T32.softness = (float)softness; T32.contact = 1;
+    for (int i = 0; i < 13; ++i) g_state[i] = 0;
+    for (int p = 0; p < n; ++p) {
+        double x[3];
+        float v[3], ext[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; ++i) { x[i] = pos[3 * p + i]; v[i] = (float)vel[3 * p + i]; }
+        const float vin[3] = {v[0], v[1], v[2]};
+        const bool act = collide_mixed_hybrid<double, float>(T64, T32, st13, x, v, (float)p_mass, dt, life, ext);
+        active[p] = act;
+        for (int i = 0; i < 3; ++i) out_v[3 * p + i] = v[i];
+        for (int i = 0; i < 6; ++i) out_ext[6 * p + i] = ext[i];
+        for (int i = 0; i < 3; ++i) { g_pos[3 * p + i] = 0; g_vin[3 * p + i] = g_v[3 * p + i]; }     // identity outside the band
+        if (!act) continue;
+        for (int dir = 0; dir < 19; ++dir) {
+            Dual<double> xs[3], ss[13];
+            Dual<float> vs[3], es[6];
+            for (int i = 0; i < 3; ++i) { xs[i] = Dual<double>(x[i], dir == i ? 1.0 : 0.0); vs[i] = Dual<float>(vin[i], dir == 3 + i ? 1.f : 0.f); }
+            for (int i = 0; i < 13; ++i) ss[i] = Dual<double>(st13[i], dir == 6 + i ? 1.0 : 0.0);
+            collide_mixed_hybrid<Dual<double>, Dual<float>>(T64, T32, ss, xs, vs, (float)p_mass, dt, life, es);
+            double acc = 0;
+            for (int i = 0; i < 3; ++i) acc += g_v[3 * p + i] * (double)vs[i].d;
+            for (int i = 0; i < 6; ++i) acc += g_ext[i] * (double)es[i].d;
+            if (dir < 3) g_pos[3 * p + dir] = acc;
+            else if (dir < 6) g_vin[3 * p + dir - 3] = acc;
+            else g_state[dir - 6] += acc;
+        }
+    }
+}
+
 // collide_particle / collide (grid) forward + forward-mode adjoints, one particle / node per entry
 template <class R>
 static void collide_other_run(int kind, int n, const double* sdf, const double* normal, const int* res, const double* lower,
@@ -133,7 +177,10 @@ void h_collide_mixed(int prec, int n, const double* sdf, const double* normal, c
                      const double* pos, const double* vel, double p_mass, double dt, double life, const double* g_v,
                      const double* g_ext, double* out_v, double* out_ext, int* active, double* g_pos, double* g_vin,
                      double* g_state) {
-    if (prec == 64)
+    if (prec == 48)
+        collide_hybrid_run(n, sdf, normal, res, lower, upper, sdf_dx, friction, softness, st13, pos, vel, p_mass, dt,
+                           life, g_v, g_ext, out_v, out_ext, active, g_pos, g_vin, g_state);
+    else if (prec == 64)
         collide_run<double>(n, sdf, normal, res, lower, upper, sdf_dx, friction, softness, st13, pos, vel, p_mass, dt,
                             life, g_v, g_ext, out_v, out_ext, active, g_pos, g_vin, g_state);
     else

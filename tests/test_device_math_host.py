@@ -100,7 +100,9 @@ def test_jacobi_svd(lib, prec, tol):
     assert np.abs(np.sort(1 + e[:n // 2], axis=1)[:, ::-1] - s_ref).max() < (1e-14 if prec == 64 else 2e-7)
 
 
-@pytest.mark.parametrize("prec,tol", [(64, 1e-10), (32, 2e-3)])
+# prec 48: the two-width chain of float32 mode (collide_mixed_hybrid, round 5): the signed distance in f64, everything else in f32 - 1e-7 of the field's
+# maximum where the all-f32 chain (prec 32, never shipped) makes 3e-5: what lets the device leave the 2,000-instruction f64 chain and keep the 1e-5 bar
+@pytest.mark.parametrize("prec,tol", [(64, 1e-10), (48, 2e-6), (32, 2e-3)])
 def test_collide_mixed_forward_and_adjoint(lib, prec, tol):
     d = H.load_palm()
     rng = np.random.default_rng(1)
@@ -114,6 +116,8 @@ def test_collide_mixed_forward_and_adjoint(lib, prec, tol):
     st13 = np.concatenate([pos0, q, [0.1, -0.2, 0.05], [0.3, 0.2, -0.4]])
     world = O.qrot(torch.tensor(q / np.linalg.norm(q)), torch.tensor(loc)).numpy() + pos0
     vel = 0.5 * rng.standard_normal((n, 3))
+    if prec == 48:
+        vel = vel.astype(np.float32).astype(np.float64)        # (the device hands this chain a float velocity: the grid gather's)
     g_v = rng.standard_normal((n, 3)); g_ext = rng.standard_normal(6)
     Pm = O.SimParams(n_grid=64, dt=2e-4)
     prim = O.make_prim(st13[:3], st13[3:7], st13[7:10], st13[10:], d["sdf"], d["normal"], d["lower"], d["upper"], d["dx"], friction=0.3)
@@ -129,7 +133,7 @@ def test_collide_mixed_forward_and_adjoint(lib, prec, tol):
                         P(world), P(vel), ctypes.c_double(Pm.p_mass), ctypes.c_double(Pm.dt), ctypes.c_double(0.25), P(g_v), P(g_ext),
                         P(out_v), P(out_ext), act.ctypes.data_as(ip), P(g_pos), P(g_vin), P(g_state))
     assert act.sum() > 500
-    assert np.abs(out_v - ov.detach().numpy()).max() < tol
+    assert np.abs(out_v - ov.detach().numpy()).max() < tol * (np.abs(ov.detach().numpy()).max() if prec == 48 else 1.0)
     assert H.rel_err(out_ext.sum(0), ext.detach().numpy()) < tol
     assert H.rel_err(g_pos, gr[0].numpy()) < tol and H.rel_err(g_vin, gr[1].numpy()) < tol
     assert H.rel_err(g_state, torch.cat(gr[2:]).numpy()) < tol

@@ -19,7 +19,7 @@ def _engine(fused, n_sub, sort_interval, precision, n=1 << 15, grid=64):
     old = os.environ.get("SMAC_FUSED_FWD")
     os.environ["SMAC_FUSED_FWD"] = "1" if fused else "0"
     try:
-        cfg, env_dt, state, specs, s13 = scenes.s_grip(n, grid, max_steps=n_sub + 4, precision=precision)
+        cfg, env_dt, state, specs, s13 = scenes.s_grip(n, grid, max_steps=n_sub + 4, precision=precision, dt=1e-4)
         cfg.sort_interval = sort_interval
         pst = [[np.concatenate([s[:3] + s[7:10] * cfg.dt * f, s[3:]]) for s in s13] for f in range(n_sub + 4)]
         sim, prm = H.build_engine(cfg, env_dt, specs, pst)

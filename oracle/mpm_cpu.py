@@ -33,6 +33,20 @@ def _cpu_stamp():
     return "unknown"
 
 
+def cpu_share():
+    """CPUs this process may really use: the cgroup quota when there is one (a GPU box shows 256 CPUs and grants 16), else the affinity mask"""
+    import os
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def load():
     so = HERE / "_build" / "libmpm_cpu.so"
     stamp = HERE / "_build" / "cpu.stamp"

@@ -665,6 +665,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_mask(DevSim<R> D, int f) {
 
 // tail reduction (defined behind boundary(): the forward reducer applies grid_op's boundary rule)
 template <class R> __device__ __forceinline__ void tail_block_fwd(const DevSim<R>& D, int b);
+template <class R> __device__ __forceinline__ void tail_block_bwd(const DevSim<R>& D, int b);
 template <class R, class FN> __device__ __forceinline__ void tail_arrive(const DevSim<R>& D, int block, int* lds_word, FN reduce);
 
 // Grid checkpoint: the three value fields of the active blocks, packed [active slot][field][64 cells].
@@ -1095,6 +1096,25 @@ template <class R> __device__ __forceinline__ void tail_block_fwd(const DevSim<R
         o.x = v[0]; o.y = v[1]; o.z = v[2];
     }
     D.vout[cell] = o;
+    if (l == 0) __hip_atomic_store(D.tail_cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// backward: grid_v_out.grad = slab records + what drifted lanes / tile shells added to the field itself (completes g2p.grad's scatter), then the adjoint of
+// grid_op / grid_op_mixed1 at the node -> {grid_m.grad, grid_v_in.grad} (k_reduce_grid_grad's work).  The block's forward {m,p} were restored by an earlier
+// launch (plain loads); D.ck_flags: the block held no mass in this frame - nothing was scattered to it, nothing will gather from it.
+template <class R> __device__ __forceinline__ void tail_block_bwd(const DevSim<R>& D, int b) {
+    const int l = (int)(threadIdx.x & 63);
+    const unsigned cell = (unsigned)b * 64u + (unsigned)l;
+    if (!(D.ck_flags && D.ck_flags[D.block_slot[b]])) {
+        Vec4<R> acc = ld_sc1(sc1_rsrc(D.aout), cell, D.aout);
+        const Vec4<R> in = D.vin[cell];
+        slab_reduce<R, true>(D, b, l, acc);
+        if (D.any_contact) D.aout[cell] = acc;                           // the contact adjoint gathers grid_v_out.grad at the nodes of its hits
+        const int nb = D.nb;
+        const int i = 4 * (b / (nb * nb)) + (l >> 4), j = 4 * ((b / nb) % nb) + ((l >> 2) & 3), k = 4 * (b % nb) + (l & 3);
+        R g[3] = {acc.x, acc.y, acc.z};
+        D.ain[cell] = grid_op_node_adjoint(D, in, i, j, k, g);
+    }
     if (l == 0) __hip_atomic_store(D.tail_cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1692,9 +1712,12 @@ __device__ __forceinline__ void g2p_grad_chunk(const DevSim<R>& D, const Chunk& 
     SMAC_PHASE(7, valid && fused_);            // 27-node gather + scatter of the G2P adjoint
     __syncthreads();
     SMAC_PHASE(8, valid && fused_);
-    if (sparse) { tile_store<R, 3>(D, tile64, R(1), R(1)); tile_flush_shell<R, 3>(D, tile64, D.aout, ch.block, R(1), R(1)); }
-    else { tile_store<R, 3>(D, tile, from_tile, from_tile); tile_flush_shell<R, 3>(D, tile, D.aout, ch.block, from_tile, from_tile); }
+    const bool tail = D.tail_on != 0;                                   // (launch-uniform)
+    if (sparse) { tile_store<R, 3>(D, tile64, R(1), R(1), -1, tail); tile_flush_shell<R, 3>(D, tile64, D.aout, ch.block, R(1), R(1)); }
+    else { tile_store<R, 3>(D, tile, from_tile, from_tile, -1, tail); tile_flush_shell<R, 3>(D, tile, D.aout, ch.block, from_tile, from_tile); }
     SMAC_PHASE(9, valid && fused_);
+    // tail reduction (see tail_arrive): the chunk that completes a block's count finishes grid_v_out.grad there and pushes it through grid_op's node adjoint
+    if (tail) tail_arrive(D, ch.block, (int*)smax, [&](int B) { tail_block_bwd(D, B); });
 }
 
 
@@ -1774,6 +1797,17 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad(DevSim<R> D) {
 // current one - and the fused backward step that follows gathers grid_v_out from there; then the sets change roles.  The hit list is not copied:
 // the contact adjoint of that substep walks the filed list in place.  One launch and 9 us of waiting for memory less per backward substep.
 template <class R> struct GridSet { Vec4<R> *vin, *vmix, *vout, *aout; };
+// one wave restores the forward grid of active slot `a` of the NEXT frame of the sweep from its checkpoint into the buffer set `nx`
+template <class R> __device__ __forceinline__ void restore_ahead_slot(const DevSim<R>& D, const GridSet<R>& nx, const Vec4<R>* ck, int a) {
+    if (a >= D.nactive) return;
+    const int l = threadIdx.x & 63;
+    const size_t cell = (size_t)D.active[a] * 64 + l;
+    const Vec4<R>* src = ck + (size_t)a * CK_WORDS + l;
+    const Vec4<R> z = {R(0), R(0), R(0), R(0)};
+    if (D.ck_flags_next && D.ck_flags_next[a]) { nx.vin[cell] = z; nx.vout[cell] = z; }
+    else { nx.vin[cell] = src[0]; nx.vout[cell] = src[64]; }
+    nx.aout[cell] = z;                               // g2p.grad's drifted lanes add to it
+}
 template <class R>
 __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, GridSet<R> nx, const Vec4<R>* ck) {
     if (D.fk_ride > 0 && blockIdx.x >= gridDim.x - D.fk_ride) {
@@ -1793,17 +1827,18 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, G
         if (D.any_contact) D.aout[cell] = acc;
         R g[3] = {acc.x, acc.y, acc.z};
         D.ain[cell] = grid_op_node_adjoint(D, in, i, j, k, g);
-    } else {
-        const int a = ((int)blockIdx.x - half) * 4 + (int)(threadIdx.x >> 6);
-        if (a >= D.nactive) return;
-        const int l = threadIdx.x & 63;
-        const size_t cell = (size_t)D.active[a] * 64 + l;
-        const Vec4<R>* src = ck + (size_t)a * CK_WORDS + l;
-        const Vec4<R> z = {R(0), R(0), R(0), R(0)};
-        if (D.ck_flags_next && D.ck_flags_next[a]) { nx.vin[cell] = z; nx.vout[cell] = z; }
-        else { nx.vin[cell] = src[0]; nx.vout[cell] = src[64]; }
-        nx.aout[cell] = z;                               // g2p.grad's drifted lanes add to it
+    } else restore_ahead_slot(D, nx, ck, ((int)blockIdx.x - half) * 4 + (int)(threadIdx.x >> 6));
+}
+// the restore alone (tail reduction: the reduction half is done by the fused particle launch): rides in k_contact_grad's launch, or - a frame without hits -
+// runs as this launch; its last D.fk_ride workgroups: forward_kinematics.grad
+template <class R>
+__global__ __launch_bounds__(BLOCK) void k_restore_ahead(DevSim<R> D, GridSet<R> nx, const Vec4<R>* ck, int restore) {
+    if (D.fk_ride > 0 && blockIdx.x >= gridDim.x - D.fk_ride) {
+        const int prim = (int)(blockIdx.x - (gridDim.x - D.fk_ride));
+        if (threadIdx.x < 13) prim_fk_step_grad(D.prim_state + prim * D.fk_stride, D.prim_grad + prim * D.fk_stride, D.cur_frame, D.dt64, (int)threadIdx.x);
+        return;
     }
+    if (restore) restore_ahead_slot(D, nx, ck, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
 
 // Adjoint of grid_op_mixed4 / mixed3 / mixed2 for the listed particles.  One hit = one group of 32 lanes:
@@ -1812,8 +1847,20 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_grid_grad_ahead(DevSim<R> D, G
 // times in one lane.  Lane n < 27 then owns stencil node n for the mixed2 scatter and the weight adjoints.
 // DIRECT: grid_v_mixed.grad contributions go through grid_op_mixed1's node adjoint into grid_v_in.grad (see k_reduce_grid_grad)
 // CLOTH: 24 forward-mode directions of the cloth primitive's collide_mixed (p_pos3, p_v3, the face's vertex positions 9 and velocities 9)
+// ride (tail reduction: no reduction launch to carry them): the first `ride_blocks` workgroups restore the next frame's forward grid into the other buffer
+// set (restore_ahead_slot), the last D.fk_ride workgroups run forward_kinematics.grad of this substep; the hit walk uses the workgroups in between
 template <class R, bool DIRECT, bool CLOTH>
-__global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
+__global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, GridSet<R> nx, const Vec4<R>* ck, int ride_blocks) {
+    if (D.fk_ride > 0 && blockIdx.x >= gridDim.x - D.fk_ride) {
+        const int prim = (int)(blockIdx.x - (gridDim.x - D.fk_ride));
+        if (threadIdx.x < 13) prim_fk_step_grad(D.prim_state + prim * D.fk_stride, D.prim_grad + prim * D.fk_stride, D.cur_frame, D.dt64, (int)threadIdx.x);
+        return;
+    }
+    if ((int)blockIdx.x < ride_blocks) {
+        restore_ahead_slot(D, nx, ck, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+        return;
+    }
+    const int wg = (int)blockIdx.x - ride_blocks, nwg = (int)gridDim.x - ride_blocks - (D.fk_ride > 0 ? D.fk_ride : 0);
     __shared__ double pg_acc[MAX_PRIMS * 13];         // primitive-state adjoints of this workgroup's hits (see k_contact)
     if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
     __syncthreads();
@@ -1823,7 +1870,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f) {
     __shared__ tile_t atile[3 * TILE_WORDS];
     const int nh = *D.nhits;
     const int grp = threadIdx.x >> 5, d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
-    for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += gridDim.x * (BLOCK / 32)) {
+    for (int base = wg * (BLOCK / 32); base < nh; base += nwg * (BLOCK / 32)) {
         for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) atile[i] = 0.0;
         const int wg_block = D.hits[base].block;
         __syncthreads();

@@ -217,6 +217,9 @@ template <class R> struct Sim final : ISim {
     int* d_tail_cnt = nullptr;       // DevSim::tail_cnt
     int tail_env = getenv("SMAC_TAIL_REDUCE") ? atoi(getenv("SMAC_TAIL_REDUCE")) : 1;
     int p2g_tail_frame = -1;         // substep whose P2G ended with the tail reduction: {m,p} and v_out are complete, no k_grid_op launch
+    int tail_bwd_env = getenv("SMAC_TAIL_REDUCE_BWD") ? atoi(getenv("SMAC_TAIL_REDUCE_BWD")) : 1;    // the backward half of it by itself (A/B)
+    int bwd_tail_frame = -1;         // substep whose grid adjoint pass (reduction + grid_op's node adjoint) ran inside the fused launch of the substep after it
+    bool pend_restore = false, pend_fk = false;   // ... and what the reduction launch used to carry: restore of the next frame's grid, forward_kinematics.grad
     int* d_nhits = nullptr;          // [0] = nhits, [1] = ncand
     int* d_cand = nullptr;
     int* d_pmask = nullptr;
@@ -360,9 +363,6 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(vdrift, 0, D.G * sizeof(Vec4<R>), stream));
         D.vdrift = vdrift;
         // tail reduction (DevSim::tail_on): one arrival counter per grid block, zero between launches.  SMAC_TAIL_REDUCE=0: k_grid_op / the reduction launch as in round 4.
-        HIP_TRY(hipMalloc((void**)&d_tail_cnt, ((size_t)D.nb * D.nb * D.nb + 1) * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(d_tail_cnt, 0, ((size_t)D.nb * D.nb * D.nb + 1) * sizeof(int), stream));
-        D.tail_cnt = d_tail_cnt;
         D.tail_on = 0; D.tail_extra = 0; D.tail_expect = nullptr;
         D.tail_rule = tail_env ? 1 : 0;
         D.hits_next = d_hits2;
@@ -404,6 +404,9 @@ template <class R> struct Sim final : ISim {
         D.open_x = (c.flags >> 1) & 3;                               // flags bits 1,2: neighbour slab at the low / high x end
         D.nb = c.n_grid / 4;
         nblocks = D.nb * D.nb * D.nb;
+        HIP_TRY(hipMalloc((void**)&d_tail_cnt, ((size_t)nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_tail_cnt, 0, ((size_t)nblocks + 1) * sizeof(int), stream));
+        D.tail_cnt = d_tail_cnt;
         sort_interval = c.sort_interval > 0 ? c.sort_interval : 40;      // (32 until the wide tiles of round 4: a particle that crosses a block face no longer costs its wave the slow path)
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_vmax, sizeof(unsigned)));
@@ -2012,7 +2015,7 @@ template <class R> struct Sim final : ISim {
         p2g_tail_frame = -1;
         nhits_zero_frame = -1;
         HIP_TRY(hipMemsetAsync(vdrift, 0, D.G * sizeof(Vec4<R>), stream));
-        HIP_TRY(hipMemsetAsync(d_tail_cnt, 0, ((size_t)D.nb * D.nb * D.nb + 1) * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(d_tail_cnt, 0, ((size_t)nblocks + 1) * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_nhits, 0, 2 * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_nhits + 4, 0, sizeof(int), stream));
         return SMAC_OK;
@@ -2077,13 +2080,23 @@ template <class R> struct Sim final : ISim {
             D.An_map = nullptr;
             pending_adj_zero = g2p_done_paz;
             D.cur_frame = f;
-            prof_begin(K_REDUCE);
+            const bool tail_did = bwd_tail_frame == f;        // tail reduction: the fused launch of the call before also finished this substep's grid_v_out.grad / grid_v_in.grad
+            bwd_tail_frame = -1;
             DevSim<R> Dr = D;
             fk_grad_rode = fk_ride_env && cfg.rigid_velocity_control && D.P > 0;     // forward_kinematics.grad of this substep: the last D.P workgroups of the launch
             if (fk_grad_rode) { Dr.fk_ride = D.P; Dr.fk_stride = (size_t)cfg.max_frames * 13; }
             Dr.ck_flags_next = f > 0 ? ck_flags_of(f - 1) : nullptr;
             Dr.ck_flags = reduce_flags(f, e);
-            if (restore_ahead_env && can_fuse_prev(f, e, phase, action_grad_out) && grid_alt_ready()) {
+            const bool ahead_ok = restore_ahead_env && can_fuse_prev(f, e, phase, action_grad_out) && grid_alt_ready();
+            if (tail_did) {
+                // no reduction launch: the restore of substep f - 1's forward grid into the other buffer set and forward_kinematics.grad ride in the contact
+                // adjoint's launch below - or, for a frame without hits, in a launch of their own (k_restore_ahead)
+                pend_restore = ahead_ok;
+                pend_fk = fk_grad_rode;
+                if (ahead_ok) ahead_frame = f - 1;
+            } else {
+            prof_begin(K_REDUCE);
+            if (ahead_ok) {
                 // this substep will hand over to substep f - 1 inside k_p2g_g2p_grad: its forward grid is restored by THIS launch, into the other set
                 hipLaunchKernelGGL(k_reduce_grid_grad_ahead<R>, dim3(2 * ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr, grid_set_ptrs(1 - grid_set),
                                    (const Vec4<R>*)ck_slot(f - 1));
@@ -2091,6 +2104,7 @@ template <class R> struct Sim final : ISim {
             } else
                 hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr);
             prof_end();
+            }
         } else if (phase <= 0) {
             hits_from_ck_frame = -1;
             if ((rc = check_contact_supported())) return rc;
@@ -2172,12 +2186,31 @@ template <class R> struct Sim final : ISim {
                 Dc.hits = ck_hits + (size_t)f * ck_hit_cap;
                 Dc.nhits = ck_nhits + f;
             }
+            const GridSet<R> none{nullptr, nullptr, nullptr, nullptr};
             if (D.cloth.present) {
-                if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
-                else hipLaunchKernelGGL((k_contact_grad<R, false, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
-            } else if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
-            else hipLaunchKernelGGL((k_contact_grad<R, false, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+                if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
+                else hipLaunchKernelGGL((k_contact_grad<R, false, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
+            } else if (fused_grid_bwd(phase)) {
+                // (tail reduction) what the reduction launch used to carry rides here: the next frame's restore in the first workgroups, forward_kinematics.grad in the last
+                const int ride = pend_restore ? ngrid_blocks() : 0, fkr = pend_fk ? D.P : 0;
+                Dc.fk_ride = fkr; Dc.fk_stride = (size_t)cfg.max_frames * 13;
+                Dc.ck_flags_next = f > 0 ? ck_flags_of(f - 1) : nullptr;
+                hipLaunchKernelGGL((k_contact_grad<R, true, false>), dim3(ride + contact_grad_grid() + fkr), dim3(BLOCK), 0, stream, Dc, f,
+                                   pend_restore ? grid_set_ptrs(1 - grid_set) : none, pend_restore ? (const Vec4<R>*)ck_slot(f - 1) : (const Vec4<R>*)nullptr, ride);
+                pend_restore = pend_fk = false;
+            } else hipLaunchKernelGGL((k_contact_grad<R, false, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
             prof_end();
+        }
+        if (pend_restore || pend_fk) {                       // (tail reduction, no contact adjoint launch in this substep)
+            prof_begin(K_REDUCE);
+            DevSim<R> Dr = D;
+            Dr.fk_ride = pend_fk ? D.P : 0; Dr.fk_stride = (size_t)cfg.max_frames * 13;
+            Dr.ck_flags_next = f > 0 ? ck_flags_of(f - 1) : nullptr;
+            hipLaunchKernelGGL(k_restore_ahead<R>, dim3((pend_restore ? ngrid_blocks() : 0) + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr,
+                               pend_restore ? grid_set_ptrs(1 - grid_set) : GridSet<R>{nullptr, nullptr, nullptr, nullptr},
+                               pend_restore ? (const Vec4<R>*)ck_slot(f - 1) : (const Vec4<R>*)nullptr, pend_restore ? 1 : 0);
+            prof_end();
+            pend_restore = pend_fk = false;
         }
         if (phase < 0 || phase == 2) {
             if (D.nchunks > 0 && !fused_grid_bwd(phase)) {
@@ -2217,6 +2250,12 @@ template <class R> struct Sim final : ISim {
                 }
                 DevSim<R> D2 = D;
                 D2.Af_prev = Af_prev;
+                // tail reduction: the launch also completes substep f - 1's grid_v_out.grad and pushes it through grid_op's node adjoint (whole substeps; the slab
+                // pieces exchange grid_v_out.grad between the scatter and the node adjoint)
+                D2.tail_on = (tail_env && tail_bwd_env && phase < 0) ? 1 : 0;
+                D2.tail_extra = 0;
+                D2.ck_flags = D2.tail_on ? reduce_flags(f - 1, e) : nullptr;
+                bwd_tail_frame = D2.tail_on ? f - 1 : -1;
                 prof_begin(K_P2G_G2P_GRAD);
                 if (paz_prev) hipLaunchKernelGGL((k_p2g_g2p_grad<R, false>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D2, f);
                 else hipLaunchKernelGGL((k_p2g_g2p_grad<R, true>), dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, D2, f);

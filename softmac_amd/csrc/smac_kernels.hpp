@@ -52,6 +52,9 @@ namespace smac {
 #ifndef SMAC_CONTACT_HYBRID
 #define SMAC_CONTACT_HYBRID 1    // float32 mode: forecast contact in two widths - the signed distance in f64, the rest in f32 (collide_mixed_hybrid; 0: all f64, rounds 1-4)
 #endif
+#ifndef SMAC_TAIL_BUILD
+#define SMAC_TAIL_BUILD 0        // 1: the particle kernels carry the tail reduction (tail_arrive; run-time switch SMAC_TAIL_REDUCE).  Built, parity-green and 15 % SLOWER than the
+#endif                           // reduction launches it replaces (profiles/r05_tail_reduce.txt): the shipped kernels are compiled without it
 #ifndef SMAC_PHASE_CLOCK
 #define SMAC_PHASE_CLOCK 0       // 1 (tools/phase_clock.sh only): 1 workgroup in 16 of the particle kernels files s_memtime at its phase boundaries
 #endif
@@ -707,7 +710,7 @@ __device__ __forceinline__ void grid_save_block(const DevSim<R>& D, int nblocks,
     // Tail reduction: the P2G of the NEXT substep rides in this launch (k_g2p_p2g) and its last arriver overwrites {m,p} and v_out of the block.  This wave is
     // one of the block's readers: it arrives like a chunk (DevSim::tail_extra) once its loads have returned - and, should every chunk have arrived before it,
     // it is the one that reduces.
-    if (D.tail_on && D.tail_extra && D.tail_expect[b] > 0) {             // (wave-uniform)
+    if (SMAC_TAIL_BUILD && D.tail_on && D.tail_extra && D.tail_expect[b] > 0) {             // (wave-uniform)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int old = 0;
         if (l == 0) old = __hip_atomic_fetch_add(D.tail_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -950,7 +953,7 @@ __device__ __forceinline__ void p2g_body(const DevSim<R>& D, int f, const Chunk&
     SMAC_PHASE(19, valid);                     // scatter issued
     __syncthreads();
     SMAC_PHASE(20, valid);
-    const bool tail = D.tail_on != 0;                                   // (launch-uniform)
+    const bool tail = SMAC_TAIL_BUILD && D.tail_on != 0;               // (launch-uniform)
     if (sparse) { tile_store<R, 4>(D, tile64, R(1), R(1), cid, tail); tile_flush_shell<R, 4>(D, tile64, D.vdrift, ch.block, R(1), R(1)); }
     else {
         const R s_m = sizeof(R) == 4 ? D.p_mass * R(W_MAX / FIX_RANGE) : R(1);
@@ -1458,7 +1461,7 @@ __device__ __forceinline__ void g2p_particle(const DevSim<R>& D, const Chunk& ch
         leaves |= (nbase >> 2) < cbk - 1 || (nbase >> 2) > cbk + 1;
         // tail reduction: a block's arrival count covers the chunks of the 27 blocks around it, so the WHOLE stencil (base .. base + 2) of the next P2G must stay
         // inside the blocks cbk - 1 .. cbk + 1 (without it a base in block cbk + 1 may reach cbk + 2, which k_grid_op swept and no count covers)
-        leaves |= D.tail_rule && ((nbase + 2) >> 2) > cbk + 1;
+        leaves |= SMAC_TAIL_BUILD && D.tail_rule && ((nbase + 2) >> 2) > cbk + 1;
     }
     if (leaves && D.check_next) *D.drift_flag = 1;
 #pragma unroll
@@ -1712,7 +1715,7 @@ __device__ __forceinline__ void g2p_grad_chunk(const DevSim<R>& D, const Chunk& 
     SMAC_PHASE(7, valid && fused_);            // 27-node gather + scatter of the G2P adjoint
     __syncthreads();
     SMAC_PHASE(8, valid && fused_);
-    const bool tail = D.tail_on != 0;                                   // (launch-uniform)
+    const bool tail = SMAC_TAIL_BUILD && D.tail_on != 0;               // (launch-uniform)
     if (sparse) { tile_store<R, 3>(D, tile64, R(1), R(1), -1, tail); tile_flush_shell<R, 3>(D, tile64, D.aout, ch.block, R(1), R(1)); }
     else { tile_store<R, 3>(D, tile, from_tile, from_tile, -1, tail); tile_flush_shell<R, 3>(D, tile, D.aout, ch.block, from_tile, from_tile); }
     SMAC_PHASE(9, valid && fused_);

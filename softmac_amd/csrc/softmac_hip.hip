@@ -215,7 +215,8 @@ template <class R> struct Sim final : ISim {
     Hit* d_hits2 = nullptr;          // the hit list of odd frames (k_g2p_p2g appends the next substep's hits while this substep's list is filed)
     Vec4<R>* vdrift = nullptr;       // DevSim::vdrift
     int* d_tail_cnt = nullptr;       // DevSim::tail_cnt
-    int tail_env = getenv("SMAC_TAIL_REDUCE") ? atoi(getenv("SMAC_TAIL_REDUCE")) : 1;
+    // (only in builds that carry it, -DSMAC_TAIL_BUILD=1: it measured slower than the launches it replaces and the shipped kernels are compiled without it)
+    int tail_env = SMAC_TAIL_BUILD ? (getenv("SMAC_TAIL_REDUCE") ? atoi(getenv("SMAC_TAIL_REDUCE")) : 1) : 0;
     int p2g_tail_frame = -1;         // substep whose P2G ended with the tail reduction: {m,p} and v_out are complete, no k_grid_op launch
     int tail_bwd_env = getenv("SMAC_TAIL_REDUCE_BWD") ? atoi(getenv("SMAC_TAIL_REDUCE_BWD")) : 1;    // the backward half of it by itself (A/B)
     int bwd_tail_frame = -1;         // substep whose grid adjoint pass (reduction + grid_op's node adjoint) ran inside the fused launch of the substep after it

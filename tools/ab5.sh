@@ -5,9 +5,11 @@ O=$1; R=$2; shift 2
 mkdir -p $O
 for round in $(seq 1 $R); do
   for spec in "$@"; do
-    label=${spec%%=*}; rest=${spec#*=}; lib=${rest%%,*}; envs=""
+    label=${spec%%=*}; rest=${spec#*=}; lib=${rest%%,*}; envs=""; flags=""
     if [[ "$rest" == *,* ]]; then envs=$(echo "${rest#*,}" | tr ',' ' '); fi
-    env SMAC_LIB=$PWD/softmac_amd/lib/$lib $envs timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f64 --no-cloth --no-env-loop > $O/run_${label}_$round.json 2> $O/run_${label}_$round.err || echo "$label round $round FAILED (see $O/run_${label}_$round.err)"
+    # (an entry BENCH_FLAGS=--sort-interval:80 adds bench.py flags, ':' for the blank)
+    for e in $envs; do if [[ "$e" == BENCH_FLAGS=* ]]; then flags=$(echo "${e#BENCH_FLAGS=}" | tr ':' ' '); fi; done
+    env SMAC_LIB=$PWD/softmac_amd/lib/$lib $envs timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f64 --no-cloth --no-env-loop $flags > $O/run_${label}_$round.json 2> $O/run_${label}_$round.err || echo "$label round $round FAILED (see $O/run_${label}_$round.err)"
   done
 done
 python3 - "$O" "$@" <<'PY'

@@ -53,8 +53,9 @@ namespace smac {
 #define SMAC_CONTACT_HYBRID 1    // float32 mode: forecast contact in two widths - the signed distance in f64, the rest in f32 (collide_mixed_hybrid; 0: all f64, rounds 1-4)
 #endif
 #ifndef SMAC_HITS_PER_WAVE
-#define SMAC_HITS_PER_WAVE 1     // contact kernels: hits per 64-lane wave.  2 (rounds 1-4): two 32-lane groups per wave - hits are appended in the order the P2G waves of all XCDs
-#endif                           // finish, so the two hits of a wave are as often as not in reach of DIFFERENT primitives and the wave runs both collide_mixed chains, half its lanes off each time
+#define SMAC_HITS_PER_WAVE 2     // contact kernels: hits per 64-lane wave (two 32-lane groups).  1 was tried in round 5 on the theory that the two hits of a wave are often in reach of
+#endif                           // DIFFERENT primitives and the wave then runs both collide_mixed chains: k_contact_hits 19.1 -> 21.0 us, k_contact_grad 25.7 -> 33.2 us (profiles/r05_contact.txt) -
+                                 // twice the workgroups pay twice the per-workgroup tile zeroing / flush; the chains are not what these kernels wait for
 #ifndef SMAC_TAIL_BUILD
 #define SMAC_TAIL_BUILD 0        // 1: the particle kernels carry the tail reduction (tail_arrive; run-time switch SMAC_TAIL_REDUCE).  Built, parity-green and 15 % SLOWER than the
 #endif                           // reduction launches it replaces (profiles/r05_tail_reduce.txt): the shipped kernels are compiled without it

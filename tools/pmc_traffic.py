@@ -3,9 +3,11 @@
 MI355X_MICROARCH.md prescribes) -> profiles/traffic_latest.json (read by bench.py for roofline.traffic).
 
 gfx950 correction (same guide): FETCH_SIZE tallies 128-B read requests at 64 B, i.e. reports 1/2 of the bytes of a
-coalesced stream.  Calibrated on this code: k_grid_save moves the same bytes in and out (16 B/lane): WRITE_SIZE =
-13.87 MB, FETCH_SIZE = 7.02 MB = 0.506x; the SoA particle kernels (4 B/lane, 256 B per wave instruction) read
-0.56-0.58x of their known byte counts.  So bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+coalesced stream.  The guide states that for 16-B-per-lane loads; CALIBRATED in round 5 on known byte counts in this code's
+access shapes (tools/microbench/fetch_calib.hip, profiles/r05_fetch_calib.txt): FETCH_SIZE / bytes = 0.500 for 16 B per lane
+AND for the particle kernels' 4-B-per-lane SoA row reads (24 rows of 1M floats, working set beyond the Infinity Cache);
+WRITE_SIZE / bytes = 1.000 for both store shapes.  So bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, no further factor.
+(Round 4 had read 0.56-0.58 off the particle kernels themselves: that was their re-read traffic, not the counter.)"""
 import collections
 import csv
 import json
@@ -23,7 +25,9 @@ NAMES = {"k_p2g<float, true, false>": "p2g", "k_p2g_grad<float, false, true>": "
          # round 4: G2P of substep f + P2G of substep f+1 in one launch (with the checkpoint save in its first workgroups)
          "k_g2p_p2g<float, true>": "g2p_p2g", "k_g2p_p2g<float, false>": "g2p_p2g",
          # (k_grid_op got a third template parameter: the slab loop's instantiation packs / adds the shared planes itself)
-         "k_grid_op<float, false, false>": "grid_op"}
+         "k_grid_op<float, false, false>": "grid_op",
+         # round 5: the slab loop's instantiations pack / add the shared planes of grid_v_out.grad themselves (a template parameter more)
+         "k_reduce_aout<float, false>": "reduce_agvout", "k_grid_op_grad<float, false, false>": "grid_op_grad"}
 
 
 def mean_by_kernel(path, counter):

@@ -182,9 +182,11 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
             # 1.0e-5 ... 2.1e-5): the bound of an ill-conditioned particle is GAP_C / gap where that exceeds 1e-5, i.e. for gaps below 1.5e-4
             s2 = np.linalg.svd((np.eye(3)[None] + cfg.dt * dev[f][2]) @ dev[f][3], compute_uv=False) ** 2
             gap = np.minimum(np.abs(s2[:, 0] - s2[:, 1]), np.minimum(np.abs(s2[:, 1] - s2[:, 2]), np.abs(s2[:, 0] - s2[:, 2])))
-            ill = (gap < GAP_C / tg) & ~(zone | near | kink | knear)
+            ill = (gap < GAP_C / tg) & ~(zone | near | kink)
             ill_worst = float((per[ill] * gap[ill]).max() / GAP_C) if ill.any() else 0.0       # worst error in units of its bound GAP_C / gap
-            rest = ~(zone | near | kink | knear | ill)
+            # (a flipped kink changes that particle's OWN adjoint rows; its stencil neighbours feel it one substep EARLIER, through the grid: in the substep itself they
+            #  stay inside the bar - measured 6.5e-6 next to a particle that moved by 7e-2 - and are not a tier)
+            rest = ~(zone | near | kink | ill)
             pick = lambda m: float(per[m].max()) if m.any() else 0.0
             # who is beyond the bar outside every tier (diagnostics for the record: which field, how close to the clamp / a clip bound, where)
             off = np.nonzero(rest & (per > tg))[0][:10]
@@ -192,7 +194,7 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
                               clamp_gap=float(gap[q]), clip_distance=float(dk[q]),
                               x=[round(float(c), 4) for c in dev[f][0][q]], speed=float(np.abs(dev[f][1][q]).max())) for i, q in enumerate(off)]
             per_frame[f] = dict(rest=pick(rest), offenders=offenders, ill_conditioned=dict(particles=int(ill.sum()), over_1e5=int((per[ill] > tg).sum()), max=pick(ill),
-                                                                                           worst_in_units_of_its_bound=ill_worst), clamp=pick(zone), near_clamp=pick(near & ~kink & ~knear), kink=pick(kink), near_kink=pick(knear & ~zone),
+                                                                                           worst_in_units_of_its_bound=ill_worst), clamp=pick(zone), near_clamp=pick(near & ~kink & ~knear), kink=pick(kink), stencil_neighbours_of_kink=pick(knear & ~zone & ~near),
                                 sizes=dict(clamp=int(zone.sum()), near_clamp=int(near.sum()), kink=int(kink.sum()), near_kink=int(knear.sum()), rest=int(rest.sum())),
                                 over_1e5_in_rest=int((per[rest] > tg).sum()))
     # (c) end to end: what the adjoint kernels add (device vs the chain along its own states) against what the state difference does to the reference's derivative
@@ -207,7 +209,7 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
         f32_end_to_end=dict(vs_pure_f64_window=dict(max=float(per_total.max()), particles_over=count(per_total)),
                             adjoint_kernels_only__device_vs_port_chain_along_device_states=dict(max=float(per_impl.max()), particles_over=count(per_impl)),
                             reference_sensitivity__port_chain_along_device_states_vs_pure_f64=dict(max=float(per_sens.max()), particles_over=count(per_sens))),
-        bounds=dict(rest=tg, near_clamp=H.F32_TOL["near_clamp"], clamp=H.F32_TOL["clamp"], kink=0.2, near_kink=H.F32_TOL["clamp"],
+        bounds=dict(rest=tg, near_clamp=H.F32_TOL["near_clamp"], clamp=H.F32_TOL["clamp"], kink=0.2,
                     ill_conditioned=f"{GAP_C:g} / gap for gap < {GAP_C / tg:g}"),
         launches={k: int(c[1]) for k, c in counts.items() if c[1] > 0}))
     sim._h.close()
@@ -215,8 +217,7 @@ def test_headline_env_step_fwd_bwd_vs_cpu_port():
         assert r["rest"] < tg, (f, per_frame)
         assert r["ill_conditioned"]["worst_in_units_of_its_bound"] < 1.0, (f, per_frame)
         assert r["near_clamp"] < H.F32_TOL["near_clamp"] and r["clamp"] < H.F32_TOL["clamp"], (f, per_frame)
-        assert r["kink"] < 0.2 and r["near_kink"] < H.F32_TOL["clamp"], (f, per_frame)
-        assert r["sizes"]["kink"] + r["sizes"]["near_kink"] < N // 1000, (f, per_frame)   # the carve-out stays a carve-out: < 0.1 % of the particles
+        assert r["kink"] < 0.2 and r["sizes"]["kink"] < 64, (f, per_frame)                 # the kink carve-out: a few particles of a million per substep
     assert e_pg < 10 * tg, e_pg
     # (c) the adjoint kernels' own share of the end-to-end distance is the small one
     assert np.median(per_total) < 1e-6 and per_total.max() < 0.2

@@ -189,7 +189,10 @@ def test_fullsize_rebinning_invariance(precision):
     What the test can state without knowing the flips: the state agrees to 1e-5 for every particle; every adjoint stays within 1e-1 of the
     field's max; the particles beyond 1e-3 are at most 128 = 1.2e-4 of the cloud.  That last number is an observed property of this scene,
     not a derivation: 9, 32, 35, 35, 37, 41, 54, 72 over eight builds of round 2, 51, 59, 82 in round 3 - it moves with every change of the
-    summation order and has been fixed at 128 since commit 88268e1; the branch statistics are printed so that a change of regime is visible."""
+    summation order and has been fixed at 128 since commit 88268e1; the branch statistics are printed so that a change of regime is visible.
+    Round 5 put a derivation beside the observation (tests/test_gpu_window_parity.py): against the f64 oracle on the same window, every SINGLE substep's
+    adjoint on identical inputs holds 1e-5 outside recorded carve-outs of a few dozen particles; what two float32 rollouts (or a float32 and a float64 one) differ
+    by END TO END is the f64 function's own sensitivity to their 1e-7 state difference - the f64 port moves by more when only its F is stored in float32."""
     f32 = precision == "float32"
     outs = [_rebinning_outputs(precision, si, branches=f32) for si in (1, 16, 1000)]
     N = outs[0][0].shape[0]

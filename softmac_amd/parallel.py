@@ -303,6 +303,13 @@ class FailureWatch:
         self.rank, self.world, self.runner, self.poll = int(rank), int(world), runner, float(poll)
         if key is None:
             key = f"{os.environ.get('MASTER_ADDR', 'local')}-{os.environ.get('MASTER_PORT', '0')}-{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}"
+            # a token of THIS run, made by rank 0 and handed round while every rank is still healthy: a file a crashed earlier run left under the same
+            # rendezvous address must not look like a failure of this one
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world:
+                import uuid
+                box = [uuid.uuid4().hex if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                key += "-" + str(box[0])
         base = directory or os.environ.get("SMAC_FAIL_DIR") or tempfile.gettempdir()
         self.dir = os.path.join(base, "smac-fail-" + "".join(c if c.isalnum() or c in "-_." else "_" for c in str(key)))
         os.makedirs(self.dir, exist_ok=True)

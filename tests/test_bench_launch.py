@@ -74,3 +74,22 @@ def test_window_plan_gives_the_resorts_their_steady_state_share():
         assert R * K <= 480 or R == math.lcm(K, I) // K, (K, I, R)
     assert bench.window_plan(20, 40) == 8 and bench.window_plan(32, 40) == 10          # the driver's flags, the default flags
     assert bench.window_plan(1000, 40) == 1                                           # one window is the least there is
+
+
+def test_workloads_take_the_sizes_and_time_steps_of_the_survey():
+    """S-grip 1M / 128^3 at dt 1e-4, S-elastic 262,144 / 64^3, S-pour 4M / 256^3 at 2.5e-4, S-mixed 16M / 256^3; `metric` is BASELINE.json's only for
+    the headline configuration; S-grip's dt keeps c dt / dx at every resolution (1e-4 at 256^3 diverged)."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from softmac_amd import scenes
+    want = {"s-grip": (1 << 20, 128, 32), "s-elastic": (1 << 18, 64, 32), "s-pour": (1 << 22, 256, 32), "s-mixed": (1 << 24, 256, 5)}
+    for w, (n, g, k) in want.items():
+        a = bench.parse_args(["--workload", w])
+        assert (a.particles, a.grid, a.steps) == (n, g, k), (w, a)
+        assert (bench.metric_name(a) == bench.baseline_metric()) == (w == "s-grip")
+    assert "not the headline" in bench.metric_name(bench.parse_args(["--particles", "65536", "--grid", "64"]))
+    for g in (64, 128, 256):
+        assert abs(scenes.grip_dt(g) * g * 57.735 - 0.739) < 1e-3          # c dt / dx with c = sqrt((lam + 2 mu) / rho) = 57.7 m/s
+    cfg = scenes.s_grip(4096, 256, 4)[0]
+    assert cfg.dt == 5e-5
+    assert scenes.s_pour(4096, 256, 4)[0].dt == 2.5e-4

@@ -186,6 +186,37 @@ template <class R> struct DevSim {
 constexpr int TW = 6, TSY = 6, TSX = 36, TILE_WORDS = 216;
 constexpr int CK_WORDS = 128;    // grid checkpoint: [active slot][{m,p} | v_out][64 cells] (v_mixed is recomputed from {m,p}: grid_v_mixed_at)
 __device__ __forceinline__ int tile_index(int li, int lj, int lk) { return li * TSX + lj * TSY + lk; }
+// Order of a chunk's 216 records in its SLAB (round 5): by DESTINATION block.  The 6^3 core of a tile falls on 8 grid blocks - region q = 4 ex + 2 ey + ez holds the
+// nodes whose local coordinate is >= 4 along the axes with e = 1 (they belong to the +1 block there) - and a region's nodes are stored in the destination block's
+// own cell order.  The wave that sums a block reads, from each overlapping chunk, ONE contiguous run of 64 / 32 / 16 / 8 records (1 KB ... 128 B, every run a
+// multiple of 128 B from the slab's start); in the tile's own row-major order the same wave read 4-record (64-B) runs: half of every 128-B line fetched for nothing
+// (PMC: 31.6 MB read for 18 MB of records in k_grid_op).  SMAC_SLAB_BY_BLOCK=0: the tile's order (rounds 1-4).
+#ifndef SMAC_SLAB_BY_BLOCK
+#define SMAC_SLAB_BY_BLOCK 1
+#endif
+__device__ __forceinline__ int slab_region_offset(int q) {          // 64, 32, 32, 16, 32, 16, 16, 8 records
+    return q == 0 ? 0 : (q == 1 ? 64 : (q == 2 ? 96 : (q == 3 ? 128 : (q == 4 ? 144 : (q == 5 ? 176 : (q == 6 ? 192 : 208))))));
+}
+// record of destination-local cell (lx, ly, lz) in region q (requires lx < 2 where ex, etc.)
+__device__ __forceinline__ int slab_record(int q, int lx, int ly, int lz) {
+#if SMAC_SLAB_BY_BLOCK
+    const int ny = (q & 2) ? 2 : 4, nz = (q & 1) ? 2 : 4;
+    return slab_region_offset(q) + (lx * ny + ly) * nz + lz;
+#else
+    return tile_index(lx + 4 * (q >> 2), ly + 4 * ((q >> 1) & 1), lz + 4 * (q & 1));
+#endif
+}
+// tile node (0..5 per axis) of slab record i
+__device__ __forceinline__ void slab_node(int i, int& ti, int& tj, int& tk) {
+#if SMAC_SLAB_BY_BLOCK
+    const int q = i < 64 ? 0 : (i < 96 ? 1 : (i < 128 ? 2 : (i < 144 ? 3 : (i < 176 ? 4 : (i < 192 ? 5 : (i < 208 ? 6 : 7))))));
+    const int r = i - slab_region_offset(q);
+    const int ny = (q & 2) ? 2 : 4, nz = (q & 1) ? 2 : 4;
+    ti = r / (ny * nz) + 4 * (q >> 2); tj = (r / nz) % ny + 4 * ((q >> 1) & 1); tk = r % nz + 4 * (q & 1);
+#else
+    ti = i / TSX; tj = (i / TSY) % TW; tk = i % TW;
+#endif
+}
 // WIDE tile of the particle kernels (round 4): the same 6^3 plus ONE node of slack on either side, 8x8x8 nodes with origin 4*block - 1.  A particle that
 // crossed a block face since the last sort (they jitter across the faces: 1-2 % of them by the end of a re-sort interval, i.e. a lane in nearly EVERY
 // wave) still gathers from LDS and scatters into LDS; the chunk's 6^3 core goes to its slab as before and the non-zero sums on the shell go to the dense
@@ -463,7 +494,9 @@ template <class R, int NS, class W> __device__ __forceinline__ void tile_store(c
     Vec4<R>* dst = D.slab + first;
     const __amdgpu_buffer_rsrc_t rs = sc1_rsrc(D.slab);
     for (int i = threadIdx.x; i < TILE_WORDS; i += BLOCK) {
-        const int w = SMAC_WIDE_TILE ? (i / TSX + PO) * PSX + ((i / TSY) % TW + PO) * PSY + i % TW + PO : i;      // the 6^3 core of the wide tile
+        int ti, tj, tk;
+        slab_node(i, ti, tj, tk);
+        const int w = SMAC_WIDE_TILE ? (ti + PO) * PSX + (tj + PO) * PSY + tk + PO : tile_index(ti, tj, tk);      // the 6^3 core of the wide tile
         Vec4<R> v;
         v.x = (R)tile[w] * s0; v.y = (R)tile[PTILE + w] * s123; v.z = (R)tile[2 * PTILE + w] * s123;
         v.w = NS > 3 ? (R)tile[3 * PTILE + w] * s123 : R(0);
@@ -531,7 +564,7 @@ __device__ __forceinline__ void slab_reduce(const DevSim<R>& D, int b, int l, Ve
         if (nch == 0) continue;
         const int dx = q >> 2, dy = (q >> 1) & 1, dz = q & 1;
         const bool mine = dx <= ex && dy <= ey && dz <= ez;
-        const int w = tile_index(lx + 4 * dx, ly + 4 * dy, lz + 4 * dz);
+        const int w = mine ? slab_record(q, lx, ly, lz) : 0;
         const Vec4<R>* sl = D.slab + (size_t)start * TILE_WORDS + w;
         const unsigned rec0 = (unsigned)start * TILE_WORDS + (unsigned)w;
         const __amdgpu_buffer_rsrc_t rs = sc1_rsrc(D.slab);

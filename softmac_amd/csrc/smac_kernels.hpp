@@ -200,8 +200,8 @@ __device__ __forceinline__ int slab_region_offset(int q) {          // 64, 32, 3
 // record of destination-local cell (lx, ly, lz) in region q (requires lx < 2 where ex, etc.)
 __device__ __forceinline__ int slab_record(int q, int lx, int ly, int lz) {
 #if SMAC_SLAB_BY_BLOCK
-    const int ny = (q & 2) ? 2 : 4, nz = (q & 1) ? 2 : 4;
-    return slab_region_offset(q) + (lx * ny + ly) * nz + lz;
+    const int sy = (q & 2) ? 1 : 2, sz = (q & 1) ? 1 : 2;
+    return slab_region_offset(q) + (((lx << sy) + ly) << sz) + lz;
 #else
     return tile_index(lx + 4 * (q >> 2), ly + 4 * ((q >> 1) & 1), lz + 4 * (q & 1));
 #endif
@@ -211,8 +211,8 @@ __device__ __forceinline__ void slab_node(int i, int& ti, int& tj, int& tk) {
 #if SMAC_SLAB_BY_BLOCK
     const int q = i < 64 ? 0 : (i < 96 ? 1 : (i < 128 ? 2 : (i < 144 ? 3 : (i < 176 ? 4 : (i < 192 ? 5 : (i < 208 ? 6 : 7))))));
     const int r = i - slab_region_offset(q);
-    const int ny = (q & 2) ? 2 : 4, nz = (q & 1) ? 2 : 4;
-    ti = r / (ny * nz) + 4 * (q >> 2); tj = (r / nz) % ny + 4 * ((q >> 1) & 1); tk = r % nz + 4 * (q & 1);
+    const int sy = (q & 2) ? 1 : 2, sz = (q & 1) ? 1 : 2;                 // log2 of the region's extent along y, z (4 or 2 nodes): shifts, not divisions
+    ti = (r >> (sy + sz)) + 4 * (q >> 2); tj = ((r >> sz) & ((1 << sy) - 1)) + 4 * ((q >> 1) & 1); tk = (r & ((1 << sz) - 1)) + 4 * (q & 1);
 #else
     ti = i / TSX; tj = (i / TSY) % TW; tk = i % TW;
 #endif

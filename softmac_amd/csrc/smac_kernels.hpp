@@ -190,9 +190,10 @@ __device__ __forceinline__ int tile_index(int li, int lj, int lk) { return li * 
 // nodes whose local coordinate is >= 4 along the axes with e = 1 (they belong to the +1 block there) - and a region's nodes are stored in the destination block's
 // own cell order.  The wave that sums a block reads, from each overlapping chunk, ONE contiguous run of 64 / 32 / 16 / 8 records (1 KB ... 128 B, every run a
 // multiple of 128 B from the slab's start); in the tile's own row-major order the same wave read 4-record (64-B) runs: half of every 128-B line fetched for nothing
-// (PMC: 31.6 MB read for 18 MB of records in k_grid_op).  SMAC_SLAB_BY_BLOCK=0: the tile's order (rounds 1-4).
+// (PMC: 31.6 MB read for 18 MB of records in k_grid_op).  MEASURED (profiles/r05_slab_order.txt): k_grid_op 12.9 -> 12.3 us, the backward reduction 14.9 -> 13.9 us - and the fused
+// backward particle kernel, which stores its tile in that order, 121.9 -> 123.5 us: nothing in all (3,575 vs 3,568 substeps/s).  Default 0: the tile's own order (rounds 1-4).
 #ifndef SMAC_SLAB_BY_BLOCK
-#define SMAC_SLAB_BY_BLOCK 1
+#define SMAC_SLAB_BY_BLOCK 0
 #endif
 __device__ __forceinline__ int slab_region_offset(int q) {          // 64, 32, 32, 16, 32, 16, 16, 8 records
     return q == 0 ? 0 : (q == 1 ? 64 : (q == 2 ? 96 : (q == 3 ? 128 : (q == 4 ? 144 : (q == 5 ? 176 : (q == 6 ? 192 : 208))))));

@@ -926,6 +926,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
+    if world == 1:
+        try:
+            sim._h.close()                                   # (destroys the handle: a -DSMAC_PHASE_CLOCK build dumps its markers there, tools/phase_clock.py)
+        except Exception:                                    # noqa: BLE001 - closed already by a sub-record
+            pass
     if watch is not None:
         watch.close()
     if dist is not None:

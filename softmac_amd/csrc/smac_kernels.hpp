@@ -299,8 +299,15 @@ template <class R> __device__ __forceinline__ void atomic_add(R* p, R v) { unsaf
 template <class R> __device__ __forceinline__ Vec4<R> gld(const Vec4<R>* base, unsigned cell) {
     return *(const Vec4<R>*)((const char*)base + cell * (unsigned)sizeof(Vec4<R>));
 }
+#ifndef SMAC_TIMING_PLAIN_GRID_ADDS
+#define SMAC_TIMING_PLAIN_GRID_ADDS 0    // 1 (timing experiment only, WRONG results): the grid adds of the hit-list kernels as plain stores - what the atomics cost (profiles/r05_contact_grid.txt)
+#endif
 template <class R> __device__ __forceinline__ void gatomic(Vec4<R>* base, unsigned cell, int comp, R v) {
+#if SMAC_TIMING_PLAIN_GRID_ADDS
+    ((R*)((char*)base + cell * (unsigned)sizeof(Vec4<R>)))[comp] = v;
+#else
     unsafeAtomicAdd((R*)((char*)base + cell * (unsigned)sizeof(Vec4<R>)) + comp, v);
+#endif
 }
 
 template <class R> __device__ __forceinline__ R wave_sum(R v) {
@@ -421,8 +428,36 @@ template <class R> __device__ __forceinline__ void f_tmp(const R* C, const R* E,
 // ------------------------------------------------------------------------------------------
 #if SMAC_PHASE_CLOCK
 // [marker][slot]: sums of timestamps (mod 2^64: differences of sums are sums of differences) and hit counts; markers 0-15 backward, 16-31 forward kernels
-__device__ unsigned long long smac_phase_sum[32 * 64];
-__device__ unsigned long long smac_phase_cnt[32 * 64];
+__device__ unsigned long long smac_phase_sum[48 * 64];
+__device__ unsigned long long smac_phase_cnt[48 * 64];
+// [kernel: 0 k_contact_hits, 1 k_contact_grad][bin]: EVERY wave's time from entry to exit in bins of 1024 ticks (a launch lasts as long as its slowest wave)
+__device__ unsigned long long smac_phase_hist[2 * 64];
+#define SMAC_WAVE_T0() const unsigned long long wave_t0_ = __builtin_readcyclecounter(); unsigned long long wave_tm_[6] = {0, 0, 0, 0, 0, 0}, wave_note_ = 0; (void)wave_tm_; (void)wave_note_
+#define SMAC_WAVE_HIST(k)                                                                            \
+    do {                                                                                             \
+        if ((threadIdx.x & 63) == 0) {                                                               \
+            const unsigned long long dt_ = (__builtin_readcyclecounter() - wave_t0_) >> 10;          \
+            atomicAdd(&smac_phase_hist[(k) * 64 + (int)(dt_ < 63 ? dt_ : 63)], 1ull);                \
+        }                                                                                            \
+    } while (0)
+// the slowest waves of k_contact_grad, one record of 8 words each: {entry-to-exit ticks, workgroup | wave << 16 | band masks of the wave's two hits << 24, hit count,
+// ticks from entry to five points of the walk}
+__device__ unsigned long long smac_slow[256 * 8];
+__device__ unsigned smac_slow_n;
+#define SMAC_WAVE_MARK(n) wave_tm_[n] = __builtin_readcyclecounter()
+#define SMAC_WAVE_NOTE(x) wave_note_ = (unsigned long long)(x)
+#define SMAC_WAVE_SLOW(limit, info, nh_)                                                                \
+    do {                                                                                             \
+        const unsigned long long end_ = __builtin_readcyclecounter();                                \
+        if ((threadIdx.x & 63) == 0 && end_ - wave_t0_ > (limit)) {                                  \
+            const unsigned k_ = atomicAdd(&smac_slow_n, 1u);                                         \
+            if (k_ < 256u) {                                                                         \
+                unsigned long long* r_ = smac_slow + 8 * k_;                                         \
+                r_[0] = end_ - wave_t0_; r_[1] = (info) | (wave_note_ << 24); r_[2] = (unsigned long long)(nh_);          \
+                for (int q_ = 1; q_ < 6; ++q_) r_[2 + q_] = wave_tm_[q_] - wave_t0_;                     \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
 #define SMAC_PHASE(i, cond)                                                                          \
     do {                                                                                             \
         if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 3 && (cond)) {                           \
@@ -433,6 +468,11 @@ __device__ unsigned long long smac_phase_cnt[32 * 64];
     } while (0)
 #else
 #define SMAC_PHASE(i, cond) do { } while (0)
+#define SMAC_WAVE_T0() do { } while (0)
+#define SMAC_WAVE_HIST(k) do { } while (0)
+#define SMAC_WAVE_MARK(n) do { } while (0)
+#define SMAC_WAVE_NOTE(x) do { } while (0)
+#define SMAC_WAVE_SLOW(...) do { } while (0)
 #endif
 #define SMAC_CHUNK_PROLOGUE_AT(ci)                            \
     const Chunk ch = D.chunks[ci];                            \
@@ -1275,22 +1315,32 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         if ((int)threadIdx.x < D.fk_ride) prim_fk_step(D.prim_state + threadIdx.x * D.fk_stride, f, D.dt64);
         return;
     }
-    if (D.zero_next_hits && blockIdx.x == 0 && threadIdx.x == 0) *D.nhits_next = 0;
-    if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
-    const int nh = *D.nhits;
+    SMAC_WAVE_T0();
     // one group of 32 lanes per hit; SMAC_HITS_PER_WAVE 1: the group is the lower half of a wave whose upper half idles (mask 0) - a wave then runs the chains of ONE hit
     constexpr int HPW = SMAC_HITS_PER_WAVE, WG_HITS = (BLOCK / 64) * HPW;
     const int grp = HPW == 2 ? (int)(threadIdx.x >> 5) : (int)(threadIdx.x >> 6), d = threadIdx.x & 31;
     const bool live = HPW == 2 || (threadIdx.x & 32) == 0;
     const double life = 1.0 / (double)(D.substeps - (f - D.frame_shift) % D.substeps);     // :425
     const int nwg = (int)gridDim.x - (D.fk_ride > 0 ? 1 : 0);            // (the last workgroup of a launch that carries forward_kinematics walks no hits)
-    for (int base = blockIdx.x * WG_HITS; base < nh; base += nwg * WG_HITS) {
-        for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) ctile[i] = 0.0;
-        const int wg_block = D.hits[base].block;
-        __syncthreads();
+    // This kernel is a chain of dependent round trips on an idle chip (a few thousand hits): the hit count, the first hit's block and this group's own hit record
+    // are asked for TOGETHER (the records speculatively - the list holds D.Npad entries - and dropped when the count says there is none), not one after the other
+    const int base0 = (int)blockIdx.x * WG_HITS;
+    Hit h_next = D.hits[min(base0 + grp, D.Npad - 1)];
+    int block_next = D.hits[min(base0, D.Npad - 1)].block;
+    const int nh = *D.nhits;
+    if (threadIdx.x < MAX_PRIMS * 6) ext_acc[threadIdx.x] = 0.0;
+    __syncthreads();                                                                        // (waits for the three loads as well: the walk needs them at once anyway)
+    if (D.zero_next_hits && blockIdx.x == 0 && threadIdx.x == 0) *D.nhits_next = 0;
+    for (int base = base0; base < nh; base += nwg * WG_HITS) {
+        for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) ctile[i] = 0.0;           // (the barrier that publishes the zeros stands behind the chain: by then no load is in flight)
+        const int wg_block = block_next;
         const int hi = base + grp;
         Hit h = {0, 0, 0, 0};
-        if (hi < nh && live) h = D.hits[hi];
+        if (hi < nh && live) h = h_next;
+        {
+            const int nb2 = base + nwg * WG_HITS;                                           // (a workgroup with a second round: the same, one round ahead)
+            if (nb2 < nh) { h_next = D.hits[min(nb2 + grp, D.Npad - 1)]; block_next = D.hits[min(nb2, D.Npad - 1)].block; }
+        }
         const int mask = h.mask, p = h.p;
         PX x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
         if (mask) load_pos(frame(D.S, f, D.Npad), D.Npad, p, x);
@@ -1365,18 +1415,23 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
                 }
             }
         }
+        __syncthreads();                                                                    // tile zeroed everywhere
+        R late[3] = {R(0), R(0), R(0)};                                                     // a node outside the tile: its global atomics leave AFTER the barrier below
+        bool is_late = false;                                                               // (a barrier waits for every memory operation of the wave, atomics included)
         if (mask && d < 27 && has) {                                                        // mixed4, alpha = 2 (:437)
             const bool in_tile = h.block == wg_block && ((nd.okx >> ni) & (nd.oky >> nj) & (nd.okz >> nk) & 1) != 0;
             const int tw = (ni == 0 ? nd.tx[0] : (ni == 1 ? nd.tx[1] : nd.tx[2])) + (nj == 0 ? nd.ty[0] : (nj == 1 ? nd.ty[1] : nd.ty[2])) +
                            (nk == 0 ? nd.tz[0] : (nk == 1 ? nd.tz[1] : nd.tz[2]));
+            is_late = !in_tile;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const R val = -R(2) * wn * (R)((double)v_tmp[c] - v_tgt[c]);
                 if (in_tile) lds_add(ctile + tw + c * TILE_WORDS, val);
-                else gatomic(D.vout, cell, c, val);
+                else late[c] = val;
             }
         }
         __syncthreads();
+        if (is_late) { gatomic(D.vout, cell, 0, late[0]); gatomic(D.vout, cell, 1, late[1]); gatomic(D.vout, cell, 2, late[2]); }
         {
             const int nb = D.nb;
             const int bz = wg_block % nb, by = (wg_block / nb) % nb, bx = wg_block / (nb * nb);
@@ -1389,10 +1444,11 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
                 }
             }
         }
-        __syncthreads();
+        if (base + nwg * WG_HITS < nh) __syncthreads();                                     // (the tile is zeroed again only in a second round)
     }
     __syncthreads();
     if (threadIdx.x < D.P * 6 && ext_acc[threadIdx.x] != 0.0) atomic_add(D.ext_f + threadIdx.x, ext_acc[threadIdx.x]);
+    SMAC_WAVE_HIST(0);
 }
 
 // one particle of g2p :299-318: gather from the staged tile `gt` (global fallback for a lane that drifted out of it), write frame f+1
@@ -1916,26 +1972,57 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
     }
     const int wg = (int)blockIdx.x - ride_blocks, nwg = (int)gridDim.x - ride_blocks - (D.fk_ride > 0 ? D.fk_ride : 0);
     __shared__ double pg_acc[MAX_PRIMS * 13];         // primitive-state adjoints of this workgroup's hits (see k_contact)
-    if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
-    __syncthreads();
     // grid_v_mixed.grad corrections of this workgroup's 8 hits are pre-reduced in an LDS tile over the block of its first
     // hit (k_p2g appends a wave's hits contiguously, so the 8 nearly always share the block): neighbouring contact
     // particles hit the same few nodes and their global atomics would serialise on those cache lines
     __shared__ tile_t atile[3 * TILE_WORDS];
-    const int nh = *D.nhits;
+    __shared__ double jac[MAX_PRIMS * 4 * BLOCK];      // per primitive and lane: d(velocity out)/d(direction of the lane) and the ext_f adjoint's share (each lane reads only what it wrote)
+    SMAC_WAVE_T0();
+    SMAC_PHASE(32, wg * 8 < 1024);                // (entry; the first 128 workgroups hold hits in the bench scene)
     constexpr int HPW = SMAC_HITS_PER_WAVE, WG_HITS = (BLOCK / 64) * HPW;      // (see k_contact_hits)
     const int grp = HPW == 2 ? (int)(threadIdx.x >> 5) : (int)(threadIdx.x >> 6), d = threadIdx.x & 31, lane0 = (threadIdx.x & 63) & ~31;
     const bool live = HPW == 2 || (threadIdx.x & 32) == 0;
-    for (int base = wg * WG_HITS; base < nh; base += nwg * WG_HITS) {
-        for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) atile[i] = 0.0;
-        const int wg_block = D.hits[base].block;
-        __syncthreads();
+    // a latency chain on an idle chip, as k_contact_hits: hit count, first hit's block and own hit record are asked for together (the records speculatively)
+    const int base0 = wg * WG_HITS;
+    Hit h_next = D.hits[min(base0 + grp, D.Npad - 1)];
+    int block_next = D.hits[min(base0, D.Npad - 1)].block;
+    const int nh = *D.nhits;
+    if (threadIdx.x < MAX_PRIMS * 13) pg_acc[threadIdx.x] = 0.0;
+    __syncthreads();                              // (waits for the three loads as well: the walk needs them at once anyway)
+    SMAC_PHASE(33, wg * 8 < 1024);                // hit count, block and record in; accumulators zeroed
+    SMAC_WAVE_MARK(1);
+    for (int base = base0; base < nh; base += nwg * WG_HITS) {
+        for (int i = threadIdx.x; i < 3 * TILE_WORDS; i += BLOCK) atile[i] = 0.0;             // (published by the barrier behind the chains: no load is in flight there)
+        const int wg_block = block_next;
         const int hi = base + grp;
         Hit h = {0, 0, 0, 0};
-        if (hi < nh && live) h = D.hits[hi];
+        if (hi < nh && live) h = h_next;
+        {
+            const int nb2 = base + nwg * WG_HITS;                                             // (a workgroup with a second round: the same, one round ahead)
+            if (nb2 < nh) { h_next = D.hits[min(nb2 + grp, D.Npad - 1)]; block_next = D.hits[min(nb2, D.Npad - 1)].block; }
+        }
         const int mask = h.mask, p = h.p;
         typename pos_of<R>::type x[3] = {pos_mid<R>(), pos_mid<R>(), pos_mid<R>()};
         if (mask) load_pos(frame(D.S, f, D.Npad), D.Npad, p, x);
+        // asked for NOW, used at the end: x.grad's old value (lane d < 3) and - DIRECT - the {m,p} records of the tile nodes this thread flushes.  Read where they are
+        // used, each would wait behind this wave's global atomics (loads and atomics retire in order) or add a round trip of its own
+        R ax_old = R(0);
+        if (mask && d < 3) ax_old = D.Af[rowoff(CX + d, p, D.Npad)];
+        static_assert(TILE_WORDS <= BLOCK, "one tile node per thread in the flush below");
+        Vec4<R> flush_in = {R(0), R(0), R(0), R(0)};
+        unsigned flush_cell = 0u;
+        int flush_i = 0, flush_j = 0, flush_k = 0;
+        if (threadIdx.x < TILE_WORDS) {
+            const int nb = D.nb, idx = threadIdx.x;
+            flush_i = 4 * (wg_block / (nb * nb)) + idx / TSX;
+            flush_j = 4 * ((wg_block / nb) % nb) + (idx / TSY) % TW;
+            flush_k = 4 * (wg_block % nb) + idx % TW;
+            if (flush_i < D.n && flush_j < D.n && flush_k < D.n) {                              // (the tile of a block at the far wall overhangs the grid; nothing is added there)
+                flush_cell = (unsigned)cell_of(nb, flush_i, flush_j, flush_k);
+                if (DIRECT) flush_in = gld(D.vin, flush_cell);
+            }
+        }
+        SMAC_PHASE(34, wg * 8 < 1024 && base == base0);        // tile zeroed, position / x.grad / flush records asked for
         Stencil<R> st;
         Nodes nd;
         stencil_at(D, x, st, nd, h.block);
@@ -1968,35 +2055,48 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
             for (int c = 0; c < 3; ++c) { v_tmp[c] += __shfl_xor(v_tmp[c], o, 64); gd[c] += __shfl_xor(gd[c], o, 64); }
         // forward chain (every lane), then its adjoint primitive by primitive in reverse - in double whatever R is (the
         // push-out and its derivative carry a factor 1/dt)
+        SMAC_WAVE_MARK(2);
+        SMAC_WAVE_NOTE((__shfl(mask, 0, 64) & 0xff) | ((__shfl(mask, 32, 64) & 0xff) << 8));
+        SMAC_PHASE(35, wg * 8 < 1024 && base == base0);        // position in, 27 node records gathered and reduced over the group
         constexpr bool HYB = SMAC_CONTACT_HYBRID && sizeof(R) == 4;          // (see k_contact_hits: float32 mode keeps only the distance in double)
-        // the forward chain of ONE primitive on a velocity held in double (exact for the float values the hybrid chain works on)
-        auto chain_fwd = [&](int i, const double* s13v, double* vel) {
-            if (HYB) {
-                float v32[3] = {(float)vel[0], (float)vel[1], (float)vel[2]}, e32[6];
-                collide_mixed_hybrid<double, float>(D.prim64[i], *(const PrimTable<float>*)&D.prim[i], s13v, x64, v32, (float)D.p_mass, D.dt64, life, e32);
-                vel[0] = (double)v32[0]; vel[1] = (double)v32[1]; vel[2] = (double)v32[2];
-            } else {
-                double dummy6[6];
-                collide_mixed(D.prim64[i], s13v, x64, vel, pm64, D.dt64, life, dummy6);
-            }
-        };
-        double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
-        // One primitive in range (the usual case): the value part of the dual pass below IS the forward result,
-        // so the separate forward evaluation - a second chain of dependent SDF lookups - is skipped.
         // (CLOTH instantiation: sheet bits | primitive band bits << 8, see k_contact_hits; the forward chain is primitives in index order, then the sheet,
         //  so the adjoint takes the sheet first and the primitives in reverse)
         const int pm = CLOTH ? (mask >> 8) & 15 : mask;
         const bool cloth_on = CLOTH && (mask & 1) != 0;
-        const bool single = !cloth_on && pm != 0 && (pm & (pm - 1)) == 0;
-        if (!single) {                        // velocity after the primitives (the sheet's input; the final velocity when there is no sheet)
+        // FORWARD over the primitives in range, in index order, ONE dual pass each: its value part is the forward velocity the next primitive starts from, its
+        // tangent part - lane d: direction d - is filed per lane (jac: the velocity's three tangents and the ext_f adjoint's share, which does not depend on the
+        // velocity adjoint) for the reverse walk below.  Rounds 1-4 walked in reverse and re-ran the plain chain up to every primitive: a particle between both fingers
+        // cost 3 plain + 2 dual chains, and the launch lasts as long as its slowest wave (profiles/r05_contact_grid.txt); now 2 dual chains, nothing replayed.
+        double v_tgt[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
 #pragma unroll 1
-            for (int i = 0; i < D.P; ++i)
-                if ((pm >> i) & 1) {
-                    const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-                    double s13[13];
-                    for (int c = 0; c < 13; ++c) s13[c] = ps[c];
-                    chain_fwd(i, s13, v_tgt);
+        for (int i = 0; i < D.P; ++i) {
+            const bool act = (pm >> i) & 1;
+            if (!__ballot(act)) continue;
+            double jv[3] = {0.0, 0.0, 0.0}, je = 0.0, vfwd[3] = {0.0, 0.0, 0.0};
+            if (act && d < 19) {
+                const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
+                Dual<double> pos[3], stt[13];
+                for (int c = 0; c < 3; ++c) pos[c] = Dual<double>(x64[c], d == c ? 1.0 : 0.0);
+                for (int c = 0; c < 13; ++c) stt[c] = Dual<double>(ps[c], d == 6 + c ? 1.0 : 0.0);
+                if (HYB) {
+                    Dual<float> v[3], ext[6];
+                    for (int c = 0; c < 3; ++c) v[c] = Dual<float>((float)v_tgt[c], d == 3 + c ? 1.f : 0.f);
+                    collide_mixed_hybrid<Dual<double>, Dual<float>>(D.prim64[i], *(const PrimTable<float>*)&D.prim[i], stt, pos, v, (float)D.p_mass, D.dt64, life, ext);
+                    for (int c = 0; c < 3; ++c) { jv[c] = (double)v[c].d; vfwd[c] = (double)v[c].v; }
+                    for (int c = 0; c < 6; ++c) je += D.ext_f_grad[i * 6 + c] * (double)ext[c].d;
+                } else {
+                    Dual<double> v[3], ext[6];
+                    for (int c = 0; c < 3; ++c) v[c] = Dual<double>(v_tgt[c], d == 3 + c ? 1.0 : 0.0);
+                    collide_mixed(D.prim64[i], stt, pos, v, pm64, D.dt64, life, ext);
+                    for (int c = 0; c < 3; ++c) { jv[c] = v[c].d; vfwd[c] = v[c].v; }
+                    for (int c = 0; c < 6; ++c) je += D.ext_f_grad[i * 6 + c] * ext[c].d;
                 }
+            }
+            jac[(i * 4 + 0) * BLOCK + threadIdx.x] = jv[0]; jac[(i * 4 + 1) * BLOCK + threadIdx.x] = jv[1];
+            jac[(i * 4 + 2) * BLOCK + threadIdx.x] = jv[2]; jac[(i * 4 + 3) * BLOCK + threadIdx.x] = je;
+            // the velocity this primitive leaves, from the group's first lane (outside the band the chain leaves it as it was)
+            const double f0 = __shfl(vfwd[0], lane0, 64), f1 = __shfl(vfwd[1], lane0, 64), f2 = __shfl(vfwd[2], lane0, 64);
+            if (act) { v_tgt[0] = f0; v_tgt[1] = f1; v_tgt[2] = f2; }
         }
         double g[3] = {-(double)gd[0], -(double)gd[1], -(double)gd[2]};             // adjoint of v_tgt
         double gpos[3] = {0.0, 0.0, 0.0};
@@ -2039,47 +2139,13 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
             }
         }
 #pragma unroll 1
-        for (int i = D.P - 1; i >= 0; --i) {
+        for (int i = D.P - 1; i >= 0; --i) {                 // REVERSE: the filed tangents against the velocity adjoint of the moment
             const bool act = (pm >> i) & 1;
             if (!__ballot(act)) continue;
             double out = 0.0;
-            double vfwd[3] = {0.0, 0.0, 0.0};
-            if (act) {
-                const double* ps = D.prim_state + ((size_t)i * D.max_frames + f) * 13;
-                // velocity entering primitive i: replay the chain up to i
-                double vin[3] = {(double)v_tmp[0], (double)v_tmp[1], (double)v_tmp[2]};
-                for (int q = 0; q < i; ++q)
-                    if ((pm >> q) & 1) {
-                        const double* pq = D.prim_state + ((size_t)q * D.max_frames + f) * 13;
-                        double sq[13];
-                        for (int c = 0; c < 13; ++c) sq[c] = pq[c];
-                        chain_fwd(q, sq, vin);
-                    }
-                if (d < 19) {
-                    Dual<double> pos[3], stt[13];
-                    for (int c = 0; c < 3; ++c) pos[c] = Dual<double>(x64[c], d == c ? 1.0 : 0.0);
-                    for (int c = 0; c < 13; ++c) stt[c] = Dual<double>(ps[c], d == 6 + c ? 1.0 : 0.0);
-                    if (HYB) {
-                        Dual<float> v[3], ext[6];
-                        for (int c = 0; c < 3; ++c) v[c] = Dual<float>((float)vin[c], d == 3 + c ? 1.f : 0.f);
-                        collide_mixed_hybrid<Dual<double>, Dual<float>>(D.prim64[i], *(const PrimTable<float>*)&D.prim[i], stt, pos, v, (float)D.p_mass, D.dt64, life, ext);
-                        for (int c = 0; c < 3; ++c) out += g[c] * (double)v[c].d;
-                        for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * (double)ext[c].d;
-                        for (int c = 0; c < 3; ++c) vfwd[c] = (double)v[c].v;
-                    } else {
-                        Dual<double> v[3], ext[6];
-                        for (int c = 0; c < 3; ++c) v[c] = Dual<double>(vin[c], d == 3 + c ? 1.0 : 0.0);
-                        collide_mixed(D.prim64[i], stt, pos, v, pm64, D.dt64, life, ext);
-                        for (int c = 0; c < 3; ++c) out += g[c] * v[c].d;
-                        for (int c = 0; c < 6; ++c) out += D.ext_f_grad[i * 6 + c] * ext[c].d;
-                        for (int c = 0; c < 3; ++c) vfwd[c] = v[c].v;
-                    }
-                }
-            }
-            {   // forward velocity after this primitive, from the group's first lane
-                const double f0 = __shfl(vfwd[0], lane0, 64), f1 = __shfl(vfwd[1], lane0, 64), f2 = __shfl(vfwd[2], lane0, 64);
-                if (act && single) { v_tgt[0] = f0; v_tgt[1] = f1; v_tgt[2] = f2; }
-            }
+            if (act && d < 19)
+                out = g[0] * jac[(i * 4 + 0) * BLOCK + threadIdx.x] + g[1] * jac[(i * 4 + 1) * BLOCK + threadIdx.x] + g[2] * jac[(i * 4 + 2) * BLOCK + threadIdx.x] +
+                      jac[(i * 4 + 3) * BLOCK + threadIdx.x];
             // direction d of this group's hit sits in lane lane0 + d
             const double o0 = __shfl(out, lane0 + 0, 64), o1 = __shfl(out, lane0 + 1, 64), o2 = __shfl(out, lane0 + 2, 64);
             const double o3 = __shfl(out, lane0 + 3, 64), o4 = __shfl(out, lane0 + 4, 64), o5 = __shfl(out, lane0 + 5, 64);
@@ -2093,7 +2159,12 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
             if ((threadIdx.x & 63) >= 6 && (threadIdx.x & 63) < 19 && sg != 0.0)
                 __hip_atomic_fetch_add(pg_acc + i * 13 + (d - 6), sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        SMAC_WAVE_MARK(3);
+        SMAC_PHASE(36, wg * 8 < 1024 && base == base0);        // forward replay + dual chains of the primitives in range
         const R diff[3] = {(R)((double)v_tmp[0] - v_tgt[0]), (R)((double)v_tmp[1] - v_tgt[1]), (R)((double)v_tmp[2] - v_tgt[2])};
+        __syncthreads();                                                                        // tile zeroed everywhere
+        R late[4] = {R(0), R(0), R(0), R(0)};                  // a node outside the tile: its global atomics leave AFTER the barrier below (a barrier waits for
+        bool is_late = false;                                  // every memory operation of the wave, atomics included)
         if (mask) {
             // adjoint of v_tmp = direct (mixed4) + through the chain (mixed3); mixed2.grad scatter by node
             const R gvt[3] = {(R)((double)gd[0] + g[0]), (R)((double)gd[1] + g[1]), (R)((double)gd[2] + g[2])};
@@ -2107,13 +2178,14 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
                     cell_ijk(D.nb, cell, ci, cj, ck);
                     R gn[3] = {wn * gvt[0], wn * gvt[1], wn * gvt[2]};
                     const Vec4<R> o = grid_op_node_adjoint(D, vin_n, ci, cj, ck, gn);
-                    if (has != R(0)) { gatomic(D.ain, cell, 0, o.x); gatomic(D.ain, cell, 1, o.y); gatomic(D.ain, cell, 2, o.z); gatomic(D.ain, cell, 3, o.w); }
-                } else {
+                    if (has != R(0)) { is_late = true; late[0] = o.x; late[1] = o.y; late[2] = o.z; late[3] = o.w; }
+                } else if (in_tile) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (in_tile) lds_add(atile + tw + c * TILE_WORDS, wn * gvt[c]);
-                        else gatomic(D.amix, cell, c, wn * gvt[c]);
-                    }
+                    for (int c = 0; c < 3; ++c) lds_add(atile + tw + c * TILE_WORDS, wn * gvt[c]);
+                } else {
+                    is_late = true;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) late[c] = wn * gvt[c];
                 }
                 gw = vm.x * gvt[0] + vm.y * gvt[1] + vm.z * gvt[2]                           // mixed2: d/dw
                      - R(2) * has * (diff[0] * G.x + diff[1] * G.y + diff[2] * G.z);        // mixed4: d/dw
@@ -2129,40 +2201,46 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
 #pragma unroll
                 for (int c = 0; c < 3; ++c) gfx[c] += __shfl_xor(gfx[c], o, 64);
             if (d < 3) {
-                R* Af = D.Af;
                 const double gp = d == 0 ? gpos[0] : (d == 1 ? gpos[1] : gpos[2]);
                 const R gf = d == 0 ? gfx[0] : (d == 1 ? gfx[1] : gfx[2]);
-                Af[rowoff(CX + d, p, D.Npad)] += (R)(gp + (double)(D.inv_dx * gf));
+                D.Af[rowoff(CX + d, p, D.Npad)] = ax_old + (R)(gp + (double)(D.inv_dx * gf));   // (a particle stands in the list once: nobody else adds to this word)
             }
         }
+        SMAC_PHASE(37, wg * 8 < 1024 && base == base0);        // node scatter into the LDS tile, x.grad out
         __syncthreads();
-        {
-            const int nb = D.nb;
-            const int bz = wg_block % nb, by = (wg_block / nb) % nb, bx = wg_block / (nb * nb);
-            for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
-                const R a0 = (R)atile[idx], a1 = (R)atile[TILE_WORDS + idx], a2 = (R)atile[2 * TILE_WORDS + idx];
-                if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
-                    const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
-                    const unsigned cell = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
-                    if (DIRECT) {
-                        R gn[3] = {a0, a1, a2};
-                        const Vec4<R> o = grid_op_node_adjoint(D, gld(D.vin, cell), 4 * bx + li, 4 * by + lj, 4 * bz + lk, gn);
-                        if (o.x != R(0) || o.y != R(0) || o.z != R(0) || o.w != R(0)) {
-                            gatomic(D.ain, cell, 0, o.x); gatomic(D.ain, cell, 1, o.y); gatomic(D.ain, cell, 2, o.z); gatomic(D.ain, cell, 3, o.w);
-                        }
-                    } else {
-                        gatomic(D.amix, cell, 0, a0); gatomic(D.amix, cell, 1, a1); gatomic(D.amix, cell, 2, a2);
+        SMAC_WAVE_MARK(4);
+        SMAC_PHASE(38, wg * 8 < 1024 && base == base0);        // barrier
+        if (is_late) {
+            if (DIRECT) { gatomic(D.ain, cell, 0, late[0]); gatomic(D.ain, cell, 1, late[1]); gatomic(D.ain, cell, 2, late[2]); gatomic(D.ain, cell, 3, late[3]); }
+            else { gatomic(D.amix, cell, 0, late[0]); gatomic(D.amix, cell, 1, late[1]); gatomic(D.amix, cell, 2, late[2]); }
+        }
+        if (threadIdx.x < TILE_WORDS) {
+            const int idx = threadIdx.x;
+            const R a0 = (R)atile[idx], a1 = (R)atile[TILE_WORDS + idx], a2 = (R)atile[2 * TILE_WORDS + idx];
+            if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
+                if (DIRECT) {
+                    R gn[3] = {a0, a1, a2};
+                    const Vec4<R> o = grid_op_node_adjoint(D, flush_in, flush_i, flush_j, flush_k, gn);
+                    if (o.x != R(0) || o.y != R(0) || o.z != R(0) || o.w != R(0)) {
+                        gatomic(D.ain, flush_cell, 0, o.x); gatomic(D.ain, flush_cell, 1, o.y); gatomic(D.ain, flush_cell, 2, o.z); gatomic(D.ain, flush_cell, 3, o.w);
                     }
+                } else {
+                    gatomic(D.amix, flush_cell, 0, a0); gatomic(D.amix, flush_cell, 1, a1); gatomic(D.amix, flush_cell, 2, a2);
                 }
             }
         }
-        __syncthreads();
+        if (base + nwg * WG_HITS < nh) __syncthreads();                                     // (the tile is zeroed again only in a second round)
+        SMAC_WAVE_MARK(5);
+        SMAC_PHASE(39, wg * 8 < 1024 && base == base0);        // late atomics, tile flushed through grid_op's node adjoint (global atomics)
     }
     __syncthreads();
     if (threadIdx.x < D.P * 13 && pg_acc[threadIdx.x] != 0.0) {
         const int i = threadIdx.x / 13, c = threadIdx.x % 13;
         atomic_add(D.prim_grad + ((size_t)i * D.max_frames + f) * 13 + c, pg_acc[threadIdx.x]);
     }
+    SMAC_PHASE(40, wg * 8 < 1024);
+    SMAC_WAVE_HIST(1);
+    SMAC_WAVE_SLOW(36000ull, (unsigned long long)wg | ((unsigned long long)(threadIdx.x >> 6) << 16), nh);
 }
 
 // Adjoint of the penalty contact impulse of p2g (collision_type 1) for the listed particles: the impulse's

@@ -254,15 +254,24 @@ template <class R> struct Sim final : ISim {
         if (stream) hipStreamSynchronize(stream);
 #if SMAC_PHASE_CLOCK
         if (const char* path = getenv("SMAC_PHASE_DUMP")) {          // tools/phase_clock.sh: per marker, sum of timestamps (mod 2^64) and hits
-            static unsigned long long hs[32 * 64], hc[32 * 64];
+            static unsigned long long hs[48 * 64], hc[48 * 64];
             (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(smac::smac_phase_sum), sizeof(hs));
             (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(smac::smac_phase_cnt), sizeof(hc));
             if (FILE* fp = fopen(path, "a")) {
-                for (int m = 0; m < 32; ++m) {
+                for (int m = 0; m < 48; ++m) {
                     unsigned long long a = 0, c = 0;
                     for (int k = 0; k < 64; ++k) { a += hs[m * 64 + k]; c += hc[m * 64 + k]; }
                     fprintf(fp, "%d %llu %llu\n", m, a, c);
                 }
+                static unsigned long long hh[2 * 64];                  // per-wave durations of the two contact kernels: "-1 kernel*64+bin count"
+                (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(smac::smac_phase_hist), sizeof(hh));
+                for (int k = 0; k < 2 * 64; ++k)
+                    if (hh[k]) fprintf(fp, "-1 %d %llu\n", k, hh[k]);
+                static unsigned long long slow[256 * 8];               // the slowest waves of k_contact_grad: "-2 record*8+word value"
+                unsigned ns = 0;
+                (void)hipMemcpyFromSymbol(slow, HIP_SYMBOL(smac::smac_slow), sizeof(slow));
+                (void)hipMemcpyFromSymbol(&ns, HIP_SYMBOL(smac::smac_slow_n), sizeof(ns));
+                for (unsigned k = 0; k < (ns < 256u ? ns : 256u) * 8; ++k) fprintf(fp, "-2 %u %llu\n", k, slow[k]);
                 fclose(fp);
             }
         }
@@ -1665,7 +1674,26 @@ template <class R> struct Sim final : ISim {
     int nchunk_blocks() const { return ((D.nchunks + 7) / 8) * 8; }   // XCD-aware chunk mapping (xcd_chunk) needs a multiple of 8
     // hit list: 8 hits per workgroup and pass; the count lives on the device, so size the grid for the chip (a group
     // that finds no hit left exits at once) - a short grid turns the list into a serial chain of SDF-lookup latencies
-    int contact_grad_grid() const { const int per = (BLOCK / 64) * SMAC_HITS_PER_WAVE, need = (D.N + per - 1) / per; return need < 2048 ? (need > 0 ? need : 1) : 2048; }
+    // Workgroups of the two hit-list kernels.  Both walk the list with a grid stride, so ANY count is correct; what the count costs is time: 2,048 workgroups for the
+    // 250 that find a hit (2,000 of 1M particles in contact) meant 1,800 empty ones queueing behind the working ones - k_contact_grad holds a whole CU per workgroup -
+    // and the launch lasted twice as long as its slowest wave (profiles/r05_contact_grid.txt).  The host cannot read the device's counter without a stall, but the
+    // checkpoint saves drop every frame's count into pinned host memory (h_nhits): the count of frame f itself when it has landed (backward: always), else the
+    // largest count among the neighbouring frames (the contact set moves slowly), with a quarter on top.  Nothing known (no saves yet): the old 2,048.
+    int contact_grid_env = getenv("SMAC_CONTACT_GRID_HINT") ? atoi(getenv("SMAC_CONTACT_GRID_HINT")) : 1;
+    int contact_grad_grid(int f = -1, bool exact = false) const {
+        const int per = (BLOCK / 64) * SMAC_HITS_PER_WAVE, all = (D.N + per - 1) / per;
+        const int cap = all < 2048 ? (all > 0 ? all : 1) : 2048;
+        if (!contact_grid_env || f < 0 || !h_nhits) return cap;
+        const volatile int* seen = h_nhits;
+        int hint = exact ? seen[f] : -1;
+        if (hint < 0) {
+            for (int i = f > 24 ? f - 24 : 0; i < cfg.max_frames && i <= f + 24; ++i) hint = seen[i] > hint ? seen[i] : hint;
+            if (hint < 0) return cap;
+            hint += hint / 4 + 64;
+        }
+        const int need = (hint + per - 1) / per;
+        return need < 8 ? 8 : (need < cap ? need : cap);
+    }
     // Forward grid passes.  stage 0: everything; stage 1: clear_grid :93-114 on the active blocks, p2g, (forward
     // kinematics), slab reduction; stage 2: grid_op + contact.  Stages 1/2 exist for the slab decomposition, which
     // sums the {m,p} halo planes across neighbouring GPUs between them.
@@ -1764,13 +1792,13 @@ template <class R> struct Sim final : ISim {
             Dc.zero_next_hits = 0;
             if (D.cloth.present) {
                 hipLaunchKernelGGL(k_cloth_hit_list<R>, dim3(nchunk_blocks()), dim3(BLOCK), 0, stream, Dc, f);
-                hipLaunchKernelGGL((k_contact_hits<R, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f);
+                hipLaunchKernelGGL((k_contact_hits<R, true>), dim3(contact_grad_grid(f)), dim3(BLOCK), 0, stream, Dc, f);
             } else {
                 if (tail_done) {
                     Dc.zero_next_hits = fuse_next ? 1 : 0;
                     if (fk_in_contact) { Dc.fk_ride = D.P; Dc.fk_stride = (size_t)cfg.max_frames * 13; }
                 }
-                hipLaunchKernelGGL((k_contact_hits<R, false>), dim3(contact_grad_grid() + (fk_in_contact ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, f);
+                hipLaunchKernelGGL((k_contact_hits<R, false>), dim3(contact_grad_grid(f) + (fk_in_contact ? 1 : 0)), dim3(BLOCK), 0, stream, Dc, f);
                 Dc.fk_ride = 0; Dc.zero_next_hits = 0;
             }
             prof_end();
@@ -2190,18 +2218,19 @@ template <class R> struct Sim final : ISim {
                 Dc.nhits = ck_nhits + f;
             }
             const GridSet<R> none{nullptr, nullptr, nullptr, nullptr};
+            const int cgrid = contact_grad_grid(f, hits_from_ck_frame == f);          // (the filed list's own count when the list is the filed one)
             if (D.cloth.present) {
-                if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
-                else hipLaunchKernelGGL((k_contact_grad<R, false, true>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
+                if (fused_grid_bwd(phase)) hipLaunchKernelGGL((k_contact_grad<R, true, true>), dim3(cgrid), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
+                else hipLaunchKernelGGL((k_contact_grad<R, false, true>), dim3(cgrid), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
             } else if (fused_grid_bwd(phase)) {
                 // (tail reduction) what the reduction launch used to carry rides here: the next frame's restore in the first workgroups, forward_kinematics.grad in the last
                 const int ride = pend_restore ? ngrid_blocks() : 0, fkr = pend_fk ? D.P : 0;
                 Dc.fk_ride = fkr; Dc.fk_stride = (size_t)cfg.max_frames * 13;
                 Dc.ck_flags_next = f > 0 ? ck_flags_of(f - 1) : nullptr;
-                hipLaunchKernelGGL((k_contact_grad<R, true, false>), dim3(ride + contact_grad_grid() + fkr), dim3(BLOCK), 0, stream, Dc, f,
+                hipLaunchKernelGGL((k_contact_grad<R, true, false>), dim3(ride + cgrid + fkr), dim3(BLOCK), 0, stream, Dc, f,
                                    pend_restore ? grid_set_ptrs(1 - grid_set) : none, pend_restore ? (const Vec4<R>*)ck_slot(f - 1) : (const Vec4<R>*)nullptr, ride);
                 pend_restore = pend_fk = false;
-            } else hipLaunchKernelGGL((k_contact_grad<R, false, false>), dim3(contact_grad_grid()), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
+            } else hipLaunchKernelGGL((k_contact_grad<R, false, false>), dim3(cgrid), dim3(BLOCK), 0, stream, Dc, f, none, (const Vec4<R>*)nullptr, 0);
             prof_end();
         }
         if (pend_restore || pend_fk) {                       // (tail reduction, no contact adjoint launch in this substep)

@@ -15,14 +15,28 @@ NAMES = {
     "k_p2g_g2p_grad, every wave": [(10, "entry"), (11, "chunk descriptor in")],
     "k_p2g, every wave": [(22, "entry"), (23, "primitive states -> LDS, barrier, chunk descriptor in")],
     "k_g2p": [(24, "start"), (25, "x in, tile staged; barrier"), (26, "27-node gather, 15 rows out")],
+    # round 5: the contact adjoint (workgroups that hold hits; the markers inside the hit loop fire in its first trip)
+    "k_contact_grad": [(32, "entry"), (33, "hit count, first hit's block and own hit record in (asked for together); barrier"),
+                       (34, "tile zeroed; position, x.grad's old value and the flush nodes' {m,p} asked for"),
+                       (35, "position in, 27 node records (grid_v_out.grad, {m,p}) gathered, group reductions"), (36, "forward replay + dual chains of the primitives in range"),
+                       (37, "barrier; node scatter into the LDS tile, x.grad out"), (38, "barrier"), (39, "late global atomics, tile flushed through grid_op's node adjoint"),
+                       (40, "primitive-state adjoints out")],
 }
 
 
 def main(path):
     M = 1 << 64
     acc = {}
+    hist = {}
+    slow = {}
     for line in open(path):
         m, a, c = (int(v) for v in line.split())
+        if m == -1:                                # "-1 kernel*64+bin count": every wave's entry-to-exit time of the two contact kernels, bins of 1024 ticks
+            hist[a] = hist.get(a, 0) + c
+            continue
+        if m == -2:                                # "-2 record*8+word value": the slowest waves of k_contact_grad
+            slow[a] = c
+            continue
         s, n = acc.get(m, (0, 0))
         acc[m] = ((s + a) % M, n + c)
     for kern, marks in NAMES.items():
@@ -41,7 +55,25 @@ def main(path):
         for label, d, note in rows:
             print(f"   {d:10.0f} ticks  {100 * d / total:5.1f} %   {label}{note}")
         print(f"   {total:10.0f} ticks  per wave")
+    for k, kern in enumerate(("k_contact_hits", "k_contact_grad")):
+        bins = {b - 64 * k: c for b, c in hist.items() if 64 * k <= b < 64 * (k + 1)}
+        if bins:
+            n = sum(bins.values())
+            print(f"{kern}: entry-to-exit time of all {n} waves (a launch lasts as long as its slowest wave), k ticks: share of the waves")
+            print("   " + "  ".join(f"{b}{'+' if b == 63 else ''}k: {100 * c / n:.1f} %" for b, c in sorted(bins.items())))
+    slow_report(slow)
+
+
+def slow_report(slow):
+    n = (max(slow) + 1) // 8 if slow else 0
+    if n:
+        print(f"k_contact_grad: {n} waves over 36,000 ticks (the first 256 recorded): ticks entry-to-exit | workgroup wave | band masks of the wave's two hits | hit count | "
+              "ticks from entry to: loads in, nodes gathered, chains done, tile scattered + barrier, flushed")
+    for r in range(n):
+        w = [slow.get(8 * r + q, 0) for q in range(8)]
+        print(f"   {w[0]:6d} | wg {w[1] & 0xffff:4d} wave {(w[1] >> 16) & 0xff} | {(w[1] >> 24) & 0xff:#04x} {(w[1] >> 32) & 0xff:#04x} | {w[2]:5d} | " + " ".join(f"{v:6d}" for v in w[3:8]))
 
 
 if __name__ == "__main__":
     main(sys.argv[1])
+

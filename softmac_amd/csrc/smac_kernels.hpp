@@ -310,6 +310,25 @@ template <class R> __device__ __forceinline__ void gatomic(Vec4<R>* base, unsign
 #endif
 }
 
+// Flush of a workgroup's node sums onto a grid field, a node's four words in four NEIGHBOURING LANES of one atomic instruction.  The memory side of the fabric performs
+// the adds that reach one 128-byte line one REQUEST after the other (about 10 ns each, whatever the number of lanes in it: tools/microbench/atomic_chain.hip), and a
+// launch lasts until the last one is done.  One lane per node and one instruction per word sends a line of 8 nodes FOUR requests per workgroup; this sends it one or
+// two (microbenchmark, 64 workgroups on the same 216 nodes: 7.4 -> 3.2 us; 256: 25.8 -> 7.4).  stage / cells: BLOCK * 4 values and BLOCK cell indices in LDS.
+// Every thread of the workgroup calls it (two barriers inside) with its node's sum (all zero: nothing to add).
+template <class R> __device__ __forceinline__ void flush_nodes_by_lanes(Vec4<R>* field, const Vec4<R>& o, unsigned cell, R* stage, unsigned* cells) {
+    const int t = threadIdx.x;
+    stage[4 * t + 0] = o.x; stage[4 * t + 1] = o.y; stage[4 * t + 2] = o.z; stage[4 * t + 3] = o.w;
+    cells[t] = cell;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = (t & ~63) + 16 * q + ((t & 63) >> 2), c = t & 3;
+        const R v = stage[4 * n + c];
+        if (v != R(0)) gatomic(field, cells[n], c, v);
+    }
+    __syncthreads();
+}
+
 template <class R> __device__ __forceinline__ R wave_sum(R v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -1310,6 +1329,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
     typedef typename pos_of<R>::type PX;
     __shared__ tile_t ctile[3 * TILE_WORDS];
     __shared__ double ext_acc[MAX_PRIMS * 6];
+    __shared__ R fl_val[BLOCK * 4];                     // the flush's staging (flush_nodes_by_lanes)
+    __shared__ unsigned fl_cell[BLOCK];
     // (tail reduction: no k_grid_op launch - forward_kinematics to frame f + 1 and the emptying of the next substep's hit counter ride here instead)
     if (D.fk_ride > 0 && blockIdx.x == gridDim.x - 1) {
         if ((int)threadIdx.x < D.fk_ride) prim_fk_step(D.prim_state + threadIdx.x * D.fk_stride, f, D.dt64);
@@ -1433,18 +1454,17 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         __syncthreads();
         if (is_late) { gatomic(D.vout, cell, 0, late[0]); gatomic(D.vout, cell, 1, late[1]); gatomic(D.vout, cell, 2, late[2]); }
         {
-            const int nb = D.nb;
-            const int bz = wg_block % nb, by = (wg_block / nb) % nb, bx = wg_block / (nb * nb);
-            for (int idx = threadIdx.x; idx < TILE_WORDS; idx += BLOCK) {
-                const R a0 = (R)ctile[idx], a1 = (R)ctile[TILE_WORDS + idx], a2 = (R)ctile[2 * TILE_WORDS + idx];
-                if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
-                    const int li = idx / TSX, lj = (idx / TSY) % TW, lk = idx % TW;
-                    const unsigned c2 = (unsigned)cell_of(nb, 4 * bx + li, 4 * by + lj, 4 * bz + lk);
-                    gatomic(D.vout, c2, 0, a0); gatomic(D.vout, c2, 1, a1); gatomic(D.vout, c2, 2, a2);
-                }
+            static_assert(TILE_WORDS <= BLOCK, "one tile node per thread in the flush");
+            Vec4<R> o = {R(0), R(0), R(0), R(0)};
+            unsigned c2 = 0u;
+            if (threadIdx.x < TILE_WORDS) {
+                const int nb = D.nb, idx = threadIdx.x;
+                const int bz = wg_block % nb, by = (wg_block / nb) % nb, bx = wg_block / (nb * nb);
+                o = Vec4<R>{(R)ctile[idx], (R)ctile[TILE_WORDS + idx], (R)ctile[2 * TILE_WORDS + idx], R(0)};
+                if (o.x != R(0) || o.y != R(0) || o.z != R(0)) c2 = (unsigned)cell_of(nb, 4 * bx + idx / TSX, 4 * by + (idx / TSY) % TW, 4 * bz + idx % TW);
             }
+            flush_nodes_by_lanes(D.vout, o, c2, fl_val, fl_cell);                             // (its closing barrier: the tile may be zeroed again)
         }
-        if (base + nwg * WG_HITS < nh) __syncthreads();                                     // (the tile is zeroed again only in a second round)
     }
     __syncthreads();
     if (threadIdx.x < D.P * 6 && ext_acc[threadIdx.x] != 0.0) atomic_add(D.ext_f + threadIdx.x, ext_acc[threadIdx.x]);
@@ -1976,6 +1996,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
     // hit (k_p2g appends a wave's hits contiguously, so the 8 nearly always share the block): neighbouring contact
     // particles hit the same few nodes and their global atomics would serialise on those cache lines
     __shared__ tile_t atile[3 * TILE_WORDS];
+    __shared__ R fl_val[BLOCK * 4];                     // the flush's staging (flush_nodes_by_lanes)
+    __shared__ unsigned fl_cell[BLOCK];
     __shared__ double jac[MAX_PRIMS * 4 * BLOCK];      // per primitive and lane: d(velocity out)/d(direction of the lane) and the ext_f adjoint's share (each lane reads only what it wrote)
     SMAC_WAVE_T0();
     SMAC_PHASE(32, wg * 8 < 1024);                // (entry; the first 128 workgroups hold hits in the bench scene)
@@ -2214,22 +2236,19 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
             if (DIRECT) { gatomic(D.ain, cell, 0, late[0]); gatomic(D.ain, cell, 1, late[1]); gatomic(D.ain, cell, 2, late[2]); gatomic(D.ain, cell, 3, late[3]); }
             else { gatomic(D.amix, cell, 0, late[0]); gatomic(D.amix, cell, 1, late[1]); gatomic(D.amix, cell, 2, late[2]); }
         }
-        if (threadIdx.x < TILE_WORDS) {
-            const int idx = threadIdx.x;
-            const R a0 = (R)atile[idx], a1 = (R)atile[TILE_WORDS + idx], a2 = (R)atile[2 * TILE_WORDS + idx];
-            if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
-                if (DIRECT) {
+        {
+            Vec4<R> o = {R(0), R(0), R(0), R(0)};
+            if (threadIdx.x < TILE_WORDS) {
+                const int idx = threadIdx.x;
+                const R a0 = (R)atile[idx], a1 = (R)atile[TILE_WORDS + idx], a2 = (R)atile[2 * TILE_WORDS + idx];
+                if (a0 != R(0) || a1 != R(0) || a2 != R(0)) {
                     R gn[3] = {a0, a1, a2};
-                    const Vec4<R> o = grid_op_node_adjoint(D, flush_in, flush_i, flush_j, flush_k, gn);
-                    if (o.x != R(0) || o.y != R(0) || o.z != R(0) || o.w != R(0)) {
-                        gatomic(D.ain, flush_cell, 0, o.x); gatomic(D.ain, flush_cell, 1, o.y); gatomic(D.ain, flush_cell, 2, o.z); gatomic(D.ain, flush_cell, 3, o.w);
-                    }
-                } else {
-                    gatomic(D.amix, flush_cell, 0, a0); gatomic(D.amix, flush_cell, 1, a1); gatomic(D.amix, flush_cell, 2, a2);
+                    if (DIRECT) o = grid_op_node_adjoint(D, flush_in, flush_i, flush_j, flush_k, gn);
+                    else o = Vec4<R>{a0, a1, a2, R(0)};
                 }
             }
+            flush_nodes_by_lanes(DIRECT ? D.ain : D.amix, o, flush_cell, fl_val, fl_cell);     // (its closing barrier: the tile may be zeroed again)
         }
-        if (base + nwg * WG_HITS < nh) __syncthreads();                                     // (the tile is zeroed again only in a second round)
         SMAC_WAVE_MARK(5);
         SMAC_PHASE(39, wg * 8 < 1024 && base == base0);        // late atomics, tile flushed through grid_op's node adjoint (global atomics)
     }

@@ -4,6 +4,7 @@
 //   k_same     G workgroups, lanes 0..W-1 of each add one double to word [lane] of ONE record            (what the kernels did through round 5)
 //   k_spread   the same, workgroup g aiming at record g % K of K records                                  (partial sums, folded by the reader)
 //   k_f32      G workgroups x 216 lanes add 4 floats each to node records; every run of `share` consecutive workgroups aims at the same 216 nodes
+//   k_f32_lanes  the same adds, the four words of a node in four neighbouring lanes of one instruction
 // Build + run: hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -o atomic_chain atomic_chain.hip && ./atomic_chain
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -18,6 +19,11 @@ __global__ void k_f32(float* dst, int share) {
         float* rec = dst + ((size_t)(blockIdx.x / share) * 216 + threadIdx.x) * 4;
         unsafeAtomicAdd(rec + 0, 1.f); unsafeAtomicAdd(rec + 1, 1.f); unsafeAtomicAdd(rec + 2, 1.f); unsafeAtomicAdd(rec + 3, 1.f);
     }
+}
+
+// the same adds with the four words of a node in four neighbouring LANES of one instruction (a line of 8 nodes gets ONE request per workgroup, not four)
+__global__ void k_f32_lanes(float* dst, int share) {
+    for (int q = threadIdx.x; q < 216 * 4; q += blockDim.x) unsafeAtomicAdd(dst + (size_t)(blockIdx.x / share) * 216 * 4 + q, 1.f);
 }
 
 template <class F> static float time_us(F launch, int reps = 200) {
@@ -49,9 +55,10 @@ int main() {
                        (t - empty) * 1e3f / (G / K), G / K);
             }
     for (int G : {64, 256})
-        for (int share : {1, 4, 16, 64}) {
+        for (int share : {1, 4, 16, 64, 256}) {
             const float t = time_us([&] { hipLaunchKernelGGL(k_f32, dim3(G), dim3(256), 0, 0, d32, share); });
-            printf("f32 adds: %3d workgroups x 216 nodes x 4 words, %2d workgroups per node set: %6.2f us per launch\n", G, share, t);
+            const float t2 = time_us([&] { hipLaunchKernelGGL(k_f32_lanes, dim3(G), dim3(256), 0, 0, d32, share); });
+            printf("f32 adds: %3d workgroups x 216 nodes x 4 words, %2d workgroups per node set: %6.2f us per launch; a node's words in neighbouring lanes: %6.2f us\n", G, share, t, t2);
         }
     return 0;
 }

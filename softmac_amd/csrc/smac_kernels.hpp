@@ -1452,7 +1452,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
             }
         }
         __syncthreads();
-        if (is_late) { gatomic(D.vout, cell, 0, late[0]); gatomic(D.vout, cell, 1, late[1]); gatomic(D.vout, cell, 2, late[2]); }
+        if (__syncthreads_or(is_late)) {                                                    // (hits of another block than the tile's: by lanes as the tile's)
+            const Vec4<R> lo = {late[0], late[1], late[2], R(0)};
+            flush_nodes_by_lanes(D.vout, lo, cell, fl_val, fl_cell);
+        }
         {
             static_assert(TILE_WORDS <= BLOCK, "one tile node per thread in the flush");
             Vec4<R> o = {R(0), R(0), R(0), R(0)};
@@ -2232,9 +2235,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
         __syncthreads();
         SMAC_WAVE_MARK(4);
         SMAC_PHASE(38, wg * 8 < 1024 && base == base0);        // barrier
-        if (is_late) {
-            if (DIRECT) { gatomic(D.ain, cell, 0, late[0]); gatomic(D.ain, cell, 1, late[1]); gatomic(D.ain, cell, 2, late[2]); gatomic(D.ain, cell, 3, late[3]); }
-            else { gatomic(D.amix, cell, 0, late[0]); gatomic(D.amix, cell, 1, late[1]); gatomic(D.amix, cell, 2, late[2]); }
+        if (__syncthreads_or(is_late)) {                       // (hits of another block than the tile's: all 27 nodes of such a hit come this way - by lanes as the tile's)
+            const Vec4<R> lo = {late[0], late[1], late[2], late[3]};
+            flush_nodes_by_lanes(DIRECT ? D.ain : D.amix, lo, cell, fl_val, fl_cell);
         }
         {
             Vec4<R> o = {R(0), R(0), R(0), R(0)};

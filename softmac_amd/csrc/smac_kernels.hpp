@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(BLOCK) void k_contact_hits(DevSim<R> D, int f) {
         }
         __syncthreads();                                                                    // tile zeroed everywhere
         R late[3] = {R(0), R(0), R(0)};                                                     // a node outside the tile: its global atomics leave AFTER the barrier below
-        bool is_late = false;                                                               // (a barrier waits for every memory operation of the wave, atomics included)
+        bool is_late = false;                                                               // (adds queued in the memory pipeline hold up their wave's next memory instruction, and with the wave everybody at a barrier)
         if (mask && d < 27 && has) {                                                        // mixed4, alpha = 2 (:437)
             const bool in_tile = h.block == wg_block && ((nd.okx >> ni) & (nd.oky >> nj) & (nd.okz >> nk) & 1) != 0;
             const int tw = (ni == 0 ? nd.tx[0] : (ni == 1 ? nd.tx[1] : nd.tx[2])) + (nj == 0 ? nd.ty[0] : (nj == 1 ? nd.ty[1] : nd.ty[2])) +
@@ -2188,8 +2188,8 @@ __global__ __launch_bounds__(BLOCK) void k_contact_grad(DevSim<R> D, int f, Grid
         SMAC_PHASE(36, wg * 8 < 1024 && base == base0);        // forward replay + dual chains of the primitives in range
         const R diff[3] = {(R)((double)v_tmp[0] - v_tgt[0]), (R)((double)v_tmp[1] - v_tgt[1]), (R)((double)v_tmp[2] - v_tgt[2])};
         __syncthreads();                                                                        // tile zeroed everywhere
-        R late[4] = {R(0), R(0), R(0), R(0)};                  // a node outside the tile: its global atomics leave AFTER the barrier below (a barrier waits for
-        bool is_late = false;                                  // every memory operation of the wave, atomics included)
+        R late[4] = {R(0), R(0), R(0), R(0)};                  // a node outside the tile: its global atomics leave AFTER the barrier below (queued adds hold up their
+        bool is_late = false;                                  // wave's next memory instruction, and with the wave everybody at a barrier)
         if (mask) {
             // adjoint of v_tmp = direct (mixed4) + through the chain (mixed3); mixed2.grad scatter by node
             const R gvt[3] = {(R)((double)gd[0] + g[0]), (R)((double)gd[1] + g[1]), (R)((double)gd[2] + g[2])};

@@ -1387,6 +1387,12 @@ template <class R> struct Sim final : ISim {
         else if (!strcmp(name, "comm_world")) *value = (comm || (comm_stub == 2 && ipc.shm)) ? (double)c_world : 0.0;   // ranks of this handle's LIVE communicator (0: none / aborted)
         else if (!strcmp(name, "comm_transport")) *value = comm ? 1.0 : ((comm_stub == 2 && ipc.shm) ? 2.0 : (comm_stub == 1 && sc.on ? 3.0 : 0.0));   // 1 RCCL, 2 IPC test link, 3 device-copy stub, 0 none
         else if (!strcmp(name, "contact_skips")) *value = (double)contact_skips;        // backward substeps that needed no contact adjoint launch (empty filed hit list)
+        else if (!strcmp(name, "max_hits")) {                                          // the longest contact hit list the checkpoint saves have filed so far (-1: none yet)
+            HIP_TRY(hipStreamSynchronize(stream));
+            int m = -1;
+            for (int i = 0; h_nhits && i < cfg.max_frames; ++i) m = h_nhits[i] > m ? h_nhits[i] : m;
+            *value = (double)m;
+        }
         else if (!strcmp(name, "hit_overflows")) *value = (double)hit_overflows;      // times a contact hit list did not fit its checkpoint slot (backward then repeats the band test)
         else if (!strcmp(name, "plasticity")) *value = (double)D.mat.plast;
         else if (!strcmp(name, "yield_ratio")) *value = (double)D.mat.yield_c;
@@ -1402,7 +1408,7 @@ template <class R> struct Sim final : ISim {
             }
             *value = (double)h;
         }
-        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | exchanges | comm_world | comm_transport | resorts | resort_moved | resort_far | cloth_hash_entries | plasticity | yield_ratio | mass_eps)");
+        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | max_hits | contact_skips | exchanges | comm_world | comm_transport | resorts | resort_moved | resort_far | cloth_hash_entries | plasticity | yield_ratio | mass_eps)");
         return SMAC_OK;
     }
     int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,
@@ -1680,9 +1686,11 @@ template <class R> struct Sim final : ISim {
     // checkpoint saves drop every frame's count into pinned host memory (h_nhits): the count of frame f itself when it has landed (backward: always), else the
     // largest count among the neighbouring frames (the contact set moves slowly), with a quarter on top.  Nothing known (no saves yet): the old 2,048.
     int contact_grid_env = getenv("SMAC_CONTACT_GRID_HINT") ? atoi(getenv("SMAC_CONTACT_GRID_HINT")) : 1;
+    int contact_grid_max = getenv("SMAC_CONTACT_GRID_MAX") ? atoi(getenv("SMAC_CONTACT_GRID_MAX")) : 0;      // > 0 (tests): never more workgroups than this - every one walks several rounds
     int contact_grad_grid(int f = -1, bool exact = false) const {
         const int per = (BLOCK / 64) * SMAC_HITS_PER_WAVE, all = (D.N + per - 1) / per;
-        const int cap = all < 2048 ? (all > 0 ? all : 1) : 2048;
+        int cap = all < 2048 ? (all > 0 ? all : 1) : 2048;
+        if (contact_grid_max > 0) return cap < contact_grid_max ? cap : contact_grid_max;
         if (!contact_grid_env || f < 0 || !h_nhits) return cap;
         const volatile int* seen = h_nhits;
         int hint = exact ? seen[f] : -1;

@@ -177,6 +177,27 @@ def test_grip_fixture_forecast_contact(precision):
     _compare_rollout(cfg, 1e-3, state, 3, specs, pstates, ext_f_grad=eg)
 
 
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+@pytest.mark.parametrize("batched", [False, True])
+def test_hit_list_walked_in_several_rounds_by_a_narrow_launch(precision, batched, monkeypatch):
+    """Round 5: the two hit-list kernels are launched as wide as the host-visible hit counts of the neighbouring frames say (softmac_hip.hip contact_grad_grid) and
+    walk the list with a grid stride - a list that grew past the estimate costs further rounds per workgroup (the next round's hit records asked for one round ahead,
+    the tile zeroed and flushed again).  SMAC_CONTACT_GRID_MAX=2 sends every hit of the fixture through that path: two workgroups of 8 hits per round."""
+    monkeypatch.setenv("SMAC_CONTACT_GRID_MAX", "2")
+    d = np.load(H.GOLDEN / "grip_state_2k.npz")
+    state = d["state"]
+    specs, pstates = _palm_scene(state, 5)
+    cfg = H.sim_cfg(len(state), n_grid=64, dt=2e-4, ptype=0, material_model=0, ground_friction=20.0, precision=precision)
+    seen = {}
+    real = H.build_engine
+    def build(*a, **k):
+        seen["sim"], prims = real(*a, **k)
+        return seen["sim"], prims
+    monkeypatch.setattr(H, "build_engine", build)
+    _compare_rollout(cfg, 1e-3, state, 4, specs, pstates, ext_f_grad=[np.full(6, 1e-2)], batched=batched)
+    assert seen["sim"].get_param("max_hits") > 16 * 3                    # (more than three rounds of the two workgroups)
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_a_primitive_out_of_reach_costs_no_contact_adjoint_launch(batched, monkeypatch):
     """Round 4: the hit count of every frame is filed with its grid checkpoint and copied to pinned host memory by the saving launch; substep_grad does

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-LIB_SORT_INTERVAL = 40        # the library's default re-sort interval (softmac_hip.hip: smac_config.sort_interval = 0)
+LIB_SORT_INTERVAL = 80        # the library's default re-sort interval (softmac_hip.hip: smac_config.sort_interval = 0)
 
 
 def baseline_metric():
@@ -436,7 +436,7 @@ def launch_check(args, world, rank):
 
 def window_plan(K, interval):
     """Windows of EXACTLY K substep pairs that advance through the episode, as many of them as it takes for the re-sorts inside them to have their
-    steady-state share: R * K is a multiple of the re-sort interval (so K = 20 at an interval of 40 alternates windows without and with a re-sort),
+    steady-state share: R * K is a multiple of the re-sort interval (so K = 20 at an interval of 80 has a re-sort in every fourth window),
     and R >= 8 so that the GPU's clocks have settled for most of them (the first two windows after a cold start run 5-8 % slower:
     profiles/r04_z_first_pass.txt).  Every window is timed and counted - nothing is dropped, `value` comes from their sum."""
     block = math.lcm(K, max(interval, 1)) // K

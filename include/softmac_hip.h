@@ -62,7 +62,7 @@ typedef struct smac_config {
     int32_t n_control;        /* cfg.n_controllers (:74-77) */
     int32_t n_primitives;     /* <= SMAC_MAX_PRIMS */
     int32_t rigid_velocity_control; /* 1: substep() advances primitive poses with forward_kinematics (:329-331, 367-369) */
-    int32_t sort_interval;    /* re-bin particles at most every this many substeps (0 = default 40; shortened by the library when
+    int32_t sort_interval;    /* re-bin particles at most every this many substeps (0 = default 80; shortened by the library when
                                  particles are fast enough to leave their block's halo sooner); no reference counterpart */
     int32_t flags;            /* bit 0: substep_grad recomputes the forward grid like the reference (:352-359) instead of
                                  restoring the copy saved by substep (DESIGN.md "grid checkpoint");

@@ -417,7 +417,8 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&d_tail_cnt, ((size_t)nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_tail_cnt, 0, ((size_t)nblocks + 1) * sizeof(int), stream));
         D.tail_cnt = d_tail_cnt;
-        sort_interval = c.sort_interval > 0 ? c.sort_interval : 40;      // (32 until the wide tiles of round 4: a particle that crosses a block face no longer costs its wave the slow path)
+        sort_interval = c.sort_interval > 0 ? c.sort_interval : 80;      // (32 until the wide tiles of round 4: a particle that crosses a block face no longer costs its wave the slow path;
+                                                                         //  40 until the end of round 5: the fused kernels' times are flat over 160 substeps of S-grip, profiles/r05_sort_interval.txt)
         HIP_TRY(hipMalloc((void**)&d_cell_count, D.G * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_vmax, sizeof(unsigned)));
         HIP_TRY(hipMalloc((void**)&d_vmax_part, ((size_t)D.Npad / 64 + 8) * sizeof(float)));

@@ -68,11 +68,12 @@ def test_window_plan_gives_the_resorts_their_steady_state_share():
     in 480 resident frames, so that windows without and with a re-sort appear in their steady-state proportion."""
     sys.path.insert(0, str(ROOT))
     import bench
-    for K, I in ((20, 40), (32, 40), (40, 40), (20, 20), (64, 40), (7, 40), (100, 40)):
+    for K, I in ((20, 40), (32, 40), (40, 40), (20, 20), (64, 40), (7, 40), (100, 40), (20, 80), (32, 80)):
         R = bench.window_plan(K, I)
         assert R >= 1 and (R * K) % I == 0, (K, I, R)
         assert R * K <= 480 or R == math.lcm(K, I) // K, (K, I, R)
-    assert bench.window_plan(20, 40) == 8 and bench.window_plan(32, 40) == 10          # the driver's flags, the default flags
+    assert bench.window_plan(20, 40) == 8 and bench.window_plan(32, 40) == 10          # the driver's flags, the default flags (rounds 4 - 5)
+    assert bench.window_plan(20, bench.LIB_SORT_INTERVAL) == 8 and bench.window_plan(32, bench.LIB_SORT_INTERVAL) == 10      # ... and at the library's default interval of today
     assert bench.window_plan(1000, 40) == 1                                           # one window is the least there is
 
 

@@ -847,13 +847,13 @@ def main():
             par = "1 gpu"
         elif strong:
             par = (f"strong scaling: the one {N}-particle scene cut into {world} x-slabs of one global {args.grid}^3 grid, balanced by particle count "
-                   f"({[c[0] for c in allc]} particles per rank); per substep neighbour-only RCCL send/recv of the 4 shared grid planes "
+                   f"({[c[0] for c in allc]} particles per rank); per substep neighbour-only send/recv of the 4 shared grid planes (over what: `transport`) "
                    f"(fwd: m,p + contact corrections; bwd: grid_v_out.grad + grid_v_mixed.grad; the two contact exchanges only across "
                    f"boundaries a gripper finger can reach - rank 0: {getattr(run, 'contact_sides_note', None)}); ext_f all-reduced per env step, "
                    f"primitive adjoints per window")
         else:
             par = (f"weak scaling: {world} x-slabs of one bar, {N} particles each; value counts every slab's substep; per substep "
-                   f"neighbour-only RCCL send/recv of 2 shared grid planes")
+                   f"neighbour-only send/recv of 2 shared grid planes (over what: `transport`)")
         out = {
             "metric": metric_name(args),
             "value": value, "unit": "substeps/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -875,7 +875,7 @@ def main():
             "multi_gpu_note": None if world == 1 else ("no N > 1 run on N GPUs existed when this code was committed: the in-library slab loop has run between two and three "
                                                          "ranks over the IPC test transport on one GPU (tests/test_slabs.py) and as a world-1 RCCL self exchange"),
             "repeats": len(walls), "aggregate": "mean", "ms_per_step_all": [round(1e3 * w / K, 5) for w in walls],
-            "spread": (max(walls) - min(walls)) / wall, "drift_repairs": int(sim.get_param("drift_repairs")), "resorts": int(sim.get_param("resorts")),
+            "spread": (max(walls) - min(walls)) / wall, "drift_repairs": int(sim.get_param("drift_repairs")), "resorts": int(sim.get_param("resorts")), "chunks": int(sim.get_param("chunks")),
             "device_ms_per_step": dev_ms / K,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": traffic_note,

@@ -38,12 +38,68 @@ constexpr unsigned RANK_BITS = (1u << (KMAX - 1)) - 1u;
 // per particle slot of an epoch: (cell << 5) | min(rank, 31) at the time of its binning
 __host__ __device__ __forceinline__ int cellrank_pack(int cell, int r) { return (int)(((unsigned)cell << 5) | (unsigned)(r < 31 ? r : 31)); }
 
+// ---- guests (round 5): a block's particles beyond a whole number of chunks are handed to a face neighbour with room ----
+// The fused particle kernels are limited by their workgroup slots: time = chunks x a chunk's lifetime / resident workgroups, and a chunk's lifetime hardly
+// depends on how many of its lanes hold a particle.  At 8 particles per cell a 4^3 block holds 400 ... 585: 512 nominal, so three blocks in ten need a THIRD chunk for
+// a few dozen particles.  Since the wide tiles (round 4) a particle whose stencil base lies ONE node outside its chunk's block runs on the fast path; so the
+// binning may pretend that a particle of the block's outermost cell layer sits in the neighbour's adjacent cell.  Pass 0 counts the blocks' particles, pass 0b lets
+// every block whose remainder over whole chunks is small reserve room in a face neighbour that keeps its chunk count, pass 1 (k_sort_rank) hands that many tickets
+// to particles of the layer that faces it.  Kernels, lists and maps see an ordinary binning; the guests have three cells of drift left before the halo ends.
+constexpr int DONATE_MAX = 96;      // largest remainder a block tries to hand over (its facing layer holds about a quarter of its particles)
+
+template <class R>
+__global__ void k_block_count(const R* x0, const R* x1, const R* x2, int N, int n, int nb, int* blk_count) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    typedef typename pos_of<R>::type PX;
+    const PX x[3] = {((const PX*)x0)[poff(p)], ((const PX*)x1)[poff(p)], ((const PX*)x2)[poff(p)]};
+    int b[3];
+    for (int d = 0; d < 3; ++d) {
+        const int v = pos_base(x[d], n);
+        b[d] = v < 0 ? 0 : (v > n - 3 ? n - 3 : v);
+    }
+    const int blk = block_of(nb, b[0], b[1], b[2]);
+    // the frame is in the order of the last binning: the lanes of a wave mostly share their block - one add for all that share the first lane's
+    const unsigned long long act = __ballot(1);
+    const int lead = __ffsll((long long)act) - 1;
+    const int b0 = __shfl(blk, lead, 64);
+    const unsigned long long same = __ballot(blk == b0);
+    if (blk != b0) atomicAdd(blk_count + blk, 1);
+    else if ((int)(threadIdx.x & 63) == lead) atomicAdd(blk_count + b0, __popcll(same));
+}
+__device__ __forceinline__ bool donor_candidate(int c) { const int r = c % CHUNK; return c > CHUNK && r > 0 && r <= DONATE_MAX && r * 6 <= c; }
+// direction d = 2 * axis + (0: towards +, 1: towards -)
+__global__ void k_donate_plan(int nblocks, int nb, const int* blk_count, int* incoming, int* don_dir, int* don_left) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    don_dir[b] = -1;
+    don_left[b] = 0;
+    const int c = blk_count[b];
+    if (!donor_candidate(c)) return;
+    const int r = c % CHUNK;
+    const int q[3] = {b / (nb * nb), (b / nb) % nb, b % nb};
+    for (int t = 0; t < 6; ++t) {
+        const int d = (t + b) % 6, ax = d >> 1, sg = (d & 1) ? -1 : 1;
+        int m[3] = {q[0], q[1], q[2]};
+        m[ax] += sg;
+        if (m[ax] < 0 || m[ax] >= nb) continue;
+        const int nbr = (m[0] * nb + m[1]) * nb + m[2];
+        const int cn = blk_count[nbr];
+        if (cn <= 0 || donor_candidate(cn)) continue;                                // (a block that gives does not take: its own remainder would only be replaced)
+        const int room = (cn + CHUNK - 1) / CHUNK * CHUNK - cn;
+        if (room < r) continue;
+        if (atomicAdd(incoming + nbr, r) + r <= room) { don_dir[b] = d; don_left[b] = r; return; }
+        atomicSub(incoming + nbr, r);
+    }
+}
+
 // pass 1: claim a rank in the particle's cell (see "ranks" above); the cell and the claim go to pass 2.
 // Also records the largest velocity component (float bits of a non-negative value order like unsigned ints): the
 // host turns it into the number of substeps the binning stays valid for.
 template <class R>
 __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, const R* v1, const R* v2, int N, int n, int nb,
-                            R inv_dx, int* cell_count, int* cell_out, int* tag_out, float* vmax_part, const int* cellrank_old) {
+                            R inv_dx, int* cell_count, int* cell_out, int* tag_out, float* vmax_part, const int* cellrank_old,
+                            const int* don_dir = nullptr, int* don_left = nullptr) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     float vm = 0.f;
     if (p < N) {
@@ -69,6 +125,15 @@ __global__ void k_sort_rank(const R* x0, const R* x1, const R* x2, const R* v0, 
     for (int d = 0; d < 3; ++d) {
         int v = pos_base(x[d], n);                       // the base of make_stencil_pos
         b[d] = v < 0 ? 0 : (v > n - 3 ? n - 3 : v);
+    }
+    if (don_dir) {                                                                   // guests: see k_donate_plan
+        const int blk = block_of(nb, b[0], b[1], b[2]);
+        const int d = don_dir[blk];
+        if (d >= 0) {
+            const int ax = d >> 1, sg = (d & 1) ? -1 : 1;
+            const int to = b[ax] + sg;
+            if ((b[ax] & 3) == (sg > 0 ? 3 : 0) && to >= 0 && to <= n - 3 && don_left[blk] > 0 && atomicSub(don_left + blk, 1) > 0) b[ax] = to;
+        }
     }
     const int cell = (int)cell_of(nb, b[0], b[1], b[2]);
     int tag;

@@ -202,6 +202,7 @@ template <class R> struct Sim final : ISim {
     float* d_vmax_part = nullptr;
     int *d_cell_count = nullptr, *d_bin = nullptr, *d_bin_start = nullptr, *d_key = nullptr, *d_slot = nullptr, *d_dest = nullptr;
     int *d_block_start = nullptr, *d_block_chunks = nullptr, *d_chunk_start = nullptr, *d_active_flag = nullptr, *d_active_start = nullptr;
+    int* d_guest = nullptr;          // 4 x (nblocks + 1): the blocks' particle counts, room reserved in them, direction and tickets of the blocks that hand particles over (smac_sort.hpp "guests")
     int* d_map = nullptr;
     void* d_cub = nullptr;
     size_t cub_bytes = 0;
@@ -284,7 +285,7 @@ template <class R> struct Sim final : ISim {
         for (auto& e : epoch_pool) free_epoch(e);
         hipFree(d_bin_mask); hipFree(d_over_prefix); hipFree(d_vmax); hipFree(d_vmax_part);
         hipFree(d_cell_count); hipFree(d_bin); hipFree(d_bin_start); hipFree(d_key); hipFree(d_slot); hipFree(d_dest);
-        hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start);
+        hipFree(d_block_start); hipFree(d_block_chunks); hipFree(d_chunk_start); hipFree(d_active_flag); hipFree(d_active_start); hipFree(d_guest);
         hipFree(d_map); hipFree(d_map_an); hipFree(d_cub); hipFree(tmp_frame); hipFree(tmp_frame2); hipFree(slab); hipFree(d_drift); hipFree(dense_tmp);
         for (PIdx* I : {&pi_target, &pi_cur}) { hipFree(I->cell_start); hipFree(I->count); hipFree(I->key); hipFree(I->ids); hipFree(I->slots); hipFree(I->pts); }
         hipFree(d_io); hipFree(ext_snap); hipFree(cloth_ext_snap);
@@ -431,6 +432,7 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMalloc((void**)&d_dest, D.Npad * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_map, D.Npad * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_block_start, (nblocks + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&d_guest, 4 * (size_t)(nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&d_block_chunks, (nblocks + 1) * sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_block_chunks, 0, (nblocks + 1) * sizeof(int), stream));        // (entry [nblocks] stays 0: the scans read one element past the blocks)
         HIP_TRY(hipMalloc((void**)&d_chunk_start, (nblocks + 1) * sizeof(int)));
@@ -1110,6 +1112,7 @@ template <class R> struct Sim final : ISim {
     int resorts_done = 0;
     long long epoch_serial = 0;
     int stable_ranks = getenv("SMAC_STABLE_RANKS") ? atoi(getenv("SMAC_STABLE_RANKS")) : 1;   // 0: every re-sort hands the ranks out afresh (round 2)
+    int guests_env = getenv("SMAC_GUESTS") ? atoi(getenv("SMAC_GUESTS")) : 1;                  // 0: every particle is binned in its own block (rounds 1 - 5)
     int sort_frame(int f, bool read_drift = false, bool allow_repair = true, const double* aos = nullptr, int cols = 0) {
         const int e_old = frame_epoch[f];
         gc_epochs();
@@ -1119,10 +1122,22 @@ template <class R> struct Sim final : ISim {
         R* Sf = D.S + (size_t)f * frame_scalars();
         HIP_TRY(hipMemsetAsync(d_cell_count, 0, D.G * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_bin + nbins, 0, sizeof(int), stream));
+        // guests (smac_sort.hpp): blocks hand their few particles beyond whole chunks to a face neighbour with room - fewer chunks, the unit the fused kernels pay for.
+        // Not with a sheet (its contact-face search culls the faces per chunk by the chunk's block) and not in the slab pieces (a guest of a boundary block would
+        // belong to the neighbour rank's planes); SMAC_GUESTS=0: off
+        const bool guests = guests_env && !D.cloth.present && !sc.on && D.N > 0;
+        int *g_count = d_guest, *g_in = d_guest + (nblocks + 1), *g_dir = d_guest + 2 * (size_t)(nblocks + 1), *g_left = d_guest + 3 * (size_t)(nblocks + 1);
+        if (guests) {
+            HIP_TRY(hipMemsetAsync(d_guest, 0, 2 * (size_t)(nblocks + 1) * sizeof(int), stream));
+            hipLaunchKernelGGL(k_block_count<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + rowbase(1, D.Npad)),
+                               (const R*)(Sf + rowbase(2, D.Npad)), D.N, D.n, D.nb, g_count);
+            hipLaunchKernelGGL(k_donate_plan, dim3(nblk(nblocks)), dim3(BLOCK), 0, stream, nblocks, D.nb, (const int*)g_count, g_in, g_dir, g_left);
+        }
         hipLaunchKernelGGL(k_sort_rank<R>, dim3(nblk(D.N)), dim3(BLOCK), 0, stream, (const R*)Sf, (const R*)(Sf + rowbase(1, D.Npad)),
                            (const R*)(Sf + rowbase(2, D.Npad)), (const R*)(Sf + rowbase(3, D.Npad)), (const R*)(Sf + rowbase(4, D.Npad)),
                            (const R*)(Sf + rowbase(5, D.Npad)), D.N, D.n, D.nb, D.inv_dx, d_cell_count, d_key, d_slot, d_vmax_part,
-                           (const int*)((e_old > 0 && stable_ranks && D.G <= ((size_t)1 << 26)) ? epochs[e_old].cellrank : nullptr));
+                           (const int*)((e_old > 0 && stable_ranks && D.G <= ((size_t)1 << 26)) ? epochs[e_old].cellrank : nullptr),
+                           guests ? (const int*)g_dir : (const int*)nullptr, guests ? g_left : (int*)nullptr);
         hipLaunchKernelGGL(k_bin_masks, dim3((nblocks + 3) / 4), dim3(BLOCK), 0, stream, nblocks, (const int*)d_cell_count, d_bin,
                            d_bin_mask, d_over_prefix, (const float*)d_vmax_part, nblk(D.N), (float*)d_vmax);
         int rc = scan(d_bin, d_bin_start, nbins + 1);
@@ -1388,6 +1403,7 @@ template <class R> struct Sim final : ISim {
         else if (!strcmp(name, "comm_world")) *value = (comm || (comm_stub == 2 && ipc.shm)) ? (double)c_world : 0.0;   // ranks of this handle's LIVE communicator (0: none / aborted)
         else if (!strcmp(name, "comm_transport")) *value = comm ? 1.0 : ((comm_stub == 2 && ipc.shm) ? 2.0 : (comm_stub == 1 && sc.on ? 3.0 : 0.0));   // 1 RCCL, 2 IPC test link, 3 device-copy stub, 0 none
         else if (!strcmp(name, "contact_skips")) *value = (double)contact_skips;        // backward substeps that needed no contact adjoint launch (empty filed hit list)
+        else if (!strcmp(name, "chunks")) *value = (double)D.nchunks;                  // work items (<= 256 particles of one block each) of the binning in use
         else if (!strcmp(name, "max_hits")) {                                          // the longest contact hit list the checkpoint saves have filed so far (-1: none yet)
             HIP_TRY(hipStreamSynchronize(stream));
             int m = -1;
@@ -1409,7 +1425,7 @@ template <class R> struct Sim final : ISim {
             }
             *value = (double)h;
         }
-        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | max_hits | contact_skips | exchanges | comm_world | comm_transport | resorts | resort_moved | resort_far | cloth_hash_entries | plasticity | yield_ratio | mass_eps)");
+        else REQUIRE(false, "get_param: unknown parameter (drift_repairs | hit_overflows | max_hits | chunks | contact_skips | exchanges | comm_world | comm_transport | resorts | resort_moved | resort_far | cloth_hash_entries | plasticity | yield_ratio | mass_eps)");
         return SMAC_OK;
     }
     int cloth_create(int nv, int nf, const int32_t* faces, int nn, const int32_t* nbr, const int8_t* nbr_dir, double friction, double softness,

@@ -28,7 +28,9 @@ def test_a_cloud_at_rest_keeps_every_slot_across_resorts(precision):
     assert H.rel_err(sim.get_x(3), state[:, :3]) < 1e-6                                   # (nothing moved: F = I, v = 0, no gravity)
 
 
-def test_a_drifting_cloud_is_re_binned_by_short_shifts():
+@pytest.mark.parametrize("guests", [0, 1])
+def test_a_drifting_cloud_is_re_binned_by_short_shifts(guests, monkeypatch):
+    monkeypatch.setenv("SMAC_GUESTS", str(guests))          # (1, the default since round 5: blocks hand their particles beyond whole chunks to a face neighbour)
     n_grid, N = 32, 20000
     cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, gravity=(0., -9.8, 0.), precision="float32", sort_interval=4, max_steps=16)
     state = H.make_cloud(N, n_grid, seed=6, lo=(0.3, 0.4, 0.3), hi=(0.6, 0.7, 0.6), v_std=0.05)
@@ -46,7 +48,9 @@ def test_a_drifting_cloud_is_re_binned_by_short_shifts():
     base = lambda x: np.clip((x * n_grid - 0.5).astype(np.int64), 0, n_grid - 3)
     changed = int((base(sim.get_x(4)) != base(sim.get_x(8))).any(axis=1).sum())
     print(f"          {changed} particles changed their cell between the two binnings")
-    assert 0 < changed < 0.2 * N and far <= changed
+    # (with guests: which particles of a block's facing layer take the tickets is settled by the order of their atomics, binning by binning - a guest of the last
+    #  binning that is none now, or the reverse, moves to another block's range: a few per block that hands particles over)
+    assert 0 < changed < 0.2 * N and (far <= changed if not guests else far <= changed + 0.05 * N)
     assert np.isfinite(sim.get_state(9)).all()
 
 

@@ -1123,9 +1123,9 @@ template <class R> struct Sim final : ISim {
         HIP_TRY(hipMemsetAsync(d_cell_count, 0, D.G * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(d_bin + nbins, 0, sizeof(int), stream));
         // guests (smac_sort.hpp): blocks hand their few particles beyond whole chunks to a face neighbour with room - fewer chunks, the unit the fused kernels pay for.
-        // Not with a sheet (its contact-face search culls the faces per chunk by the chunk's block) and not in the slab pieces (a guest of a boundary block would
-        // belong to the neighbour rank's planes); SMAC_GUESTS=0: off
-        const bool guests = guests_env && !D.cloth.present && !sc.on && D.N > 0;
+        // Not with a sheet (its contact-face search culls the faces per chunk by the chunk's block); SMAC_GUESTS=0: off.  (The slab pieces take it too: the planes a
+        // rank exchanges are grid nodes, whichever chunk a particle that touches them sits in.)
+        const bool guests = guests_env && !D.cloth.present && D.N > 0;
         int *g_count = d_guest, *g_in = d_guest + (nblocks + 1), *g_dir = d_guest + 2 * (size_t)(nblocks + 1), *g_left = d_guest + 3 * (size_t)(nblocks + 1);
         if (guests) {
             HIP_TRY(hipMemsetAsync(d_guest, 0, 2 * (size_t)(nblocks + 1) * sizeof(int), stream));

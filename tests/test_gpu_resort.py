@@ -90,3 +90,34 @@ def test_contact_counts_follow_the_frame_through_batches_and_a_backward_pass():
     sim2.run_substeps_grad(0, 5)
     sim2.run_substeps(0, 4)
     assert sim2.contact_counts()[0] == counts[3]
+
+
+@pytest.mark.parametrize("precision,tol", [("float64", 1e-10), ("float32", 2e-4)])
+def test_guests_cut_the_chunk_count_and_change_nothing_else(precision, tol, monkeypatch):
+    """Round 5 (smac_sort.hpp "guests"): the fused particle kernels are limited by their workgroup slots - time = chunks x a chunk's lifetime / resident workgroups.
+    At 8 particles per cell a 4^3 block holds about 512 +- 40: three blocks in ten need a third chunk for a few dozen particles.  The re-sort hands such a remainder
+    to a face neighbour with room (the particles of the block's outermost cell layer are binned one cell further: the wide tile takes a particle one node outside its
+    chunk's block on the fast path).  Here: a box at 8 per cell; fewer chunks with guests, the same states and gradients over substeps with a re-sort in between."""
+    n_grid, N = 32, 8 * 16 ** 3
+    state = H.make_cloud(N, n_grid, seed=11, lo=(0.252, 0.252, 0.252), hi=(0.752, 0.752, 0.752), v_std=0.05, C_std=0.5, F_std=0.005)
+    rng = np.random.default_rng(3)
+    gx = rng.standard_normal((N, 3))
+    out = {}
+    for guests in (0, 1):
+        monkeypatch.setenv("SMAC_GUESTS", str(guests))
+        cfg = H.sim_cfg(N, n_grid=n_grid, dt=2e-4, ptype=1, gravity=(0., -9.8, 0.), precision=precision, sort_interval=3, max_steps=8)
+        sim, _ = H.build_engine(cfg, 1e-3, [], None)
+        sim.reset(state)
+        sim.run_substeps(0, 6)                # re-binned at frames 3 (and 6)
+        chunks = sim.get_param("chunks")
+        sim.clear_grads()
+        sim.add_grad(6, gx=gx)
+        sim.run_substeps_grad(0, 6)
+        out[guests] = (chunks, sim.get_state(6), sim.get_grad(0))
+        assert sim.get_param("drift_repairs") == 0
+    (c0, s0, g0), (c1, s1, g1) = out[0], out[1]
+    print(f"\n[guests] {int(c0)} chunks -> {int(c1)}")
+    assert c1 <= 0.95 * c0
+    assert H.rel_err(s1, s0) < tol
+    for a, b in zip(g1, g0):
+        assert H.rel_err(a, b) < tol

@@ -201,7 +201,8 @@ int smac_set_param(smac_handle h, const char* name, double value);
 /* reads a parameter back; also "drift_repairs": how many times an epoch was recomputed because a particle out-ran its binning (no reference
  * counterpart: the reference's dense grid has no binning); "contact_skips": backward substeps that launched no contact adjoint because the hit list
  * filed with the frame's grid checkpoint was empty; "max_hits": the longest contact hit list filed so far (synchronises; -1: none filed yet - the
- * library sizes the two hit-list launches from these counts) */
+ * library sizes the two hit-list launches from these counts); "chunks": work items (<= 256 particles of one grid block each, one workgroup per item)
+ * of the binning in use */
 int smac_get_param(smac_handle h, const char* name, double* value);
 
 /* ---- cloth primitive: replaces soft_cloth/engine/primitive/primitive_cloth.py (Primitive_Cloth) and the contact bookkeeping of
